@@ -1,0 +1,197 @@
+"""ctypes front-end of the parity oracle (TEST INFRASTRUCTURE -- never imported by the product).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  It wraps
+
+  * oracle/liboracle.so        -- our C restatement (oracle/rq_oracle.c), and
+  * oracle/_ref/linscan_aqd.so -- the real reference scan compiled from
+                                  /root/reference/deps/src/linscan_aqd.cpp by oracle/Makefile
+                                  (present only if it was built in the build container).
+
+All arrays are numpy, C-contiguous, in the C views of the Julia layouts:
+  X [n][d] f32, centers [m][256][sub] f32 (== cat(C...,dims=3)), codes [n][m] u8 zero-based,
+  queries [nq][d] f32, outputs [nq][K].
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+_f32p = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build(with_ref=True):
+    """Compile liboracle.so (always) and oracle/_ref (only when /root/reference exists)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    if with_ref and os.path.isfile("/root/reference/deps/src/linscan_aqd.cpp"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.isfile(path):
+            build(with_ref=False)
+        _LIB = C.CDLL(path)
+        _LIB.oracle_linscan_aqd_query.restype = None
+        _LIB.oracle_linscan_aqd_query.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        _LIB.oracle_adc_lut.restype = None
+        _LIB.oracle_adc_lut.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _LIB.oracle_adc_distances.restype = None
+        _LIB.oracle_adc_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int, C.c_int, C.c_int]
+        _LIB.oracle_rotate_T.restype = None
+        _LIB.oracle_rotate_T.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64]
+        _LIB.oracle_encode_pq.restype = None
+        _LIB.oracle_encode_pq.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int64, C.c_int, C.c_int, C.c_int]
+        _LIB.oracle_encode_opq.restype = None
+        _LIB.oracle_encode_opq.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int64, C.c_int, C.c_int, C.c_int]
+        _LIB.oracle_splitarray.restype = None
+        _LIB.oracle_splitarray.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        _LIB.oracle_num_threads.restype = C.c_int
+    return _LIB
+
+
+def ref_available():
+    return os.path.isfile(os.path.join(_HERE, "_ref", "linscan_aqd.so"))
+
+
+def ref():
+    """The compiled reference linscan_aqd.so (deps/src/linscan_aqd.cpp:105-114)."""
+    global _REF
+    if _REF is None:
+        _REF = C.CDLL(os.path.join(_HERE, "_ref", "linscan_aqd.so"))
+        _REF.linscan_aqd_query.restype = None
+        _REF.linscan_aqd_query.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    return _REF
+
+
+def _c(a, dt):
+    a = np.ascontiguousarray(a, dtype=dt)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def num_threads():
+    return int(lib().oracle_num_threads())
+
+
+def splitarray(d, m):
+    off = np.zeros(m + 1, dtype=np.int32)
+    lib().oracle_splitarray(d, m, _ptr(off))
+    return off
+
+
+def _scan(fn, codes, centers, queries, K):
+    codes = _c(codes, np.uint8)
+    centers = _c(centers, np.float32)
+    queries = _c(queries, np.float32)
+    n, m = codes.shape
+    nq, d = queries.shape
+    assert centers.shape[0] == m and centers.shape[1] == 256
+    sub = centers.shape[2]
+    assert sub * m == d, "scan needs d % m == 0 (src/Linscan.jl:23)"
+    assert 1 <= K <= n
+    dists = np.zeros((nq, K), dtype=np.float32)
+    ids = np.zeros((nq, K), dtype=np.uint32)
+    fn(_ptr(dists), _ptr(ids), _ptr(codes), _ptr(centers), _ptr(queries),
+       n, nq, 8 * m, K, m, d, sub)
+    return dists, ids
+
+
+def linscan_aqd_query(codes, centers, queries, K):
+    """Our restatement.  Returns (dists [nq][K] f32, ids [nq][K] u32 zero-based)."""
+    return _scan(lib().oracle_linscan_aqd_query, codes, centers, queries, K)
+
+
+def ref_linscan_aqd_query(codes, centers, queries, K):
+    """The real reference (needs oracle/_ref/linscan_aqd.so)."""
+    return _scan(ref().linscan_aqd_query, codes, centers, queries, K)
+
+
+def adc_lut(centers, query):
+    centers = _c(centers, np.float32)
+    query = _c(query, np.float32)
+    m, h, sub = centers.shape
+    assert h == 256
+    lut = np.zeros((m, 256), dtype=np.float32)
+    lib().oracle_adc_lut(_ptr(lut), _ptr(centers), _ptr(query), m, sub)
+    return lut
+
+
+def adc_distances(codes, centers, query):
+    codes = _c(codes, np.uint8)
+    centers = _c(centers, np.float32)
+    query = _c(query, np.float32)
+    n, m = codes.shape
+    out = np.zeros(n, dtype=np.float32)
+    lib().oracle_adc_distances(_ptr(out), _ptr(codes), _ptr(centers), _ptr(query),
+                               n, m, centers.shape[2])
+    return out
+
+
+def rotate_T(R, X):
+    """RX = R'X in the C views: X [n][d], R [d][d] (Rc[i][k] = R[k,i]), RX [n][d]."""
+    R = _c(R, np.float32)
+    X = _c(X, np.float32)
+    n, d = X.shape
+    RX = np.zeros((n, d), dtype=np.float32)
+    lib().oracle_rotate_T(_ptr(RX), _ptr(R), _ptr(X), d, n)
+    return RX
+
+
+def encode_pq(X, C_cat, m, h, with_costs=False):
+    """codes [n][m] u8 zero-based.  C_cat: flat concat over subspaces of [h][sub_i] blocks
+    (for even splits simply centers [m][h][sub])."""
+    X = _c(X, np.float32)
+    Cc = _c(np.asarray(C_cat).reshape(-1), np.float32)
+    n, d = X.shape
+    assert Cc.size == h * d
+    codes = np.zeros((n, m), dtype=np.uint8)
+    costs = np.zeros((n, m), dtype=np.float32) if with_costs else None
+    lib().oracle_encode_pq(_ptr(codes), _ptr(costs) if with_costs else None, _ptr(X), _ptr(Cc),
+                           n, d, m, h)
+    return (codes, costs) if with_costs else codes
+
+
+def encode_opq(X, R, C_cat, m, h):
+    X = _c(X, np.float32)
+    R = _c(R, np.float32)
+    Cc = _c(np.asarray(C_cat).reshape(-1), np.float32)
+    n, d = X.shape
+    codes = np.zeros((n, m), dtype=np.uint8)
+    lib().oracle_encode_opq(_ptr(codes), _ptr(X), _ptr(R), _ptr(Cc), n, d, m, h)
+    return codes
+
+
+def eval_recall(ids_gnd, ids_predicted, k):
+    """src/Linscan.jl:196-234.  ids_gnd [nq], ids_predicted [nq][k] (C view of the k x nq
+    Julia matrix), same index base.  rank = position (1-based) of the ground-truth id if it
+    occurs EXACTLY once among the k predictions, else k+1; recall_at_i[R-1] = #{rank<=R}/nq."""
+    ids_gnd = np.asarray(ids_gnd).reshape(-1)
+    P = np.asarray(ids_predicted)[:, :k]
+    nq = P.shape[0]
+    assert nq == ids_gnd.shape[0]
+    hit = P == ids_gnd[:, None]
+    cnt = hit.sum(axis=1)
+    first = hit.argmax(axis=1) + 1
+    ranks = np.where(cnt == 1, first, k + 1)
+    hist = np.bincount(ranks, minlength=k + 2)[1:k + 1]
+    return np.cumsum(hist) / float(nq)

@@ -1,0 +1,12 @@
+"""Import alias: `import rayuela_jl_amd` loads the package directory `rayuela.jl_amd/`
+(a dot is not legal in a Python package name, the directory name is fixed by the project)."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rayuela.jl_amd")
+_spec = importlib.util.spec_from_file_location(
+    __name__, os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)
