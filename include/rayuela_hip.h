@@ -1,0 +1,133 @@
+/*
+ * rayuela_hip.h -- C ABI of librayuela_hip.so: MI355X (gfx950) PQ/OPQ encode + ADC linear scan.
+ *
+ * Drop-in boundary for Rayuela.jl's hot path.  Every entry point names the reference
+ * interface it replaces (paths relative to the Rayuela.jl repository):
+ *
+ *   src/Linscan.jl:19-23  ccall(("linscan_aqd_query", linscan_aqd), ...)  -> linscan_aqd_query
+ *   deps/src/linscan_aqd.cpp:105-114 (extern "C" symbol)                  -> linscan_aqd_query
+ *   src/Linscan.jl:5-37    linscan_pq                                     -> rq_linscan_pq
+ *   src/Linscan.jl:93-115  linscan_opq                                    -> rq_linscan_opq
+ *   src/PQ.jl:18-48        quantize_pq                                    -> rq_encode_pq[_i16]
+ *   src/OPQ.jl:19-27       quantize_opq  (R'X then quantize_pq)           -> rq_encode_opq[_i16], rq_rotate_T
+ *
+ * Array layouts are the C views of the Julia (column-major) arrays, so Julia passes its
+ * arrays as they are (zero-copy on the host side):
+ *   X, queries   Julia d x n   == C [n][d]   float
+ *   R            Julia d x d   == C [d][d]   with Rc[i][k] = R[k,i]
+ *   C (PQ)       Vector of m (sub_i x h) matrices, concatenated == C [m][h][sub] when d%m==0
+ *                (cat(C...,dims=3), src/Linscan.jl:22); for uneven splits (src/utils.jl:179-203)
+ *                the concatenation of the m [h][sub_i] blocks in order
+ *   codes        Julia m x n   == C [n][m]   uint8, ZERO-based (the scan's wire format,
+ *                src/Linscan.jl:35, demos/experiment_utils.jl:10,17)
+ *   dists, ids   Julia k x nq  == C [nq][k]  ascending per query
+ *
+ * Numerics contract: codes and ids are bit-exact with the CPU oracle; ADC
+ * distances are bit-exact with deps/src/linscan_aqd.cpp (unfused f32 LUT, sequential sum,
+ * lexicographic (dist,id) top-k).
+ *
+ * All int-returning functions return 0 on success, a negative RQ_E* code on argument
+ * errors and a positive hipError_t on HIP failures; rq_last_error() describes the last
+ * failure on the calling thread.  Host-pointer entry points are synchronous and keep no
+ * pointer after they return.  The library never falls back to a CPU path.
+ */
+#ifndef RAYUELA_HIP_H_
+#define RAYUELA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RQ_OK 0
+#define RQ_EINVAL (-1)      /* bad argument (message in rq_last_error) */
+#define RQ_EUNSUPPORTED (-2) /* shape outside what the kernels cover (h>256, LUT > LDS, ...) */
+#define RQ_ENODEVICE (-3)   /* no gfx950 device visible */
+
+#define RQ_MAX_K 16384      /* largest k the scan returns */
+
+const char *rq_version(void);
+const char *rq_last_error(void);
+int rq_device_count(void);
+/* Select the device used by the calling thread's subsequent calls (hipSetDevice). */
+int rq_set_device(int device);
+
+/* ---- legacy symbol: signature-identical to deps/src/linscan_aqd.cpp:107-113 -------------
+ * so the stock src/Linscan.jl:19-23 ccall works by pointing `linscan_aqd` at this library.
+ * Host pointers; ids zero-based (Julia adds 1, src/Linscan.jl:25).  B = 8*m bits, h = 256.
+ * Returns void like the reference; failures are reported on stderr and leave outputs zeroed. */
+void linscan_aqd_query(float *dists, unsigned int *res, unsigned char *codes, float *centers,
+                       float *queries, int N, unsigned int NQ, int B, int K, int dim1codes,
+                       int dim1queries, int subdim);
+
+/* ---- host-pointer entry points (what the julia/ shims ccall) ---------------------------------- */
+/* linscan_pq (src/Linscan.jl:5-26).  id_base = 1 folds Julia's `res .+= 1` into the kernel. */
+int rq_linscan_pq(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers,
+                  const float *queries, int64_t n, int64_t nq, int m, int d, int k, int id_base);
+/* linscan_opq (src/Linscan.jl:93-103): queries are rotated by R' on the device first. */
+int rq_linscan_opq(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers,
+                   const float *queries, const float *R, int64_t n, int64_t nq, int m, int d,
+                   int k, int id_base);
+/* quantize_pq (src/PQ.jl:18-48): codes [n][m] uint8 zero-based.  h <= 256. */
+int rq_encode_pq(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m, int h);
+/* quantize_opq (src/OPQ.jl:19-27). */
+int rq_encode_opq(uint8_t *codes, const float *X, const float *R, const float *C, int64_t n,
+                  int d, int m, int h);
+/* Same, but emitting Julia's return type directly: Int16, ONE-based, m x n (src/PQ.jl:45-47). */
+int rq_encode_pq_i16(int16_t *codes1, const float *X, const float *C, int64_t n, int d, int m,
+                     int h);
+int rq_encode_opq_i16(int16_t *codes1, const float *X, const float *R, const float *C, int64_t n,
+                      int d, int m, int h);
+/* RX = R' * X (src/OPQ.jl:26, src/Linscan.jl:102). */
+int rq_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n);
+
+/* ---- device-pointer entry points: asynchronous on `stream` (a hipStream_t, NULL = default).
+ * All pointers are device pointers on the current device, 16-byte aligned. ------------------ */
+int rq_dev_encode_pq(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m,
+                     int h, void *stream);
+int rq_dev_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n, void *stream);
+/* Fused rotate+encode is an implementation detail; tmp may be NULL (library workspace). */
+int rq_dev_encode_opq(uint8_t *codes, const float *X, const float *R, const float *C, int64_t n,
+                      int d, int m, int h, void *stream);
+/* Per-query ADC look-up tables lut [nq][m][256] (deps/src/linscan_aqd.cpp:66-74); test aid. */
+int rq_dev_adc_lut(float *lut, const float *centers, const float *queries, int64_t nq, int m,
+                   int subdim, void *stream);
+/* The ADC scan + exact top-k over one resident shard of n rows.
+ *   dists/ids [nq][k] (may both be NULL when keys != NULL)
+ *   keys      [nq][k] uint64 or NULL: sorted packed (ordered-dist << 32 | id) per query, the
+ *             form exchanged between shards/GPUs and consumed by rq_dev_merge_topk
+ *   id_offset added to every row index (global id of the shard's first row)
+ *   id_base   0 or 1, added to ids written to `ids` only (keys stay zero-based)           */
+int rq_dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes,
+                   const float *centers, const float *queries, int64_t n, int64_t nq, int m,
+                   int d, int k, uint32_t id_offset, int id_base, void *stream);
+/* Merge P sorted key lists per query: keys_in [nq][P][k] -> dists/ids [nq][k] (and/or
+ * keys_out [nq][k]).  Total order on (dist,id) makes the result identical to a single scan. */
+int rq_dev_merge_topk(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t *keys_in,
+                      int64_t nq, int P, int k, int id_base, void *stream);
+/* code[i][j] = splitmix64(seed ^ ((row0+i)*m+j)) >> 56 : SIFT1B-shape synthetic shard. */
+int rq_dev_synth_codes(uint8_t *codes, int64_t n, int m, uint64_t seed, int64_t row0, void *stream);
+
+/* ---- device-resident index handle (codes uploaded once; used by the Julia shim's
+ * optional fast path and by multi-GPU deployments, one handle per process/GPU) ------------- */
+typedef struct rq_index rq_index;
+rq_index *rq_index_create(int m, int d, const float *centers_host);
+int rq_index_set_codes(rq_index *ix, const uint8_t *codes_host, int64_t n, uint32_t id_offset);
+int rq_index_search(rq_index *ix, float *dists, uint32_t *ids, const float *queries_host,
+                    int64_t nq, int k, int id_base);
+void rq_index_destroy(rq_index *ix);
+
+/* Diagnostic knob used by tests and tuning runs (same effect as env RQ_<KEY>):
+ *   SCAN_SLICES  force the number of row slices per shard (0 = automatic)
+ *   ENC_WAVES    wavefronts per encode workgroup (4 or 8) */
+int rq_set_tuning(const char *key, int value);
+
+/* Milliseconds spent in the last host-pointer call on this thread: total wall, H2D, kernels
+ * (hipEvent), D2H -- so the PCIe-inclusive and the resident rates can both be reported. */
+int rq_last_timing(double *total_ms, double *h2d_ms, double *kernel_ms, double *d2h_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYUELA_HIP_H_ */

@@ -1,0 +1,102 @@
+"""Host mirror of src/Linscan.jl: linscan_pq, linscan_opq, eval_recall."""
+import numpy as np
+
+from . import _lib
+from .utils import _as_f32
+
+
+def _codes_u8(B):
+    B = np.asarray(B)
+    if B.dtype == np.uint8:
+        return np.ascontiguousarray(B)  # already the zero-based wire format (src/Linscan.jl:5-10)
+    if not np.issubdtype(B.dtype, np.integer):
+        raise TypeError("B must be an integer array")
+    Bm1 = B.astype(np.int64) - 1  # src/Linscan.jl:35  convert(Matrix{UInt8}, B .- 1)
+    if Bm1.min(initial=0) < 0 or Bm1.max(initial=0) > 255:
+        raise OverflowError("InexactError: a one-based code outside 1..256 does not fit UInt8")
+    return np.ascontiguousarray(Bm1.astype(np.uint8))
+
+
+def _centers(C, m, d):
+    sub = d // m
+    arr = np.stack([_as_f32(c, "C[i]") for c in C])
+    if arr.shape != (m, 256, sub):
+        raise ValueError("linscan needs m codebooks of shape (256, d/m); got %s" % (arr.shape,))
+    return np.ascontiguousarray(arr)  # == cat(C..., dims=3), src/Linscan.jl:22
+
+
+def linscan_pq(B, X, C, b, k=10000):
+    """linscan_pq(B, X, C, b, k=10000) -> dists, idx          (src/Linscan.jl:5-37)
+
+    B : (n, m) uint8 zero-based codes, or any other integer dtype holding ONE-based codes
+    X : (nq, d) float32 queries;  C : list of m (256, d/m) codebooks;  b = log2(h) * m
+    Returns dists (nq, k) float32 ascending and idx (nq, k) uint32, ONE-based like the reference.
+    """
+    Bu = _codes_u8(B)
+    X = _as_f32(X, "X")
+    n, m = Bu.shape
+    nq, d = X.shape
+    if d % m:
+        raise ValueError("InexactError: Cint(d/m) with d=%d m=%d (src/Linscan.jl:23)" % (d, m))
+    if b != 8 * m:
+        raise ValueError("b must be log2(256)*m = %d" % (8 * m))
+    cen = _centers(C, m, d)
+    dists = np.zeros((nq, k), dtype=np.float32)
+    idx = np.zeros((nq, k), dtype=np.uint32)
+    _lib.check(_lib.lib().rq_linscan_pq(dists.ctypes.data, idx.ctypes.data, Bu.ctypes.data, cen.ctypes.data,
+                                        X.ctypes.data, n, nq, m, d, k, 1))
+    return dists, idx
+
+
+def linscan_opq(B, X, C, b, R, k=10000):
+    """linscan_opq(B, X, C, b, R, k=10000)   (src/Linscan.jl:93-115) == linscan_pq(B, R'X, C, b, k)."""
+    Bu = _codes_u8(B)
+    X = _as_f32(X, "X")
+    R = _as_f32(R, "R")
+    n, m = Bu.shape
+    nq, d = X.shape
+    if d % m:
+        raise ValueError("InexactError: Cint(d/m) with d=%d m=%d" % (d, m))
+    if b != 8 * m:
+        raise ValueError("b must be log2(256)*m = %d" % (8 * m))
+    cen = _centers(C, m, d)
+    dists = np.zeros((nq, k), dtype=np.float32)
+    idx = np.zeros((nq, k), dtype=np.uint32)
+    _lib.check(_lib.lib().rq_linscan_opq(dists.ctypes.data, idx.ctypes.data, Bu.ctypes.data, cen.ctypes.data,
+                                         X.ctypes.data, R.ctypes.data, n, nq, m, d, k, 1))
+    return dists, idx
+
+
+def linscan_aqd_query(codes, centers, queries, K):
+    """The raw C symbol of deps/src/linscan_aqd.cpp:105-114 (zero-based ids), as Linscan.jl ccalls it."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    centers = np.ascontiguousarray(centers, dtype=np.float32)
+    queries = np.ascontiguousarray(queries, dtype=np.float32)
+    n, m = codes.shape
+    nq, d = queries.shape
+    dists = np.zeros((nq, K), dtype=np.float32)
+    res = np.zeros((nq, K), dtype=np.uint32)
+    _lib.lib().linscan_aqd_query(dists.ctypes.data, res.ctypes.data, codes.ctypes.data, centers.ctypes.data,
+                                 queries.ctypes.data, n, nq, 8 * m, K, m, d, d // m)
+    return dists, res
+
+
+def eval_recall(ids_gnd, ids_predicted, k, verbose=True):
+    """eval_recall(gt, idx, k) -> recall_at_i     (src/Linscan.jl:196-234)
+
+    rank_i = position of gt[i] in idx[i, :k] if it occurs exactly once, else k+1;
+    recall_at_i[R-1] = #{rank <= R} / nq.  Prints r@{1,2,5,...} * 100 like the reference."""
+    ids_gnd = np.asarray(ids_gnd).reshape(-1)
+    P = np.asarray(ids_predicted)[:, :k]
+    nq = P.shape[0]
+    assert nq == ids_gnd.shape[0]
+    hit = P == ids_gnd[:, None]
+    cnt = hit.sum(axis=1)
+    ranks = np.where(cnt == 1, hit.argmax(axis=1) + 1, k + 1)
+    hist = np.bincount(ranks, minlength=k + 2)[1:k + 1]
+    recall = np.cumsum(hist) / float(nq)
+    if verbose:
+        for i in (1, 2, 5, 10, 20, 50, 100, 200, 500, 1000, 2000, 5000, 10000):
+            if i <= k:
+                print("r@%d = %s" % (i, recall[i - 1] * 100))
+    return recall

@@ -1,0 +1,41 @@
+"""Host mirror of src/PQ.jl (encode only): same name, argument order and return convention."""
+import numpy as np
+
+from . import _lib
+from .utils import _as_f32, cat_codebooks
+
+
+def quantize_pq(X, C, V=False):
+    """quantize_pq(X, C, V=false) -> B          (src/PQ.jl:18-48)
+
+    X : (n, d) float32 -- the memory image of Julia's d-by-n matrix
+    C : list of m arrays (h, sub_i) float32 -- memory images of the sub_i-by-h codebooks
+    Returns B : (n, m) int16, ONE-based codes (memory image of Julia's m-by-n Matrix{Int16}).
+    """
+    X = _as_f32(X, "X")
+    n, d = X.shape
+    m = len(C)
+    h = np.asarray(C[0]).shape[0]
+    Cc = cat_codebooks(C)
+    if Cc.size != h * d:
+        raise ValueError("codebooks do not tile the %d dimensions of X" % d)
+    if V:
+        print("Encoding on %d codebooks with librayuela_hip... " % m, end="")
+    B = np.empty((n, m), dtype=np.int16)
+    _lib.check(_lib.lib().rq_encode_pq_i16(B.ctypes.data, X.ctypes.data, Cc.ctypes.data, n, d, m, h))
+    if V:
+        print("done")
+    return B
+
+
+def quantize_pq_u8(X, C):
+    """Same encode, returning the zero-based uint8 wire format the scan consumes
+    (convert(Matrix{UInt8}, B .- 1), src/Linscan.jl:35)."""
+    X = _as_f32(X, "X")
+    n, d = X.shape
+    m = len(C)
+    h = np.asarray(C[0]).shape[0]
+    Cc = cat_codebooks(C)
+    B = np.empty((n, m), dtype=np.uint8)
+    _lib.check(_lib.lib().rq_encode_pq(B.ctypes.data, X.ctypes.data, Cc.ctypes.data, n, d, m, h))
+    return B

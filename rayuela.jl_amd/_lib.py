@@ -1,0 +1,93 @@
+"""ctypes binding of librayuela_hip.so -- the ONLY compute backend of this package.
+
+There is no CPU fallback: if the library is missing or cannot be loaded this module raises,
+and every wrapper raises RayuelaHipError on a non-zero status (message from rq_last_error()).
+The binding mirrors include/rayuela_hip.h one to one.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class RayuelaHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.environ.get("RAYUELA_HIP_LIB", os.path.join(_HERE, "librayuela_hip.so"))
+
+
+_vp, _i32, _i64, _u32, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64
+
+# name -> (restype, argtypes); kept in sync with include/rayuela_hip.h (tests/test_cabi.py checks it)
+SIGNATURES = {
+    "rq_version": (C.c_char_p, []),
+    "rq_last_error": (C.c_char_p, []),
+    "rq_device_count": (_i32, []),
+    "rq_set_device": (_i32, [_i32]),
+    "linscan_aqd_query": (None, [_vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i32, _i32, _i32, _i32, _i32]),
+    "rq_linscan_pq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32]),
+    "rq_linscan_opq": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32]),
+    "rq_encode_pq": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32]),
+    "rq_encode_opq": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32]),
+    "rq_encode_pq_i16": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32]),
+    "rq_encode_opq_i16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32]),
+    "rq_rotate_T": (_i32, [_vp, _vp, _vp, _i32, _i64]),
+    "rq_dev_encode_pq": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "rq_dev_rotate_T": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp]),
+    "rq_dev_encode_opq": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "rq_dev_adc_lut": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "rq_dev_linscan": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _u32, _i32, _vp]),
+    "rq_dev_merge_topk": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "rq_dev_synth_codes": (_i32, [_vp, _i64, _i32, _u64, _i64, _vp]),
+    "rq_index_create": (_vp, [_i32, _i32, _vp]),
+    "rq_index_set_codes": (_i32, [_vp, _vp, _i64, _u32]),
+    "rq_index_search": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32]),
+    "rq_index_destroy": (None, [_vp]),
+    "rq_set_tuning": (_i32, [C.c_char_p, _i32]),
+    "rq_last_timing": (_i32, [_vp, _vp, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load the shared library (once).  Raises RayuelaHipError if it is not there."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.isfile(path):
+            raise RayuelaHipError(
+                "librayuela_hip.so not found at %s -- build it with `make -C rayuela.jl_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback" % path)
+        try:
+            # torch (when used for device memory / RCCL) bundles its own libamdhip64.so.7: importing it
+            # first makes both sides share ONE HIP runtime, so device pointers are interchangeable.
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the pure host-pointer API
+            pass
+        handle = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here == ABI mismatch; let it surface
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def check(status):
+    if status != 0:
+        msg = lib().rq_last_error().decode("utf-8", "replace")
+        raise RayuelaHipError("librayuela_hip status %d: %s" % (status, msg))
+
+
+def set_tuning(key, value):
+    check(lib().rq_set_tuning(key.encode(), int(value)))
+
+
+def last_timing():
+    t = (C.c_double * 4)()
+    p = [C.cast(C.byref(t, 8 * i), C.c_void_p) for i in range(4)]
+    lib().rq_last_timing(*p)
+    return dict(total_ms=t[0], h2d_ms=t[1], kernel_ms=t[2], d2h_ms=t[3])

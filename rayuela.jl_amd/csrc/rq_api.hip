@@ -1,0 +1,451 @@
+// rq_api.hip -- the C ABI of librayuela_hip.so (include/rayuela_hip.h): argument checks,
+// device buffers, H2D/D2H for the host-pointer entry points, the legacy linscan_aqd_query symbol.
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <mutex>
+#include <string>
+
+#include "rq_internal.h"
+
+namespace rq {
+
+static thread_local char g_err[512] = "";
+static thread_local double g_t_total = 0, g_t_h2d = 0, g_t_kernel = 0, g_t_d2h = 0;
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int fail_hip(hipError_t e, const char *what, const char *file, int line) {
+  snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d in `%s`", (int)e, hipGetErrorString(e), file,
+           line, what);
+  (void)hipGetLastError();
+  return (int)e > 0 ? (int)e : 1;
+}
+
+// ---- tuning knobs: env RQ_<KEY>, or rq_set_tuning() ---------------------------------------------
+struct Knob { char key[32]; int value; };
+static Knob g_knobs[16];
+static int g_nknobs = 0;
+static std::mutex g_mu;
+
+int tuning(const char *key, int dflt) {
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int i = 0; i < g_nknobs; ++i)
+      if (!strcmp(g_knobs[i].key, key)) return g_knobs[i].value;
+  }
+  std::string env = std::string("RQ_") + key;
+  const char *v = getenv(env.c_str());
+  return v ? atoi(v) : dflt;
+}
+
+// ---- device context -----------------------------------------------------------------------------
+struct DevCtx {
+  bool inited = false;
+  DeviceInfo info;
+  void *ws[WS_SLOTS] = {nullptr};
+  size_t ws_bytes[WS_SLOTS] = {0};
+};
+static DevCtx g_dev[16];
+
+int device_info(DeviceInfo *out) {
+  int dev = 0;
+  RQ_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return fail(RQ_ENODEVICE, "device ordinal %d out of range", dev);
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevCtx &c = g_dev[dev];
+  if (!c.inited) {
+    hipDeviceProp_t prop;
+    RQ_HIP(hipGetDeviceProperties(&prop, dev));
+    c.info.device = dev;
+    c.info.num_cu = prop.multiProcessorCount;
+    strncpy(c.info.arch, prop.gcnArchName, sizeof(c.info.arch) - 1);
+    c.info.arch[sizeof(c.info.arch) - 1] = 0;
+    if (strncmp(c.info.arch, "gfx950", 6) != 0)
+      return fail(RQ_ENODEVICE, "librayuela_hip is built for gfx950 (MI355X); device %d is %s", dev, c.info.arch);
+    c.inited = true;
+  }
+  *out = c.info;
+  return RQ_OK;
+}
+
+int workspace(int slot, size_t bytes, void **ptr) {
+  int dev = 0;
+  RQ_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevCtx &c = g_dev[dev];
+  if (c.ws_bytes[slot] < bytes) {
+    if (c.ws[slot]) {
+      RQ_HIP(hipDeviceSynchronize());
+      RQ_HIP(hipFree(c.ws[slot]));
+      c.ws[slot] = nullptr;
+      c.ws_bytes[slot] = 0;
+    }
+    size_t want = bytes + bytes / 4;
+    want = (want + 255) & ~(size_t)255;
+    RQ_HIP(hipMalloc(&c.ws[slot], want));
+    c.ws_bytes[slot] = want;
+  }
+  *ptr = c.ws[slot];
+  return RQ_OK;
+}
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) {
+    RQ_HIP(hipMalloc(&p, bytes ? bytes : 16));
+    return RQ_OK;
+  }
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+struct Timer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double ms() const {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+};
+
+// ---- shared implementation of the scan on device pointers --------------------------------------------
+static int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes, const float *centers,
+                       const float *queries, int64_t n, int64_t nq, int m, int d, int k, uint32_t id_offset,
+                       int id_base, hipStream_t stream) {
+  if (nq <= 0) return RQ_OK;
+  if (n < 1 || n >= (1LL << 31)) return fail(RQ_EINVAL, "n=%lld must be in [1, 2^31)", (long long)n);
+  if (m < 1 || d < m || d % m != 0)
+    return fail(RQ_EINVAL, "scan needs d %% m == 0 (src/Linscan.jl:23 Cint(d/m)); got d=%d m=%d", d, m);
+  if (k < 1 || k > RQ_MAX_K) return fail(RQ_EUNSUPPORTED, "k=%d outside [1, %d]", k, RQ_MAX_K);
+  if (k > n) return fail(RQ_EINVAL, "k=%d > n=%lld (undefined in the reference, deps/src/linscan_aqd.cpp:91)", k, (long long)n);
+  if ((uint64_t)id_offset + (uint64_t)n > 0xFFFFFFFFull) return fail(RQ_EINVAL, "row ids overflow uint32");
+  if (id_base != 0 && id_base != 1) return fail(RQ_EINVAL, "id_base must be 0 or 1");
+  if (!keys && (!dists || !ids)) return fail(RQ_EINVAL, "need dists+ids or keys");
+  if (((uintptr_t)codes & 15) != 0) return fail(RQ_EINVAL, "codes pointer must be 16-byte aligned");
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  ScanPlan pl;
+  RQ_TRY(scan_plan(pl, n, nq, m, d, k, di.num_cu, tuning("SCAN_SLICES", 0)));
+  void *cand = nullptr, *counter = nullptr;
+  RQ_TRY(workspace(WS_CAND, pl.cand_bytes, &cand));
+  RQ_TRY(workspace(WS_COUNTER, 256, &counter));
+  const bool direct = (pl.nslices == 1);
+  if (direct) {
+    // one slice: the scan kernel writes the final answer itself
+    if (keys && (dists || ids)) {
+      RQ_TRY(scan_launch(pl, nullptr, nullptr, keys, codes, centers, queries, n, nq, m, d, k, id_offset, id_base,
+                         (uint32_t *)counter, (uint64_t *)cand, stream));
+      return merge_launch(dists, ids, nullptr, keys, nq, 1, k, id_base, stream);
+    }
+    return scan_launch(pl, dists, ids, keys, codes, centers, queries, n, nq, m, d, k, id_offset, id_base,
+                       (uint32_t *)counter, (uint64_t *)cand, stream);
+  }
+  void *part = nullptr;
+  RQ_TRY(workspace(WS_KEYS, (size_t)nq * pl.nslices * k * sizeof(uint64_t), &part));
+  RQ_TRY(scan_launch(pl, nullptr, nullptr, (uint64_t *)part, codes, centers, queries, n, nq, m, d, k, id_offset,
+                     id_base, (uint32_t *)counter, (uint64_t *)cand, stream));
+  return merge_launch(dists, ids, keys, (const uint64_t *)part, nq, (int)pl.nslices, k, id_base, stream);
+}
+
+static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers,
+                        const float *queries, const float *R, int64_t n, int64_t nq, int m, int d, int k,
+                        int id_base) {
+  Timer tt;
+  g_t_h2d = g_t_kernel = g_t_d2h = 0;
+  if (nq <= 0) return RQ_OK;
+  if (n < 1 || m < 1 || d < m || d % m) return fail(RQ_EINVAL, "bad shape n=%lld m=%d d=%d", (long long)n, m, d);
+  if (k < 1 || k > n) return fail(RQ_EINVAL, "k=%d must be in [1, n=%lld]", k, (long long)n);
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  DevBuf dcodes, dcent, dq, dr, drq, dd, di_;
+  const size_t cb = (size_t)n * m, ce = (size_t)m * 256 * (d / m) * 4, qb = (size_t)nq * d * 4;
+  RQ_TRY(dcodes.alloc(cb)); RQ_TRY(dcent.alloc(ce)); RQ_TRY(dq.alloc(qb));
+  RQ_TRY(dd.alloc((size_t)nq * k * 4)); RQ_TRY(di_.alloc((size_t)nq * k * 4));
+  Timer t1;
+  RQ_HIP(hipMemcpy(dcodes.p, codes, cb, hipMemcpyHostToDevice));
+  RQ_HIP(hipMemcpy(dcent.p, centers, ce, hipMemcpyHostToDevice));
+  RQ_HIP(hipMemcpy(dq.p, queries, qb, hipMemcpyHostToDevice));
+  const float *qdev = dq.as<float>();
+  if (R) {
+    RQ_TRY(dr.alloc((size_t)d * d * 4)); RQ_TRY(drq.alloc(qb));
+    RQ_HIP(hipMemcpy(dr.p, R, (size_t)d * d * 4, hipMemcpyHostToDevice));
+  }
+  g_t_h2d = t1.ms();
+  Timer t2;
+  if (R) {
+    RQ_TRY(rotate_launch(drq.as<float>(), dr.as<float>(), dq.as<float>(), d, nq, di.num_cu, nullptr));
+    qdev = drq.as<float>();
+  }
+  RQ_TRY(dev_linscan(dd.as<float>(), di_.as<uint32_t>(), nullptr, dcodes.as<uint8_t>(), dcent.as<float>(), qdev,
+                     n, nq, m, d, k, 0, id_base, nullptr));
+  RQ_HIP(hipDeviceSynchronize());
+  g_t_kernel = t2.ms();
+  Timer t3;
+  RQ_HIP(hipMemcpy(dists, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+  RQ_HIP(hipMemcpy(ids, di_.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+  g_t_d2h = t3.ms();
+  g_t_total = tt.ms();
+  return RQ_OK;
+}
+
+static int host_encode(uint8_t *codes, int16_t *codes1, const float *X, const float *R, const float *C,
+                       int64_t n, int d, int m, int h) {
+  Timer tt;
+  g_t_h2d = g_t_kernel = g_t_d2h = 0;
+  if (n <= 0) return RQ_OK;
+  if (d < 1 || m < 1 || h < 1) return fail(RQ_EINVAL, "bad shape d=%d m=%d h=%d", d, m, h);
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  // chunk the rows so X never needs more than ~1 GiB of device memory per chunk
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (1LL << 30) / ((int64_t)d * 4)));
+  DevBuf dX, dRX, dR, dC, dcodes, d16;
+  RQ_TRY(dX.alloc((size_t)chunk * d * 4));
+  RQ_TRY(dC.alloc((size_t)h * d * 4));
+  RQ_TRY(dcodes.alloc((size_t)chunk * m));
+  if (codes1) RQ_TRY(d16.alloc((size_t)chunk * m * 2));
+  RQ_HIP(hipMemcpy(dC.p, C, (size_t)h * d * 4, hipMemcpyHostToDevice));
+  if (R) {
+    RQ_TRY(dR.alloc((size_t)d * d * 4));
+    RQ_TRY(dRX.alloc((size_t)chunk * d * 4));
+    RQ_HIP(hipMemcpy(dR.p, R, (size_t)d * d * 4, hipMemcpyHostToDevice));
+  }
+  for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+    const int64_t nr = std::min(chunk, n - r0);
+    Timer t1;
+    RQ_HIP(hipMemcpy(dX.p, X + (size_t)r0 * d, (size_t)nr * d * 4, hipMemcpyHostToDevice));
+    g_t_h2d += t1.ms();
+    Timer t2;
+    const float *src = dX.as<float>();
+    if (R) {
+      RQ_TRY(rotate_launch(dRX.as<float>(), dR.as<float>(), dX.as<float>(), d, nr, di.num_cu, nullptr));
+      src = dRX.as<float>();
+    }
+    RQ_TRY(encode_launch(dcodes.as<uint8_t>(), src, dC.as<float>(), nr, d, m, h, di.num_cu, nullptr));
+    if (codes1) RQ_TRY(widen_codes_launch(d16.as<int16_t>(), dcodes.as<uint8_t>(), nr * m, nullptr));
+    RQ_HIP(hipDeviceSynchronize());
+    g_t_kernel += t2.ms();
+    Timer t3;
+    if (codes1)
+      RQ_HIP(hipMemcpy(codes1 + (size_t)r0 * m, d16.p, (size_t)nr * m * 2, hipMemcpyDeviceToHost));
+    else
+      RQ_HIP(hipMemcpy(codes + (size_t)r0 * m, dcodes.p, (size_t)nr * m, hipMemcpyDeviceToHost));
+    g_t_d2h += t3.ms();
+  }
+  g_t_total = tt.ms();
+  return RQ_OK;
+}
+
+}  // namespace rq
+
+using namespace rq;
+
+struct rq_index {
+  int m, d, device;
+  int64_t n;
+  uint32_t id_offset;
+  float *centers;
+  uint8_t *codes;
+};
+
+extern "C" {
+
+const char *rq_version(void) { return "rayuela-hip 0.1 (gfx950)"; }
+const char *rq_last_error(void) { return g_err; }
+
+int rq_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+int rq_set_device(int device) {
+  RQ_HIP(hipSetDevice(device));
+  return RQ_OK;
+}
+
+int rq_set_tuning(const char *key, int value) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < g_nknobs; ++i)
+    if (!strcmp(g_knobs[i].key, key)) { g_knobs[i].value = value; return RQ_OK; }
+  if (g_nknobs >= 16) return fail(RQ_EINVAL, "too many tuning keys");
+  strncpy(g_knobs[g_nknobs].key, key, 31);
+  g_knobs[g_nknobs].key[31] = 0;
+  g_knobs[g_nknobs++].value = value;
+  return RQ_OK;
+}
+
+int rq_last_timing(double *total_ms, double *h2d_ms, double *kernel_ms, double *d2h_ms) {
+  if (total_ms) *total_ms = g_t_total;
+  if (h2d_ms) *h2d_ms = g_t_h2d;
+  if (kernel_ms) *kernel_ms = g_t_kernel;
+  if (d2h_ms) *d2h_ms = g_t_d2h;
+  return RQ_OK;
+}
+
+void linscan_aqd_query(float *dists, unsigned int *res, unsigned char *codes, float *centers, float *queries,
+                       int N, unsigned int NQ, int B, int K, int dim1codes, int dim1queries, int subdim) {
+  // deps/src/linscan_aqd.cpp:48 -- the reference zeroes dists first; keep that on failure too
+  if (dists && K > 0) memset(dists, 0, (size_t)K * NQ * sizeof(float));
+  const int m = B / 8;
+  int rc;
+  if (m < 1 || dim1codes != m || dim1queries != m * subdim) {
+    rc = fail(RQ_EINVAL, "linscan_aqd_query: expects dim1codes == B/8 and dim1queries == (B/8)*subdim "
+                         "(B=%d dim1codes=%d dim1queries=%d subdim=%d)", B, dim1codes, dim1queries, subdim);
+  } else {
+    rc = host_linscan(dists, res, codes, centers, queries, nullptr, N, NQ, m, dim1queries, K, 0);
+  }
+  if (rc != RQ_OK) fprintf(stderr, "librayuela_hip: linscan_aqd_query failed (%d): %s\n", rc, g_err);
+}
+
+int rq_linscan_pq(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers, const float *queries,
+                  int64_t n, int64_t nq, int m, int d, int k, int id_base) {
+  return host_linscan(dists, ids, codes, centers, queries, nullptr, n, nq, m, d, k, id_base);
+}
+
+int rq_linscan_opq(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers, const float *queries,
+                   const float *R, int64_t n, int64_t nq, int m, int d, int k, int id_base) {
+  if (!R) return fail(RQ_EINVAL, "R is NULL");
+  return host_linscan(dists, ids, codes, centers, queries, R, n, nq, m, d, k, id_base);
+}
+
+int rq_encode_pq(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m, int h) {
+  return host_encode(codes, nullptr, X, nullptr, C, n, d, m, h);
+}
+int rq_encode_opq(uint8_t *codes, const float *X, const float *R, const float *C, int64_t n, int d, int m, int h) {
+  if (!R) return fail(RQ_EINVAL, "R is NULL");
+  return host_encode(codes, nullptr, X, R, C, n, d, m, h);
+}
+int rq_encode_pq_i16(int16_t *codes1, const float *X, const float *C, int64_t n, int d, int m, int h) {
+  return host_encode(nullptr, codes1, X, nullptr, C, n, d, m, h);
+}
+int rq_encode_opq_i16(int16_t *codes1, const float *X, const float *R, const float *C, int64_t n, int d, int m,
+                      int h) {
+  if (!R) return fail(RQ_EINVAL, "R is NULL");
+  return host_encode(nullptr, codes1, X, R, C, n, d, m, h);
+}
+
+int rq_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n) {
+  if (n <= 0) return RQ_OK;
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  DevBuf dX, dR, dRX;
+  RQ_TRY(dX.alloc((size_t)n * d * 4)); RQ_TRY(dRX.alloc((size_t)n * d * 4)); RQ_TRY(dR.alloc((size_t)d * d * 4));
+  RQ_HIP(hipMemcpy(dX.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice));
+  RQ_HIP(hipMemcpy(dR.p, R, (size_t)d * d * 4, hipMemcpyHostToDevice));
+  RQ_TRY(rotate_launch(dRX.as<float>(), dR.as<float>(), dX.as<float>(), d, n, di.num_cu, nullptr));
+  RQ_HIP(hipMemcpy(RX, dRX.p, (size_t)n * d * 4, hipMemcpyDeviceToHost));
+  return RQ_OK;
+}
+
+int rq_dev_encode_pq(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m, int h, void *stream) {
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  return encode_launch(codes, X, C, n, d, m, h, di.num_cu, (hipStream_t)stream);
+}
+
+int rq_dev_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n, void *stream) {
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  return rotate_launch(RX, R, X, d, n, di.num_cu, (hipStream_t)stream);
+}
+
+int rq_dev_encode_opq(uint8_t *codes, const float *X, const float *R, const float *C, int64_t n, int d, int m,
+                      int h, void *stream) {
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  void *tmp = nullptr;
+  RQ_TRY(workspace(WS_TMP, (size_t)n * d * 4, &tmp));
+  RQ_TRY(rotate_launch((float *)tmp, R, X, d, n, di.num_cu, (hipStream_t)stream));
+  return encode_launch(codes, (const float *)tmp, C, n, d, m, h, di.num_cu, (hipStream_t)stream);
+}
+
+int rq_dev_adc_lut(float *lut, const float *centers, const float *queries, int64_t nq, int m, int subdim,
+                   void *stream) {
+  if (nq <= 0) return RQ_OK;
+  return lut_launch(lut, centers, queries, nq, m, subdim, (hipStream_t)stream);
+}
+
+int rq_dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes, const float *centers,
+                   const float *queries, int64_t n, int64_t nq, int m, int d, int k, uint32_t id_offset,
+                   int id_base, void *stream) {
+  return dev_linscan(dists, ids, keys, codes, centers, queries, n, nq, m, d, k, id_offset, id_base,
+                     (hipStream_t)stream);
+}
+
+int rq_dev_merge_topk(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t *keys_in, int64_t nq, int P,
+                      int k, int id_base, void *stream) {
+  if (nq <= 0) return RQ_OK;
+  if (P < 1 || k < 1 || k > RQ_MAX_K) return fail(RQ_EINVAL, "merge: P=%d k=%d", P, k);
+  return merge_launch(dists, ids, keys_out, keys_in, nq, P, k, id_base, (hipStream_t)stream);
+}
+
+int rq_dev_synth_codes(uint8_t *codes, int64_t n, int m, uint64_t seed, int64_t row0, void *stream) {
+  if (n <= 0) return RQ_OK;
+  return synth_codes_launch(codes, n, m, seed, row0, (hipStream_t)stream);
+}
+
+rq_index *rq_index_create(int m, int d, const float *centers_host) {
+  if (m < 1 || d < m || d % m) { fail(RQ_EINVAL, "index: d %% m != 0"); return nullptr; }
+  rq_index *ix = new rq_index();
+  ix->m = m; ix->d = d; ix->n = 0; ix->id_offset = 0; ix->codes = nullptr; ix->centers = nullptr;
+  if (hipGetDevice(&ix->device) != hipSuccess) { delete ix; fail(RQ_ENODEVICE, "no device"); return nullptr; }
+  const size_t ce = (size_t)m * 256 * (d / m) * 4;
+  if (hipMalloc((void **)&ix->centers, ce) != hipSuccess ||
+      hipMemcpy(ix->centers, centers_host, ce, hipMemcpyHostToDevice) != hipSuccess) {
+    fail(RQ_ENODEVICE, "index: cannot upload the codebooks");
+    if (ix->centers) (void)hipFree(ix->centers);
+    delete ix;
+    return nullptr;
+  }
+  return ix;
+}
+
+int rq_index_set_codes(rq_index *ix, const uint8_t *codes_host, int64_t n, uint32_t id_offset) {
+  if (!ix) return fail(RQ_EINVAL, "index is NULL");
+  if (ix->codes) { RQ_HIP(hipFree(ix->codes)); ix->codes = nullptr; }
+  RQ_HIP(hipMalloc((void **)&ix->codes, (size_t)n * ix->m));
+  RQ_HIP(hipMemcpy(ix->codes, codes_host, (size_t)n * ix->m, hipMemcpyHostToDevice));
+  ix->n = n;
+  ix->id_offset = id_offset;
+  return RQ_OK;
+}
+
+int rq_index_search(rq_index *ix, float *dists, uint32_t *ids, const float *queries_host, int64_t nq, int k,
+                    int id_base) {
+  if (!ix || !ix->codes) return fail(RQ_EINVAL, "index has no codes");
+  if (nq <= 0) return RQ_OK;
+  Timer tt;
+  DevBuf dq, dd, di_;
+  RQ_TRY(dq.alloc((size_t)nq * ix->d * 4)); RQ_TRY(dd.alloc((size_t)nq * k * 4)); RQ_TRY(di_.alloc((size_t)nq * k * 4));
+  Timer t1;
+  RQ_HIP(hipMemcpy(dq.p, queries_host, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice));
+  g_t_h2d = t1.ms();
+  Timer t2;
+  RQ_TRY(dev_linscan(dd.as<float>(), di_.as<uint32_t>(), nullptr, ix->codes, ix->centers, dq.as<float>(), ix->n, nq,
+                     ix->m, ix->d, k, ix->id_offset, id_base, nullptr));
+  RQ_HIP(hipDeviceSynchronize());
+  g_t_kernel = t2.ms();
+  Timer t3;
+  RQ_HIP(hipMemcpy(dists, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+  RQ_HIP(hipMemcpy(ids, di_.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+  g_t_d2h = t3.ms();
+  g_t_total = tt.ms();
+  return RQ_OK;
+}
+
+void rq_index_destroy(rq_index *ix) {
+  if (!ix) return;
+  if (ix->codes) (void)hipFree(ix->codes);
+  if (ix->centers) (void)hipFree(ix->centers);
+  delete ix;
+}
+
+}  // extern "C"

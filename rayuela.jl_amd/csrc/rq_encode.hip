@@ -1,0 +1,330 @@
+// rq_encode.hip -- PQ encode (quantize_pq) and the OPQ rotation R'X on gfx950 f32 MFMA.
+//
+// Replaces the per-subspace  Distances.pairwise(SqEuclidean(), C[i], X[subdims[i],:])  +
+// Clustering.update_assignments!  pair of src/PQ.jl:37-43 (1 GB h x n distance matrix written
+// and re-read per subspace on the CPU) and the  R' * X  sgemm of src/OPQ.jl:26.
+//
+// Canonical arithmetic (oracle/rq_oracle.c, DESIGN.md "numerics"):
+//   g_k = <c_k, x>, sa_k = |c_k|^2, sb = |x|^2 : k-ordered fmaf chains from +0
+//   v_k = max( fl( fl(sa_k + sb) - 2 g_k ), 0 ) ;  code = first index of the minimum (strict '<')
+// v_mfma_f32_32x32x2_f32 IS a k-ordered fmaf chain, bit for bit, so the 256 x sub inner
+// products of a subspace come straight off the matrix cores with CPU-reproducible bits.
+//
+// Encode kernel layout (one 256- or 512-thread workgroup per CU, persistent over row tiles):
+//   LDS   cbA [m][NT][KS][64]  the sub-codebooks pre-swizzled into MFMA A-fragment order
+//                              (lane l of k-step kk holds C_i[t*32 + (l&31)][2kk + (l>>5)]),
+//                              128 KiB at SIFT (m=8,h=256,sub=16), 96 KiB at Deep (m=16,sub=6)
+//         saL [m][NT][2][16]   |c_k|^2 in C/D-fragment order (+inf for padded centroids)
+//         xs  [wave][2KS][33]  the wave's 32 x sub slice of X, transposed, bank-padded
+//   wave  owns tiles of 32 vectors; per subspace: stage slice -> B fragments in VGPRs ->
+//         NT x KS MFMAs (32 centroids x 32 vectors x 2 dims each) -> fused epilogue
+//         (add, sub, clamp, compare/select) on the 16 accumulator registers -> one cross-half
+//         shuffle -> packed code bytes, written once per tile (m contiguous bytes per vector).
+// Nothing of size h x n ever exists; X is read once, codes written once.
+#include "rq_internal.h"
+
+namespace rq {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+struct EncParams {
+  const float *X;   // [n][d]
+  const float *C;   // concat of [h][sub_i]
+  uint8_t *codes;   // [n][m]
+  int64_t n;
+  int d, m, h, NT;
+  int off[33];      // splitarray offsets (src/utils.jl:179-203)
+};
+
+constexpr int XS_STRIDE = 33;
+
+template <int KS, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void encode_pq_kernel(EncParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int m = p.m, NT = p.NT, h = p.h, d = p.d;
+  float *cbA = reinterpret_cast<float *>(smem);                 // m*NT*KS*64
+  float *saL = cbA + (size_t)m * NT * KS * 64;                  // m*NT*32
+  float *xs_all = saL + (size_t)m * NT * 32;                    // NWAVES * 2KS*33
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  float *xs = xs_all + (size_t)wave * (2 * KS * XS_STRIDE);
+
+  // ---- prologue: codebooks -> A-fragment order, norms -> C/D-fragment order -------------------
+  for (int idx = tid; idx < m * NT * KS * 64; idx += NWAVES * 64) {
+    const int l = idx & 63;
+    int rest = idx >> 6;
+    const int kk = rest % KS; rest /= KS;
+    const int t = rest % NT;
+    const int i = rest / NT;
+    const int sub = p.off[i + 1] - p.off[i];
+    const int cen = t * 32 + (l & 31);
+    const int s = 2 * kk + (l >> 5);
+    float v = 0.0f;
+    if (cen < h && s < sub) v = p.C[(size_t)h * p.off[i] + (size_t)cen * sub + s];
+    cbA[idx] = v;
+  }
+  for (int idx = tid; idx < m * NT * 32; idx += NWAVES * 64) {
+    const int c32 = idx & 31;
+    const int t = (idx >> 5) % NT;
+    const int i = (idx >> 5) / NT;
+    const int sub = p.off[i + 1] - p.off[i];
+    const int cen = t * 32 + c32;
+    float sa = __uint_as_float(0x7f800000u);
+    if (cen < h) {
+      const float *c = p.C + (size_t)h * p.off[i] + (size_t)cen * sub;
+      sa = 0.0f;
+      for (int s = 0; s < sub; ++s) sa = __builtin_fmaf(c[s], c[s], sa);
+    }
+    const int hh = (c32 >> 2) & 1;
+    const int r = (c32 & 3) + 4 * (c32 >> 3);
+    saL[((size_t)(i * NT + t) * 2 + hh) * 16 + r] = sa;
+  }
+  __syncthreads();
+
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t total_waves = (int64_t)gridDim.x * NWAVES;
+  for (int64_t tile = (int64_t)blockIdx.x * NWAVES + wave; tile < ntiles; tile += total_waves) {
+    const int64_t row0 = tile * 32;
+    uint64_t cw[4] = {0, 0, 0, 0};
+    for (int i = 0; i < m; ++i) {
+      const int o = p.off[i], sub = p.off[i + 1] - o;
+      // stage the 32 x sub slice, transposed: xs[s][row]
+      wave_lds_sync();
+      for (int e = lane; e < 32 * sub; e += 64) {
+        const int row = e / sub, s = e - row * sub;
+        int64_t gr = row0 + row;
+        if (gr >= p.n) gr = p.n - 1;
+        xs[s * XS_STRIDE + row] = p.X[gr * d + o + s];
+      }
+      wave_lds_sync();
+      float b[KS];
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const int s = 2 * kk + hi;
+        b[kk] = s < sub ? xs[s * XS_STRIDE + j] : 0.0f;
+      }
+      float sb = 0.0f;
+      for (int s = 0; s < sub; ++s) {
+        const float xv = xs[s * XS_STRIDE + j];
+        sb = __builtin_fmaf(xv, xv, sb);
+      }
+      float best_v = __uint_as_float(0x7f800000u);
+      int best_i = 0;
+      const float *cb_i = cbA + (size_t)i * NT * KS * 64 + lane;
+      const float4 *sa_i = reinterpret_cast<const float4 *>(saL + ((size_t)i * NT * 2 + hi) * 16);
+#pragma unroll 1
+      for (int t = 0; t < NT; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+          const float a = cb_i[(t * KS + kk) * 64];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[kk], acc, 0, 0, 0);
+        }
+        const float4 *sa4 = sa_i + (size_t)t * 8;  // 2 halves * 16 floats = 8 float4 per tile
+        const int cbase = t * 32 + 4 * hi;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float4 sav = sa4[g4];
+          const float sa[4] = {sav.x, sav.y, sav.z, sav.w};
+#pragma unroll
+          for (int r3 = 0; r3 < 4; ++r3) {
+            const float tt = sa[r3] + sb;
+            float v = tt - 2.0f * acc[g4 * 4 + r3];
+            v = v > 0.0f ? v : 0.0f;
+            const int idx = cbase + 8 * g4 + r3;
+            if (v < best_v) { best_v = v; best_i = idx; }
+          }
+        }
+      }
+      // the two half-waves hold disjoint centroid subsets of the same vector
+      const float ov = __shfl_xor(best_v, 32);
+      const int oi = __shfl_xor(best_i, 32);
+      if (ov < best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if ((i >> 3) == w) cw[w] |= (uint64_t)(uint32_t)best_i << (8 * (i & 7));
+    }
+    if (hi == 0 && row0 + j < p.n) {
+      uint8_t *o = p.codes + (size_t)(row0 + j) * m;
+      if ((m & 7) == 0) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          if (w * 8 < m) reinterpret_cast<uint64_t *>(o)[w] = cw[w];
+      } else {
+        for (int i = 0; i < m; ++i) o[i] = (uint8_t)(cw[i >> 3] >> (8 * (i & 7)));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Rotation  RX[j][i] = sum_k Rc[i][k] X[j][k]   (src/OPQ.jl:26, src/Linscan.jl:102)
+// R sits in LDS in A-fragment order; each wave stages a 32-vector tile of X transposed in LDS
+// and runs NT x KK 32x32x2 MFMAs; the k loop is the fmaf chain k = 0..d-1 of the oracle.
+// ------------------------------------------------------------------------------------------
+struct RotParams {
+  const float *R;  // [d][d]  Rc[i][k]
+  const float *X;  // [n][d]
+  float *RX;       // [n][d]
+  int64_t n;
+  int d, NT, KK;
+};
+
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void rotate_kernel(RotParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int d = p.d, NT = p.NT, KK = p.KK;
+  float *RA = reinterpret_cast<float *>(smem);            // NT*KK*64
+  float *xs_all = RA + (size_t)NT * KK * 64;              // NWAVES * (2KK)*33
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  float *xs = xs_all + (size_t)wave * (2 * KK * XS_STRIDE);
+  for (int idx = tid; idx < NT * KK * 64; idx += NWAVES * 64) {
+    const int l = idx & 63;
+    const int kk = (idx >> 6) % KK, t = (idx >> 6) / KK;
+    const int i = t * 32 + (l & 31), k = 2 * kk + (l >> 5);
+    RA[idx] = (i < d && k < d) ? p.R[(size_t)i * d + k] : 0.0f;
+  }
+  __syncthreads();
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t total_waves = (int64_t)gridDim.x * NWAVES;
+  for (int64_t tile = (int64_t)blockIdx.x * NWAVES + wave; tile < ntiles; tile += total_waves) {
+    const int64_t row0 = tile * 32;
+    wave_lds_sync();
+    for (int e = lane; e < 32 * d; e += 64) {
+      const int row = e / d, c = e - row * d;
+      int64_t gr = row0 + row;
+      if (gr >= p.n) gr = p.n - 1;
+      xs[c * XS_STRIDE + row] = p.X[gr * d + c];
+    }
+    if (hi == 1 && (d & 1)) xs[d * XS_STRIDE + j] = 0.0f;  // odd d: zero the padded k column
+    wave_lds_sync();
+    const float *xb = xs + hi * XS_STRIDE + j;
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      const float *ra = RA + (size_t)t * KK * 64 + lane;
+#pragma unroll 4
+      for (int kk = 0; kk < KK; ++kk) {
+        const float a = ra[kk * 64];
+        const float b = xb[2 * kk * XS_STRIDE];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+      if (row0 + j < p.n) {
+        float *o = p.RX + (size_t)(row0 + j) * d;
+        const int ibase = t * 32 + 4 * hi;
+        if ((d & 3) == 0) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int i0 = ibase + 8 * g4;
+            if (i0 < d)
+              *reinterpret_cast<float4 *>(o + i0) =
+                  make_float4(acc[g4 * 4 + 0], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = ibase + 8 * (r >> 2) + (r & 3);
+            if (i < d) o[i] = acc[r];
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ void widen_codes_kernel(int16_t *out1, const uint8_t *codes, size_t nelem) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nelem) out1[i] = (int16_t)((int)codes[i] + 1);  // src/PQ.jl:45-47: Int16, one-based
+}
+
+// ------------------------------------------------------------------------------------------
+template <int KS, int NWAVES>
+static int launch_encode(const EncParams &p, int num_cu, hipStream_t stream) {
+  const size_t lds = ((size_t)p.m * p.NT * KS * 64 + (size_t)p.m * p.NT * 32 +
+                      (size_t)NWAVES * 2 * KS * XS_STRIDE) * sizeof(float);
+  if (lds > 160 * 1024)
+    return fail(RQ_EUNSUPPORTED, "codebooks need %zu B of LDS (> 160 KiB): m=%d h=%d ksteps=%d", lds,
+                p.m, p.h, KS);
+  auto kern = encode_pq_kernel<KS, NWAVES>;
+  RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int grid = (int)std::min<int64_t>(num_cu, (ntiles + NWAVES - 1) / NWAVES);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, p);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m, int h,
+                  int num_cu, hipStream_t stream) {
+  if (n <= 0) return RQ_OK;
+  if (m < 1 || m > 32) return fail(RQ_EUNSUPPORTED, "encode covers 1 <= m <= 32; got m=%d", m);
+  if (h < 1 || h > 256) return fail(RQ_EUNSUPPORTED, "encode emits uint8 codes: 1 <= h <= 256; got h=%d", h);
+  if (d < m) return fail(RQ_EINVAL, "d=%d < m=%d", d, m);
+  EncParams p;
+  p.X = X; p.C = C; p.codes = codes; p.n = n; p.d = d; p.m = m; p.h = h;
+  p.NT = (h + 31) / 32;
+  const int per = d / m, extra = d % m;
+  int pos = 0, maxsub = 0;
+  for (int i = 0; i < m; ++i) {
+    p.off[i] = pos;
+    const int s = per + (i < extra ? 1 : 0);
+    pos += s;
+    maxsub = std::max(maxsub, s);
+  }
+  p.off[m] = pos;
+  const int ks = (maxsub + 1) / 2;
+  const int nw = tuning("ENC_WAVES", 4);
+#define RQ_ENC_CASE(KSV)                                                   \
+  if (ks <= KSV) {                                                         \
+    if (nw == 8) return launch_encode<KSV, 8>(p, num_cu, stream);          \
+    return launch_encode<KSV, 4>(p, num_cu, stream);                       \
+  }
+  RQ_ENC_CASE(1)
+  RQ_ENC_CASE(2)
+  RQ_ENC_CASE(3)
+  RQ_ENC_CASE(4)
+  RQ_ENC_CASE(6)
+  RQ_ENC_CASE(8)
+  RQ_ENC_CASE(16)
+  RQ_ENC_CASE(32)
+#undef RQ_ENC_CASE
+  return fail(RQ_EUNSUPPORTED, "sub-space dimension %d > 64 not covered by the encode kernels", maxsub);
+}
+
+int rotate_launch(float *RX, const float *R, const float *X, int d, int64_t n, int num_cu,
+                  hipStream_t stream) {
+  if (n <= 0) return RQ_OK;
+  RotParams p;
+  p.R = R; p.X = X; p.RX = RX; p.n = n; p.d = d;
+  p.NT = (d + 31) / 32;
+  p.KK = (d + 1) / 2;
+  constexpr int NW = 4;
+  const size_t lds = ((size_t)p.NT * p.KK * 64 + (size_t)NW * 2 * p.KK * XS_STRIDE) * sizeof(float);
+  if (lds > 160 * 1024) return fail(RQ_EUNSUPPORTED, "rotation with d=%d needs %zu B LDS (> 160 KiB)", d, lds);
+  auto kern = rotate_kernel<NW>;
+  RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t ntiles = (n + 31) / 32;
+  const int grid = (int)std::min<int64_t>(num_cu, (ntiles + NW - 1) / NW);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, p);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+int widen_codes_launch(int16_t *out1, const uint8_t *codes, int64_t nelem, hipStream_t stream) {
+  if (nelem <= 0) return RQ_OK;
+  hipLaunchKernelGGL(widen_codes_kernel, dim3((uint32_t)((nelem + 255) / 256)), dim3(256), 0, stream, out1,
+                     codes, (size_t)nelem);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+}  // namespace rq

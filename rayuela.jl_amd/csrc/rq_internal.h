@@ -1,0 +1,69 @@
+// rq_internal.h -- shared host-side declarations of librayuela_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <algorithm>
+
+#include "../../include/rayuela_hip.h"
+
+namespace rq {
+
+// Records the message for rq_last_error() (thread-local) and returns `code`.
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail_hip(hipError_t e, const char *what, const char *file, int line);
+
+#define RQ_HIP(expr)                                                       \
+  do {                                                                     \
+    hipError_t _e = (expr);                                                \
+    if (_e != hipSuccess) return ::rq::fail_hip(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define RQ_TRY(expr)            \
+  do {                          \
+    int _r = (expr);            \
+    if (_r != RQ_OK) return _r; \
+  } while (0)
+
+int tuning(const char *key, int dflt);  // env RQ_<KEY> or rq_set_tuning override
+
+struct DeviceInfo {
+  int device;
+  int num_cu;
+  char arch[64];
+};
+int device_info(DeviceInfo *out);
+
+// Grow-only per-device scratch, owned by the library.  Calls on one device are expected to be
+// issued from one stream at a time (the host-pointer API serialises them itself).
+int workspace(int slot, size_t bytes, void **ptr);
+enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_ENC = 4, WS_SLOTS = 8 };
+
+// ---- ADC scan -------------------------------------------------------------------------------
+struct ScanPlan {
+  int qg, blk;
+  uint32_t ngroups, nslices, rows_per_slice;
+  uint32_t cap, trigger, p2, scratch_keys, grid;
+  size_t cand_bytes;
+  bool lds_ok;
+};
+int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_cu, int force_slices);
+int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes,
+                const float *centers, const float *queries, int64_t n, int64_t nq, int m, int d, int K,
+                uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
+                hipStream_t stream);
+int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t *keys_in, int64_t nq,
+                 int P, int K, int id_base, hipStream_t stream);
+int lut_launch(float *lut, const float *centers, const float *queries, int64_t nq, int m, int sub,
+               hipStream_t stream);
+int synth_codes_launch(uint8_t *codes, int64_t n, int m, uint64_t seed, int64_t row0, hipStream_t stream);
+
+// ---- encode / rotation ----------------------------------------------------------------------
+int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m, int h,
+                  int num_cu, hipStream_t stream);
+int rotate_launch(float *RX, const float *R, const float *X, int d, int64_t n, int num_cu,
+                  hipStream_t stream);
+int widen_codes_launch(int16_t *out1, const uint8_t *codes, int64_t nelem, hipStream_t stream);
+
+}  // namespace rq

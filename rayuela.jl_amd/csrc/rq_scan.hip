@@ -1,0 +1,552 @@
+// rq_scan.hip -- ADC linear scan with exact top-k for gfx950 (MI355X).
+//
+// Replaces deps/src/linscan_aqd.cpp:37-102 (_linscan_aqd_query).  Same arithmetic:
+//   LUT   T[k][r] = sum_s (c[(k*256+r)*sub+s] - q[k*sub+s])^2   sequential f32, mul/add unfused (:66-74)
+//   dist  d_j     = ((T[0][b_j0] + T[1][b_j1]) + ...)           sequential f32               (:85-87)
+//   top-k         = k smallest (dist, id) pairs, lexicographic, ascending                    (:91-97)
+//
+// MI355X design (DESIGN.md section "ADC scan"):
+//   * One 1024-thread workgroup per CU (16 wavefronts), persistent over work items
+//     (query-group x row-slice) handed out by an atomic counter.
+//   * A query group is QG queries.  Their LUTs live in LDS interleaved 4 queries per entry:
+//     lut[k][quad][r] is a float4 = T_q[k][r] for the 4 queries of the quad, so ONE
+//     ds_read_b128 gather serves 4 queries; slot = r mod 16 spreads a 16-lane group over
+//     all 64 banks (the [k][r][QG] layout would only reach every other 16-byte slot).
+//   * Codes stream from HBM/L2 coalesced, 16 or 32 bytes per lane per block; every code byte
+//     is read once per query GROUP, not per query.
+//   * Top-k: per-query threshold tau (the k-th smallest key seen so far).  A row survives the
+//     hot loop only if dist < tau; survivors are appended (wave-aggregated LDS atomic) to a
+//     per-query candidate buffer in global memory (L2 resident).  When a buffer could overflow
+//     during the next block it is cut back to exactly k keys by an 8-pass radix select, all
+//     queries of the group in lockstep.  Strict '<' is exact because row ids only grow from
+//     block to block: a later row that ties tau's distance has a larger id, i.e. a larger key.
+//   * At the end of a slice the k survivors are bitonic-sorted in LDS (the LUT is dead by then
+//     and its space is reused) and written either as final (dist,id) or as packed keys for
+//     the slice/GPU merge kernel.
+#include "rq_internal.h"
+#include "rq_topk.h"
+
+namespace rq {
+
+constexpr int SCAN_THREADS = 1024;
+
+template <int M>
+struct ScanCfg {
+  static constexpr int QG = (M <= 8) ? 8 : 4;      // queries per group
+  static constexpr int NQUAD = QG / 4;
+  static constexpr int RPT = 32 / (M * NQUAD);      // rows per thread per block
+  static constexpr int BLK = SCAN_THREADS * RPT;    // rows per workgroup block
+  static constexpr int LUT_BYTES = M * QG * 1024;
+  static constexpr int ROW_WORDS = (M + 3) / 4;
+  static_assert(RPT >= 1, "M too large for this tiling");
+};
+
+template <int QG>
+struct ScanCtrl {
+  float tau[QG];
+  uint32_t cnt[QG];
+  uint32_t sel[QG];     // which half of the candidate ping-pong buffer is current
+  uint32_t item;
+  uint32_t pad[3];
+  SelState<QG> st;
+};
+
+struct ScanParams {
+  const uint8_t *codes;     // [n][M]
+  const float *centers;     // [M][256][sub]
+  const float *queries;     // [nq][d]
+  uint32_t n, nq;
+  int sub, d, K;
+  uint32_t id_offset;
+  int id_base;
+  uint32_t nslices, rows_per_slice, ngroups;
+  uint32_t cap;             // candidate buffer capacity per query (keys)
+  uint32_t trigger;         // compact when cnt > trigger  (cap - BLK >= trigger >= K)
+  uint32_t p2;              // next_pow2(K)
+  uint32_t scratch_keys;    // LDS sort scratch capacity in keys
+  uint32_t *work_counter;
+  uint64_t *cand;           // [gridDim][QG][2][cap]
+  // outputs: direct (nslices == 1 && keys == nullptr) or packed keys [nq][nslices][K]
+  float *dists;
+  uint32_t *ids;
+  uint64_t *keys;
+};
+
+// ------------------------------------------------------------------------------------------
+// LUT construction, one (k, r) entry at a time for all QG queries of the group.
+// deps/src/linscan_aqd.cpp:66-74; compiled with -ffp-contract=off so (c-q), square and add stay
+// three separately rounded f32 operations like the reference's x86-64 build.
+// ------------------------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ void build_lut(float *lut, const float *qstage, const float *centers,
+                                          int sub, int d, int tid) {
+  using Cfg = ScanCfg<M>;
+  constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD;
+  for (int e = tid; e < M * 256; e += SCAN_THREADS) {
+    const int k = e >> 8, r = e & 255;
+    const float *c = centers + (size_t)e * sub;
+    float acc[QG];
+#pragma unroll
+    for (int q = 0; q < QG; ++q) acc[q] = 0.0f;
+    for (int s = 0; s < sub; ++s) {
+      const float cs = c[s];
+#pragma unroll
+      for (int q = 0; q < QG; ++q) {
+        const float diff = cs - qstage[q * d + k * sub + s];
+        const float sq = diff * diff;
+        acc[q] = acc[q] + sq;
+      }
+    }
+#pragma unroll
+    for (int quad = 0; quad < NQUAD; ++quad) {
+      float4 v = make_float4(acc[quad * 4 + 0], acc[quad * 4 + 1], acc[quad * 4 + 2], acc[quad * 4 + 3]);
+      reinterpret_cast<float4 *>(lut)[(k * NQUAD + quad) * 256 + r] = v;
+    }
+  }
+}
+
+// Cut the candidate buffers of the flagged queries back to exactly K keys and refresh tau.
+template <int M>
+__device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg,
+                                              const ScanParams &p, bool need, int g, int gi) {
+  constexpr int QG = ScanCfg<M>::QG;
+  constexpr int TPG = SCAN_THREADS / QG;
+  const uint32_t cnt = ctrl->cnt[g];
+  const uint32_t sel = ctrl->sel[g];
+  const uint64_t *src = cand_wg + ((size_t)g * 2 + sel) * p.cap;
+  uint64_t *dst = cand_wg + ((size_t)g * 2 + (sel ^ 1u)) * p.cap;
+  radix_select<QG, TPG>(&ctrl->st, src, cnt, (uint32_t)p.K, need, g, gi);
+  const uint64_t tau_key = ctrl->st.prefix[g];
+  compact_leq<QG, TPG>(&ctrl->st, src, dst, cnt, tau_key, need, g, gi);
+  if (need && gi == 0) {
+    ctrl->cnt[g] = ctrl->st.newcnt[g];  // == K (keys are unique)
+    ctrl->sel[g] = sel ^ 1u;
+    ctrl->tau[g] = key_dist(tau_key);
+  }
+  __syncthreads();
+}
+
+template <int M>
+__global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
+  using Cfg = ScanCfg<M>;
+  constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD, RPT = Cfg::RPT, BLK = Cfg::BLK;
+  constexpr int TPG = SCAN_THREADS / QG;
+  constexpr int CTRL_BYTES = (sizeof(ScanCtrl<QG>) + 15) & ~15;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  ScanCtrl<QG> *ctrl = reinterpret_cast<ScanCtrl<QG> *>(smem);
+  float *lut = reinterpret_cast<float *>(smem + CTRL_BYTES);
+  float *qstage = lut + Cfg::LUT_BYTES / 4;
+  uint64_t *scratch = reinterpret_cast<uint64_t *>(smem + CTRL_BYTES);  // aliases lut (dead by then)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int g = tid / TPG, gi = tid % TPG;  // query-lane view used by select / sort
+  uint64_t *cand_wg = p.cand + (size_t)blockIdx.x * QG * 2 * p.cap;
+  const uint32_t nitems = p.ngroups * p.nslices;
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) ctrl->item = atomicAdd(p.work_counter, 1u);
+    __syncthreads();
+    const uint32_t item = ctrl->item;
+    if (item >= nitems) break;
+    const uint32_t slice = item / p.ngroups, group = item % p.ngroups;
+    const uint32_t q0 = group * QG;
+
+    // ---- stage the group's queries, reset the per-query state -------------------------------
+    for (int e = tid; e < QG * p.d; e += SCAN_THREADS) {
+      const int q = e / p.d, c = e - q * p.d;
+      const uint32_t qq = min(q0 + (uint32_t)q, p.nq - 1u);  // ragged last group: repeat a query
+      qstage[e] = p.queries[(size_t)qq * p.d + c];
+    }
+    if (tid < QG) {
+      ctrl->tau[tid] = __uint_as_float(0x7f800000u);  // +inf: everything passes until the first cut
+      ctrl->cnt[tid] = 0;
+      ctrl->sel[tid] = 0;
+    }
+    __syncthreads();
+    build_lut<M>(lut, qstage, p.centers, p.sub, p.d, tid);
+    __syncthreads();
+
+    // ---- stream the slice -----------------------------------------------------------------------
+    const uint32_t r_begin = slice * p.rows_per_slice;
+    const uint32_t r_end = min(p.n, r_begin + p.rows_per_slice);
+    const float4 *lut4 = reinterpret_cast<const float4 *>(lut);
+#pragma unroll 1
+    for (uint32_t base = r_begin; base < r_end; base += BLK) {
+      // capacity invariant: cnt[q] + BLK <= cap for every q when a block starts
+      bool need = ctrl->cnt[g] > p.trigger;
+      if (__syncthreads_or(need)) compact_group<M>(ctrl, cand_wg, p, need, g, gi);
+      float tau[QG];
+#pragma unroll
+      for (int q = 0; q < QG; ++q) tau[q] = ctrl->tau[q];
+
+      const uint32_t row0 = base + (uint32_t)tid * RPT;
+      uint32_t w[RPT * Cfg::ROW_WORDS];
+      if (row0 + RPT <= r_end) {
+        if constexpr ((RPT * M) % 16 == 0) {
+          const uint4 *src = reinterpret_cast<const uint4 *>(p.codes + (size_t)row0 * M);
+#pragma unroll
+          for (int i = 0; i < RPT * M / 16; ++i) {
+            const uint4 v = src[i];
+            w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < RPT * M / 4; ++i)
+            w[i] = reinterpret_cast<const uint32_t *>(p.codes + (size_t)row0 * M)[i];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+#pragma unroll
+          for (int i = 0; i < Cfg::ROW_WORDS; ++i) {
+            uint32_t v = 0;
+            if (row0 + r < r_end) {
+              if constexpr (M % 4 == 0) {
+                v = reinterpret_cast<const uint32_t *>(p.codes + (size_t)(row0 + r) * M)[i];
+              } else {
+                for (int b = 0; b < 4 && i * 4 + b < M; ++b)
+                  v |= (uint32_t)p.codes[(size_t)(row0 + r) * M + i * 4 + b] << (8 * b);
+              }
+            }
+            w[r * Cfg::ROW_WORDS + i] = v;
+          }
+        }
+      }
+
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        float acc[QG];
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          uint32_t word;
+          if constexpr (M % 4 == 0) word = w[(r * M + k) >> 2];
+          else word = w[r * Cfg::ROW_WORDS + (k >> 2)];
+          const uint32_t byte = (word >> (8 * (k & 3))) & 0xffu;
+#pragma unroll
+          for (int quad = 0; quad < NQUAD; ++quad) {
+            const float4 t = lut4[(k * NQUAD + quad) * 256 + byte];
+            if (k == 0) {
+              acc[quad * 4 + 0] = t.x; acc[quad * 4 + 1] = t.y;
+              acc[quad * 4 + 2] = t.z; acc[quad * 4 + 3] = t.w;
+            } else {
+              acc[quad * 4 + 0] = acc[quad * 4 + 0] + t.x;
+              acc[quad * 4 + 1] = acc[quad * 4 + 1] + t.y;
+              acc[quad * 4 + 2] = acc[quad * 4 + 2] + t.z;
+              acc[quad * 4 + 3] = acc[quad * 4 + 3] + t.w;
+            }
+          }
+        }
+        const bool valid = row0 + r < r_end;
+        bool hit = false;
+#pragma unroll
+        for (int q = 0; q < QG; ++q) hit |= acc[q] < tau[q];
+        if (__any(hit && valid)) {
+          // survivor path: wave-aggregated append, one LDS atomic per (wave, query)
+#pragma unroll
+          for (int q = 0; q < QG; ++q) {
+            const bool pq = valid && (acc[q] < tau[q]);
+            const uint64_t mask = __ballot(pq);
+            if (mask) {
+              const int leader = __ffsll((unsigned long long)mask) - 1;
+              uint32_t pos = 0;
+              if (lane == leader) pos = atomicAdd(&ctrl->cnt[q], (uint32_t)__popcll(mask));
+              pos = __shfl(pos, leader);
+              if (pq) {
+                pos += __popcll(mask & ((1ull << lane) - 1ull));
+                uint64_t *buf = cand_wg + ((size_t)q * 2 + ctrl->sel[q]) * p.cap;
+                buf[pos] = make_key(acc[q], row0 + r + p.id_offset);
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- finish the item: cut to K, sort, write ----------------------------------------------
+    {
+      bool need = ctrl->cnt[g] > (uint32_t)p.K;
+      if (__syncthreads_or(need)) compact_group<M>(ctrl, cand_wg, p, need, g, gi);
+    }
+    // sort `nconc` queries at a time in LDS (scratch aliases the LUT, which is dead now)
+    uint32_t nconc = p.scratch_keys / p.p2;
+    if (nconc > (uint32_t)QG) nconc = QG;
+    // round down to a power of two so the thread split is even
+    while (nconc & (nconc - 1)) nconc &= nconc - 1;
+    const uint32_t tps = SCAN_THREADS / nconc;  // threads per concurrent sort
+    const uint32_t sg = tid / tps, sgi = tid % tps;
+    for (uint32_t qb = 0; qb < (uint32_t)QG; qb += nconc) {
+      const uint32_t q = qb + sg;
+      const bool act = q < (uint32_t)QG;
+      uint64_t *a = scratch + (size_t)sg * p.p2;
+      const uint32_t cnt = act ? ctrl->cnt[q] : 0;
+      const uint64_t *src = cand_wg + ((size_t)(act ? q : 0) * 2 + (act ? ctrl->sel[q] : 0)) * p.cap;
+      __syncthreads();
+      if (act)
+        for (uint32_t i = sgi; i < p.p2; i += tps) a[i] = i < cnt ? src[i] : KEY_MAX;
+      __syncthreads();
+      // bitonic network, generic thread-group width
+      for (uint32_t k = 2; k <= p.p2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+          if (act) {
+            for (uint32_t i = sgi; i < (p.p2 >> 1); i += tps) {
+              const uint32_t lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+              const uint32_t hi = lo | j;
+              const bool up = (lo & k) == 0;
+              const uint64_t x = a[lo], y = a[hi];
+              if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      const uint32_t qq = q0 + q;
+      if (act && qq < p.nq) {
+        if (p.keys) {
+          uint64_t *o = p.keys + ((size_t)qq * p.nslices + slice) * p.K;
+          for (uint32_t i = sgi; i < (uint32_t)p.K; i += tps) o[i] = a[i];
+        } else {
+          float *od = p.dists + (size_t)qq * p.K;
+          uint32_t *oi = p.ids + (size_t)qq * p.K;
+          for (uint32_t i = sgi; i < (uint32_t)p.K; i += tps) {
+            const uint64_t key = a[i];
+            od[i] = key_dist(key);
+            oi[i] = key_id(key) + (uint32_t)p.id_base;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Merge P sorted key lists per query (slices of one GPU and/or shards of several GPUs).
+// One 256-thread workgroup per query: radix-select the K-th key over the P*K keys in global
+// memory, pull the K survivors into LDS, sort, write.
+// ------------------------------------------------------------------------------------------
+constexpr int MERGE_THREADS = 256;
+
+struct MergeParams {
+  const uint64_t *keys_in;  // [nq][P][K]
+  uint32_t nq, P;
+  int K, id_base;
+  uint32_t p2;
+  float *dists;
+  uint32_t *ids;
+  uint64_t *keys_out;
+};
+
+struct MergeCtrl {
+  SelState<1> st;
+};
+
+__global__ __launch_bounds__(MERGE_THREADS) void merge_topk_kernel(MergeParams p) {
+  constexpr int CTRL_BYTES = (sizeof(MergeCtrl) + 15) & ~15;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  MergeCtrl *ctrl = reinterpret_cast<MergeCtrl *>(smem);
+  uint64_t *a = reinterpret_cast<uint64_t *>(smem + CTRL_BYTES);
+  const int tid = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  const uint64_t *src = p.keys_in + (size_t)q * p.P * p.K;
+  const uint32_t cnt = p.P * (uint32_t)p.K;
+  for (uint32_t i = tid; i < p.p2; i += MERGE_THREADS) a[i] = KEY_MAX;
+  radix_select<1, MERGE_THREADS>(&ctrl->st, src, cnt, (uint32_t)p.K, true, 0, tid);
+  const uint64_t tau = ctrl->st.prefix[0];
+  // survivors straight into LDS (padding keys equal to KEY_MAX never survive unless tau is one)
+  if (tid == 0) ctrl->st.newcnt[0] = 0;
+  __syncthreads();
+  {
+    const int lane = tid & 63;
+    const uint32_t cnt_up = (cnt + 63u) & ~63u;
+    for (uint32_t idx = tid; idx < cnt_up; idx += MERGE_THREADS) {
+      const uint64_t key = idx < cnt ? src[idx] : KEY_MAX;
+      const bool take = idx < cnt && key <= tau && key != KEY_MAX;
+      const uint64_t mask = __ballot(take);
+      if (mask) {
+        const int leader = __ffsll((unsigned long long)mask) - 1;
+        uint32_t basep = 0;
+        if (lane == leader) basep = atomicAdd(&ctrl->st.newcnt[0], (uint32_t)__popcll(mask));
+        basep = __shfl(basep, leader);
+        if (take) {
+          const uint32_t pos = basep + __popcll(mask & ((1ull << lane) - 1ull));
+          if (pos < p.p2) a[pos] = key;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  bitonic_sort<MERGE_THREADS>(a, p.p2, true, tid);
+  for (uint32_t i = tid; i < (uint32_t)p.K; i += MERGE_THREADS) {
+    const uint64_t key = a[i];
+    if (p.keys_out) p.keys_out[(size_t)q * p.K + i] = key;
+    if (p.dists) p.dists[(size_t)q * p.K + i] = key_dist(key);
+    if (p.ids) p.ids[(size_t)q * p.K + i] = key_id(key) + (uint32_t)p.id_base;
+  }
+}
+
+// Stand-alone LUT kernel (test aid, rq_dev_adc_lut): lut[q][k][r], one thread per (q,k,r).
+__global__ void adc_lut_kernel(float *lut, const float *centers, const float *queries, uint32_t nq,
+                               int m, int sub) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per_q = (size_t)m * 256;
+  if (e >= per_q * nq) return;
+  const size_t q = e / per_q;
+  const int t = (int)(e - q * per_q);
+  const int k = t >> 8;
+  const float *c = centers + (size_t)t * sub;
+  const float *qv = queries + q * (size_t)(m * sub) + (size_t)k * sub;
+  float acc = 0.0f;
+  for (int s = 0; s < sub; ++s) {
+    const float diff = c[s] - qv[s];
+    const float sq = diff * diff;
+    acc = acc + sq;
+  }
+  lut[e] = acc;
+}
+
+__global__ void synth_codes_kernel(uint8_t *codes, size_t nbytes, uint64_t seed, uint64_t e0) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= nbytes) return;
+  uint64_t out = 0;
+  const int lim = (int)((nbytes - i) < 8 ? (nbytes - i) : 8);
+  for (int b = 0; b < lim; ++b) {
+    uint64_t z = ((e0 + i + b) ^ seed) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    out |= (z >> 56) << (8 * b);
+  }
+  if (lim == 8) *reinterpret_cast<uint64_t *>(codes + i) = out;
+  else for (int b = 0; b < lim; ++b) codes[i + b] = (uint8_t)(out >> (8 * b));
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+template <int M>
+static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) {
+  using Cfg = ScanCfg<M>;
+  constexpr int CTRL_BYTES = (sizeof(ScanCtrl<Cfg::QG>) + 15) & ~15;
+  size_t lds = CTRL_BYTES + (size_t)std::max<size_t>(Cfg::LUT_BYTES + (size_t)Cfg::QG * p.d * 4,
+                                                     (size_t)p.scratch_keys * 8);
+  auto kern = adc_scan_kernel<M>;
+  RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(SCAN_THREADS), lds, stream, p);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+template <int M>
+static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_cu, int force_slices) {
+  using Cfg = ScanCfg<M>;
+  constexpr int CTRL_BYTES = (sizeof(ScanCtrl<Cfg::QG>) + 15) & ~15;
+  pl.qg = Cfg::QG;
+  pl.blk = Cfg::BLK;
+  pl.ngroups = (uint32_t)((nq + Cfg::QG - 1) / Cfg::QG);
+  // row slices: enough work items to fill the chip, but slices long enough that the
+  // per-slice top-k overhead (~K(1+ln(rows/K)) survivors, one sort) stays small
+  int64_t min_rows = std::max<int64_t>(65536, 32LL * K);
+  min_rows = (min_rows + Cfg::BLK - 1) / Cfg::BLK * Cfg::BLK;
+  int64_t max_slices = std::max<int64_t>(1, n / min_rows);
+  int64_t want = (4LL * num_cu + pl.ngroups - 1) / pl.ngroups;
+  int64_t ns = std::min<int64_t>(std::max<int64_t>(1, want), max_slices);
+  if (force_slices > 0) ns = force_slices;
+  int64_t rps = (n + ns - 1) / ns;
+  rps = (rps + Cfg::BLK - 1) / Cfg::BLK * Cfg::BLK;
+  ns = (n + rps - 1) / rps;
+  pl.nslices = (uint32_t)ns;
+  pl.rows_per_slice = (uint32_t)rps;
+  const uint32_t slack = std::max<uint32_t>((uint32_t)K, 1024u);
+  pl.trigger = (uint32_t)K + slack;
+  pl.cap = pl.trigger + Cfg::BLK;
+  pl.p2 = next_pow2((uint32_t)K);
+  // LDS scratch for the final sort: at least one query, at most QG, within 160 KiB total
+  const size_t lds_max = 160 * 1024 - CTRL_BYTES;
+  size_t want_keys = (size_t)pl.p2 * Cfg::QG;
+  size_t base_keys = ((size_t)Cfg::LUT_BYTES + (size_t)Cfg::QG * d * 4) / 8;
+  size_t keys = std::max(base_keys, std::min(want_keys, (size_t)64 * 1024 / 8 * 2));
+  keys = std::max(keys, (size_t)pl.p2);
+  keys = std::min(keys, lds_max / 8);
+  pl.scratch_keys = (uint32_t)keys;
+  const uint64_t items = (uint64_t)pl.ngroups * pl.nslices;
+  pl.grid = (uint32_t)std::min<uint64_t>(items, (uint64_t)num_cu);
+  pl.cand_bytes = (size_t)pl.grid * Cfg::QG * 2 * pl.cap * sizeof(uint64_t);
+  pl.lds_ok = ((size_t)pl.p2 * 8 <= lds_max) &&
+              ((size_t)Cfg::LUT_BYTES + (size_t)Cfg::QG * d * 4 <= lds_max);
+}
+
+int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_cu, int force_slices) {
+  switch (m) {
+    case 2: plan_for<2>(pl, n, nq, d, K, num_cu, force_slices); break;
+    case 4: plan_for<4>(pl, n, nq, d, K, num_cu, force_slices); break;
+    case 8: plan_for<8>(pl, n, nq, d, K, num_cu, force_slices); break;
+    case 16: plan_for<16>(pl, n, nq, d, K, num_cu, force_slices); break;
+    case 32: plan_for<32>(pl, n, nq, d, K, num_cu, force_slices); break;
+    default:
+      return fail(RQ_EUNSUPPORTED, "ADC scan kernels cover m in {2,4,8,16,32}; got m=%d", m);
+  }
+  if (!pl.lds_ok) return fail(RQ_EUNSUPPORTED, "k=%d / d=%d does not fit the 160 KiB LDS plan", K, d);
+  return RQ_OK;
+}
+
+int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes,
+                const float *centers, const float *queries, int64_t n, int64_t nq, int m, int d, int K,
+                uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
+                hipStream_t stream) {
+  ScanParams p;
+  p.codes = codes; p.centers = centers; p.queries = queries;
+  p.n = (uint32_t)n; p.nq = (uint32_t)nq; p.sub = d / m; p.d = d; p.K = K;
+  p.id_offset = id_offset; p.id_base = id_base;
+  p.nslices = pl.nslices; p.rows_per_slice = pl.rows_per_slice; p.ngroups = pl.ngroups;
+  p.cap = pl.cap; p.trigger = pl.trigger; p.p2 = pl.p2; p.scratch_keys = pl.scratch_keys;
+  p.work_counter = work_counter; p.cand = cand;
+  p.dists = dists; p.ids = ids; p.keys = keys;
+  RQ_HIP(hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream));
+  switch (m) {
+    case 2: return launch_scan<2>(p, pl, stream);
+    case 4: return launch_scan<4>(p, pl, stream);
+    case 8: return launch_scan<8>(p, pl, stream);
+    case 16: return launch_scan<16>(p, pl, stream);
+    case 32: return launch_scan<32>(p, pl, stream);
+  }
+  return fail(RQ_EUNSUPPORTED, "m=%d", m);
+}
+
+int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t *keys_in, int64_t nq,
+                 int P, int K, int id_base, hipStream_t stream) {
+  MergeParams p;
+  p.keys_in = keys_in; p.nq = (uint32_t)nq; p.P = (uint32_t)P; p.K = K; p.id_base = id_base;
+  p.p2 = next_pow2((uint32_t)K);
+  p.dists = dists; p.ids = ids; p.keys_out = keys_out;
+  constexpr int CTRL_BYTES = (sizeof(MergeCtrl) + 15) & ~15;
+  size_t lds = CTRL_BYTES + (size_t)p.p2 * 8;
+  RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(merge_topk_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(merge_topk_kernel, dim3((uint32_t)nq), dim3(MERGE_THREADS), lds, stream, p);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+int lut_launch(float *lut, const float *centers, const float *queries, int64_t nq, int m, int sub,
+               hipStream_t stream) {
+  const size_t total = (size_t)nq * m * 256;
+  const int threads = 256;
+  hipLaunchKernelGGL(adc_lut_kernel, dim3((uint32_t)((total + threads - 1) / threads)), dim3(threads), 0,
+                     stream, lut, centers, queries, (uint32_t)nq, m, sub);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+int synth_codes_launch(uint8_t *codes, int64_t n, int m, uint64_t seed, int64_t row0, hipStream_t stream) {
+  const size_t nbytes = (size_t)n * m;
+  const size_t nthreads = (nbytes + 7) / 8;
+  hipLaunchKernelGGL(synth_codes_kernel, dim3((uint32_t)((nthreads + 255) / 256)), dim3(256), 0, stream,
+                     codes, nbytes, seed, (uint64_t)row0 * (uint64_t)m);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+}  // namespace rq

@@ -1,0 +1,157 @@
+// rq_topk.h -- exact top-k machinery shared by the ADC scan and the shard/GPU merge kernel.
+//
+// The reference keeps a full (dist,id) pair array per query and std::partial_sort's it
+// (deps/src/linscan_aqd.cpp:78-92): the answer is the k smallest pairs in LEXICOGRAPHIC
+// (dist, id) order.  Here a pair is packed into one uint64 key whose unsigned order is that
+// lexicographic order:  key = ordered_bits(dist) << 32 | id.  Keys are unique (ids are), so
+// "the k smallest keys" is a total-order statement and the result is independent of how the
+// rows were partitioned over wavefronts, workgroups, slices or GPUs.
+//
+// Device routines (all threads of the workgroup must call them; they contain barriers):
+//   radix_select  : k-th smallest key of an unsorted global buffer, 8 MSB-first 8-bit passes,
+//                   for G independent query-lanes in lockstep (TPG threads each)
+//   compact_leq   : copy the keys <= tau to the front of another buffer
+//   bitonic_sort  : ascending sort of a power-of-two LDS array
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rq {
+
+constexpr uint64_t KEY_MAX = ~0ull;
+
+// float -> uint32 whose unsigned order equals the float order (NaN-free inputs)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  uint32_t u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;
+  return __uint_as_float(u);
+}
+// d + 0.0f canonicalises -0 to +0 so key order == the reference's pair order (-0 == +0 there)
+__device__ __forceinline__ uint64_t make_key(float d, uint32_t id) {
+  return ((uint64_t)f2ord(d + 0.0f) << 32) | (uint64_t)id;
+}
+__device__ __forceinline__ float key_dist(uint64_t k) { return ord2f((uint32_t)(k >> 32)); }
+__device__ __forceinline__ uint32_t key_id(uint64_t k) { return (uint32_t)k; }
+
+template <int G>
+struct SelState {
+  uint64_t prefix[G];   // radix prefix found so far; after 8 passes the k-th smallest key
+  uint32_t krem[G];     // rank still to resolve inside the current bucket (1-based)
+  uint32_t newcnt[G];   // compaction cursor
+  uint32_t hist[G][256];
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t t = __shfl_up(v, off);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+// k-th smallest (1-based k) of src[0..cnt) for query-lane g; result in st->prefix[g].
+// `active`, `cnt`, `src`, `k` must be uniform inside a query-lane; cnt >= k when active.
+template <int G, int TPG>
+__device__ __forceinline__ void radix_select(SelState<G> *st, const uint64_t *__restrict__ src,
+                                             uint32_t cnt, uint32_t k, bool active, int g,
+                                             int gi) {
+  static_assert(TPG >= 64 && TPG % 64 == 0, "a query-lane is a whole number of wavefronts");
+  if (gi == 0 && active) {
+    st->prefix[g] = 0;
+    st->krem[g] = k;
+  }
+#pragma unroll 1
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 56 - 8 * pass;
+    for (int b = gi; b < 256; b += TPG) st->hist[g][b] = 0;
+    __syncthreads();
+    if (active) {
+      const uint64_t pfx = st->prefix[g];
+      for (uint32_t idx = gi; idx < cnt; idx += TPG) {
+        const uint64_t key = src[idx];
+        const bool match = (pass == 0) || ((key >> (shift + 8)) == (pfx >> (shift + 8)));
+        if (match) atomicAdd(&st->hist[g][(uint32_t)(key >> shift) & 255u], 1u);
+      }
+    }
+    __syncthreads();
+    if (active && gi < 64) {
+      const uint32_t c0 = st->hist[g][gi * 4 + 0], c1 = st->hist[g][gi * 4 + 1];
+      const uint32_t c2 = st->hist[g][gi * 4 + 2], c3 = st->hist[g][gi * 4 + 3];
+      const uint32_t s = c0 + c1 + c2 + c3;
+      const uint32_t incl = wave_incl_scan(s, gi);
+      const uint32_t excl = incl - s;
+      const uint32_t kk = st->krem[g];
+      if (excl < kk && kk <= incl) {
+        uint32_t r = kk - excl, b = 0;
+        if (r > c0) { r -= c0; b = 1;
+          if (r > c1) { r -= c1; b = 2;
+            if (r > c2) { r -= c2; b = 3; } } }
+        st->prefix[g] |= (uint64_t)(gi * 4 + b) << shift;
+        st->krem[g] = r;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// dst[0..) <- every key of src[0..cnt) that is <= tau (order not preserved); st->newcnt[g] = count.
+template <int G, int TPG>
+__device__ __forceinline__ void compact_leq(SelState<G> *st, const uint64_t *__restrict__ src,
+                                            uint64_t *__restrict__ dst, uint32_t cnt, uint64_t tau,
+                                            bool active, int g, int gi) {
+  if (gi == 0) st->newcnt[g] = 0;
+  __syncthreads();
+  if (active) {
+    const int lane = gi & 63;
+    const uint32_t cnt_up = (cnt + 63u) & ~63u;  // keep whole waves in the ballot
+    for (uint32_t idx = gi; idx < cnt_up; idx += TPG) {
+      const uint64_t key = idx < cnt ? src[idx] : KEY_MAX;
+      const bool take = idx < cnt && key <= tau;
+      const uint64_t mask = __ballot(take);
+      if (mask) {
+        const int leader = __ffsll((unsigned long long)mask) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&st->newcnt[g], (uint32_t)__popcll(mask));
+        base = __shfl(base, leader);
+        if (take) dst[base + __popcll(mask & ((1ull << lane) - 1ull))] = key;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ascending bitonic sort of a[0..p2) (p2 a power of two, uniform over the workgroup).
+template <int TPG>
+__device__ __forceinline__ void bitonic_sort(uint64_t *a, uint32_t p2, bool active, int gi) {
+#pragma unroll 1
+  for (uint32_t k = 2; k <= p2; k <<= 1) {
+#pragma unroll 1
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      if (active) {
+        for (uint32_t i = gi; i < (p2 >> 1); i += TPG) {
+          const uint32_t lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+          const uint32_t hi = lo | j;
+          const bool up = (lo & k) == 0;
+          const uint64_t x = a[lo], y = a[hi];
+          if ((x > y) == up) {
+            a[lo] = y;
+            a[hi] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__host__ __device__ inline uint32_t next_pow2(uint32_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace rq

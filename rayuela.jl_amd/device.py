@@ -1,0 +1,97 @@
+"""Device-resident entry points (rq_dev_* of include/rayuela_hip.h) on torch CUDA tensors.
+
+torch is plumbing here: it owns the device memory and the stream; every launch goes to the current
+torch stream, so torch.cuda.Event timing brackets exactly the kernels of this library."""
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype, name):
+    if not (t.is_cuda and t.is_contiguous() and t.dtype == dtype):
+        raise TypeError("%s must be a contiguous CUDA tensor of dtype %s" % (name, dtype))
+    return t.data_ptr()
+
+
+def encode_pq(X, Ccat, m, h, out=None):
+    n, d = X.shape
+    out = torch.empty((n, m), dtype=torch.uint8, device=X.device) if out is None else out
+    _lib.check(_lib.lib().rq_dev_encode_pq(_chk(out, torch.uint8, "codes"), _chk(X, torch.float32, "X"),
+                                           _chk(Ccat, torch.float32, "C"), n, d, m, h, _stream()))
+    return out
+
+
+def rotate_T(R, X, out=None):
+    n, d = X.shape
+    out = torch.empty_like(X) if out is None else out
+    _lib.check(_lib.lib().rq_dev_rotate_T(_chk(out, torch.float32, "RX"), _chk(R, torch.float32, "R"),
+                                          _chk(X, torch.float32, "X"), d, n, _stream()))
+    return out
+
+
+def encode_opq(X, R, Ccat, m, h, out=None):
+    n, d = X.shape
+    out = torch.empty((n, m), dtype=torch.uint8, device=X.device) if out is None else out
+    _lib.check(_lib.lib().rq_dev_encode_opq(_chk(out, torch.uint8, "codes"), _chk(X, torch.float32, "X"),
+                                            _chk(R, torch.float32, "R"), _chk(Ccat, torch.float32, "C"),
+                                            n, d, m, h, _stream()))
+    return out
+
+
+def adc_lut(centers, queries):
+    m, h, sub = centers.shape
+    nq = queries.shape[0]
+    lut = torch.empty((nq, m, 256), dtype=torch.float32, device=queries.device)
+    _lib.check(_lib.lib().rq_dev_adc_lut(lut.data_ptr(), _chk(centers, torch.float32, "centers"),
+                                         _chk(queries, torch.float32, "queries"), nq, m, sub, _stream()))
+    return lut
+
+
+def linscan(codes, centers, queries, k, id_offset=0, id_base=0, want_keys=False, out=None):
+    """Scan one resident shard.  Returns (dists, ids) or packed sorted keys [nq][k] (int64 view of
+    the uint64 keys) when want_keys."""
+    n, m = codes.shape
+    nq, d = queries.shape
+    dev = queries.device
+    if want_keys:
+        keys = torch.empty((nq, k), dtype=torch.int64, device=dev) if out is None else out
+        _lib.check(_lib.lib().rq_dev_linscan(None, None, keys.data_ptr(), _chk(codes, torch.uint8, "codes"),
+                                             _chk(centers, torch.float32, "centers"),
+                                             _chk(queries, torch.float32, "queries"), n, nq, m, d, k,
+                                             id_offset, id_base, _stream()))
+        return keys
+    if out is None:
+        dists = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    else:
+        dists, ids = out
+    _lib.check(_lib.lib().rq_dev_linscan(dists.data_ptr(), ids.data_ptr(), None, _chk(codes, torch.uint8, "codes"),
+                                         _chk(centers, torch.float32, "centers"),
+                                         _chk(queries, torch.float32, "queries"), n, nq, m, d, k,
+                                         id_offset, id_base, _stream()))
+    return dists, ids
+
+
+def merge_topk(keys_in, k, id_base=0, out=None):
+    """keys_in [nq][P][k] int64 (uint64 bit patterns) -> (dists [nq][k], ids [nq][k])."""
+    nq, P, kk = keys_in.shape
+    assert kk == k
+    dev = keys_in.device
+    if out is None:
+        dists = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    else:
+        dists, ids = out
+    _lib.check(_lib.lib().rq_dev_merge_topk(dists.data_ptr(), ids.data_ptr(), None,
+                                            _chk(keys_in, torch.int64, "keys"), nq, P, k, id_base, _stream()))
+    return dists, ids
+
+
+def synth_codes(n, m, seed, row0=0, device="cuda"):
+    codes = torch.empty((n, m), dtype=torch.uint8, device=device)
+    _lib.check(_lib.lib().rq_dev_synth_codes(codes.data_ptr(), n, m, seed, row0, _stream()))
+    return codes

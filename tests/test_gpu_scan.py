@@ -1,0 +1,198 @@
+"""GPU parity tests of the ADC scan: HIP path (through the C ABI) vs the reference's golden outputs
+and vs the pinned oracle.  Bar: ids AND distances bit-exact (deps/src/linscan_aqd.cpp semantics)."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+SCAN_CASES = ["scan_sift_mini", "scan_deep_mini", "scan_all_ties", "scan_dups", "scan_k_eq_n"]
+
+
+def _eq_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("name", SCAN_CASES)
+def test_legacy_symbol_matches_reference_golden(rq, name):
+    """The signature-identical linscan_aqd_query symbol (what src/Linscan.jl:19-23 ccalls)."""
+    g = golden(name)
+    for K in g["Ks"]:
+        dists, ids = rq.linscan_aqd_query(g["codes"], g["centers"], g["queries"], int(K))
+        assert np.array_equal(ids, g["ids_K%d" % K]), (name, K)
+        assert _eq_bits(dists, g["dists_K%d" % K]), (name, K)
+
+
+@pytest.mark.parametrize("slices", [2, 3, 7])
+@pytest.mark.parametrize("name", ["scan_sift_mini", "scan_dups"])
+def test_row_slices_merge_to_the_same_answer(rq, name, slices):
+    g = golden(name)
+    rq.set_tuning("SCAN_SLICES", slices)
+    try:
+        for K in g["Ks"]:
+            if K * slices > g["codes"].shape[0]:
+                continue
+            dists, ids = rq.linscan_aqd_query(g["codes"], g["centers"], g["queries"], int(K))
+            assert np.array_equal(ids, g["ids_K%d" % K]), (name, K, slices)
+            assert _eq_bits(dists, g["dists_K%d" % K])
+    finally:
+        rq.set_tuning("SCAN_SLICES", 0)
+
+
+def test_linscan_pq_julia_conventions(rq):
+    """linscan_pq(B::Matrix{Int16} one-based, ...) -> one-based UInt32 ids (src/Linscan.jl:25,28-37)."""
+    g = golden("scan_sift_mini")
+    m = g["codes"].shape[1]
+    C = [g["centers"][i] for i in range(m)]
+    B1 = g["codes"].astype(np.int16) + 1
+    dists, idx = rq.linscan_pq(B1, g["queries"], C, 8 * m, 100)
+    assert idx.dtype == np.uint32
+    assert np.array_equal(idx, g["ids_K100"] + 1)
+    assert _eq_bits(dists, g["dists_K100"])
+    d2, i2 = rq.linscan_pq(g["codes"], g["queries"], C, 8 * m, 100)   # UInt8 zero-based overload
+    assert np.array_equal(i2, idx) and _eq_bits(d2, dists)
+
+
+def test_lut_kernel_bit_exact(rq, oracle):
+    import torch
+    from rayuela_jl_amd import device as rqd
+    for name in ["scan_sift_mini", "scan_deep_mini"]:
+        g = golden(name)
+        lut = rqd.adc_lut(torch.from_numpy(g["centers"]).cuda(), torch.from_numpy(g["queries"]).cuda()).cpu().numpy()
+        for q in range(g["queries"].shape[0]):
+            assert _eq_bits(lut[q], oracle.adc_lut(g["centers"], g["queries"][q]))
+
+
+@pytest.mark.parametrize("n,m,sub,nq,K", [
+    (200_000, 8, 16, 40, 1000),    # 5 query groups, SIFT shape
+    (50_001, 8, 16, 13, 100),      # ragged last group, odd row count
+    (30_000, 16, 6, 9, 1000),      # Deep shape: m=16 -> 4 queries per group
+    (20_000, 4, 8, 8, 4096),       # k > 2048: big candidate buffers / sort scratch
+    (9_000, 2, 3, 5, 1),
+    (5_000, 32, 2, 3, 10),
+    (1, 8, 4, 2, 1),               # single row
+    (70_000, 8, 4, 17, 16384),     # RQ_MAX_K
+])
+def test_scan_vs_oracle_random(rq, oracle, n, m, sub, nq, K):
+    import rayuela_jl_amd.synth as synth
+    rng = np.random.default_rng(n * 31 + m)
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=n + 5)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+    assert np.array_equal(i0, i1)
+    assert _eq_bits(d0, d1)
+
+
+def test_shard_merge_equals_single_scan(rq, oracle):
+    """Row shards scanned separately (global ids via id_offset, packed keys out) and merged on the
+    device give the single-scan answer bit for bit -- the multi-GPU data path on one GPU."""
+    import torch
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import device as rqd
+    n, m, sub, nq, K = 120_000, 8, 16, 24, 1000
+    rng = np.random.default_rng(7)
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=99)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    cen, qs = torch.from_numpy(centers).cuda(), torch.from_numpy(queries).cuda()
+    bounds = [0, 30_000, 30_500, 90_001, n]   # uneven shards, one smaller than K
+    keys = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        shard = torch.from_numpy(codes[a:b]).cuda()
+        kk = min(K, b - a)
+        k_sh = rqd.linscan(shard, cen, qs, kk, id_offset=a, want_keys=True)
+        if kk < K:  # pad short lists with the maximum key, like a shard with fewer than K rows
+            pad = torch.full((nq, K - kk), -1, dtype=torch.int64, device="cuda")
+            k_sh = torch.cat([k_sh, pad], dim=1)
+        keys.append(k_sh)
+    keys = torch.stack(keys, dim=1).contiguous()  # [nq][P][K]
+    dists, ids = rqd.merge_topk(keys, K)
+    assert np.array_equal(ids.cpu().numpy().view(np.uint32), i0)
+    assert _eq_bits(dists.cpu().numpy(), d0)
+
+
+def test_linscan_opq_vs_oracle(rq, oracle):
+    g = golden("encode_sift_mini")
+    import rayuela_jl_amd.synth as synth
+    m, d = int(g["m"]), g["X"].shape[1]
+    R = g["R"]
+    centers = g["C"].reshape(m, 256, d // m)
+    codes = g["codes_opq"]
+    queries = synth.sift_like(12, d, seed=555)
+    RQ = oracle.rotate_T(R, queries)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, RQ, 50)
+    d1, i1 = rq.linscan_opq(codes, queries, [centers[i] for i in range(m)], 8 * m, R, 50)
+    assert np.array_equal(i1, i0 + 1)
+    assert _eq_bits(d1, d0)
+
+
+def test_index_handle(rq, oracle):
+    import ctypes
+    g = golden("scan_sift_mini")
+    lib = rq.lib()
+    n, m = g["codes"].shape
+    nq, d = g["queries"].shape
+    cen = np.ascontiguousarray(g["centers"])
+    ix = lib.rq_index_create(m, d, cen.ctypes.data)
+    assert ix
+    try:
+        codes = np.ascontiguousarray(g["codes"])
+        assert lib.rq_index_set_codes(ix, codes.ctypes.data, n, 0) == 0
+        K = 100
+        dists = np.zeros((nq, K), np.float32)
+        ids = np.zeros((nq, K), np.uint32)
+        q = np.ascontiguousarray(g["queries"])
+        assert lib.rq_index_search(ix, dists.ctypes.data, ids.ctypes.data, q.ctypes.data, nq, K, 0) == 0
+        assert np.array_equal(ids, g["ids_K100"]) and _eq_bits(dists, g["dists_K100"])
+    finally:
+        lib.rq_index_destroy(ctypes.c_void_p(ix))
+
+
+def test_argument_errors_are_reported(rq):
+    g = golden("scan_k_eq_n")
+    n = g["codes"].shape[0]
+    C = [g["centers"][i] for i in range(g["centers"].shape[0])]
+    with pytest.raises(rq.RayuelaHipError):   # k > n is undefined behaviour in the reference
+        rq.linscan_pq(g["codes"], g["queries"], C, 8 * len(C), n + 1)
+
+
+def test_full_size_sift1m_properties(rq, oracle):
+    """BASELINE.json size (n=1e6, m=8, nq=1e4 is the bench; here 512 queries, K=1000): size-independent
+    properties on everything + the oracle on a few queries."""
+    import torch
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import device as rqd
+    n, m, sub, nq, K = 1_000_000, 8, 16, 512, 1000
+    rng = np.random.default_rng(2024)
+    centers = (rng.standard_normal((m, 256, sub)) * 20).astype(np.float32)
+    queries = (rng.standard_normal((nq, m * sub)) * 20).astype(np.float32)
+    codes_t = rqd.synth_codes(n, m, seed=synth.SEED_BASE)
+    codes = codes_t.cpu().numpy()
+    assert np.array_equal(codes[:1000], synth.random_codes(1000, m, seed=synth.SEED_BASE))
+    cen, qs = torch.from_numpy(centers).cuda(), torch.from_numpy(queries).cuda()
+    dists, ids = rqd.linscan(codes_t, cen, qs, K)
+    ids64 = ids.long() & 0xFFFFFFFF
+    # ascending lexicographic (dist, id)
+    dd = dists[:, 1:] - dists[:, :-1]
+    assert bool((dd >= 0).all())
+    tie = dd == 0
+    assert bool((ids64[:, 1:][tie] > ids64[:, :-1][tie]).all())
+    # ids unique per query and in range
+    assert bool((ids64 < n).all())
+    assert int((torch.sort(ids64, dim=1).values[:, 1:] == torch.sort(ids64, dim=1).values[:, :-1]).sum()) == 0
+    # every reported distance is the sequential-f32 ADC distance of that row
+    lut = rqd.adc_lut(cen, qs)                                  # [nq][m][256], bit-exact (tested above)
+    rows = codes_t[ids64.reshape(-1)].long().reshape(nq, K, m)
+    acc = torch.zeros((nq, K), dtype=torch.float32, device="cuda")
+    for k in range(m):
+        acc = acc + torch.gather(lut[:, k, :], 1, rows[:, :, k])
+    assert torch.equal(acc, dists)
+    # oracle on a handful of queries
+    sel = [0, 17, 255, 511]
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries[sel], K)
+    assert np.array_equal(ids.cpu().numpy().view(np.uint32)[sel], i0)
+    assert _eq_bits(dists.cpu().numpy()[sel], d0)
