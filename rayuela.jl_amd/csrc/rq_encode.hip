@@ -35,6 +35,7 @@ struct EncParams {
   uint8_t *codes;   // [n][m]
   int64_t n;
   int d, m, h, NT;
+  int i0, i1;       // sub-quantizers handled by this launch (codebooks of [i0,i1) sit in LDS)
   int off[33];      // splitarray offsets (src/utils.jl:179-203)
 };
 
@@ -44,20 +45,21 @@ template <int KS, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void encode_pq_kernel(EncParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int m = p.m, NT = p.NT, h = p.h, d = p.d;
-  float *cbA = reinterpret_cast<float *>(smem);                 // m*NT*KS*64
-  float *saL = cbA + (size_t)m * NT * KS * 64;                  // m*NT*32
-  float *xs_all = saL + (size_t)m * NT * 32;                    // NWAVES * 2KS*33
+  const int i0 = p.i0, mg = p.i1 - p.i0;                        // this launch's group of sub-quantizers
+  float *cbA = reinterpret_cast<float *>(smem);                 // mg*NT*KS*64
+  float *saL = cbA + (size_t)mg * NT * KS * 64;                 // mg*NT*32
+  float *xs_all = saL + (size_t)mg * NT * 32;                   // NWAVES * 2KS*33
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hi = lane >> 5;
   float *xs = xs_all + (size_t)wave * (2 * KS * XS_STRIDE);
 
   // ---- prologue: codebooks -> A-fragment order, norms -> C/D-fragment order -------------------
-  for (int idx = tid; idx < m * NT * KS * 64; idx += NWAVES * 64) {
+  for (int idx = tid; idx < mg * NT * KS * 64; idx += NWAVES * 64) {
     const int l = idx & 63;
     int rest = idx >> 6;
     const int kk = rest % KS; rest /= KS;
     const int t = rest % NT;
-    const int i = rest / NT;
+    const int i = i0 + rest / NT;
     const int sub = p.off[i + 1] - p.off[i];
     const int cen = t * 32 + (l & 31);
     const int s = 2 * kk + (l >> 5);
@@ -65,10 +67,11 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_kernel(EncParams p) {
     if (cen < h && s < sub) v = p.C[(size_t)h * p.off[i] + (size_t)cen * sub + s];
     cbA[idx] = v;
   }
-  for (int idx = tid; idx < m * NT * 32; idx += NWAVES * 64) {
+  for (int idx = tid; idx < mg * NT * 32; idx += NWAVES * 64) {
     const int c32 = idx & 31;
     const int t = (idx >> 5) % NT;
-    const int i = (idx >> 5) / NT;
+    const int il = (idx >> 5) / NT;
+    const int i = i0 + il;
     const int sub = p.off[i + 1] - p.off[i];
     const int cen = t * 32 + c32;
     float sa = __uint_as_float(0x7f800000u);
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_kernel(EncParams p) {
     }
     const int hh = (c32 >> 2) & 1;
     const int r = (c32 & 3) + 4 * (c32 >> 3);
-    saL[((size_t)(i * NT + t) * 2 + hh) * 16 + r] = sa;
+    saL[((size_t)(il * NT + t) * 2 + hh) * 16 + r] = sa;
   }
   __syncthreads();
 
@@ -88,7 +91,8 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_kernel(EncParams p) {
   for (int64_t tile = (int64_t)blockIdx.x * NWAVES + wave; tile < ntiles; tile += total_waves) {
     const int64_t row0 = tile * 32;
     uint64_t cw[4] = {0, 0, 0, 0};
-    for (int i = 0; i < m; ++i) {
+    for (int il = 0; il < mg; ++il) {
+      const int i = i0 + il;
       const int o = p.off[i], sub = p.off[i + 1] - o;
       // stage the 32 x sub slice, transposed: xs[s][row]
       wave_lds_sync();
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_kernel(EncParams p) {
       }
       float best_v = __uint_as_float(0x7f800000u);
       int best_i = 0;
-      const float *cb_i = cbA + (size_t)i * NT * KS * 64 + lane;
-      const float4 *sa_i = reinterpret_cast<const float4 *>(saL + ((size_t)i * NT * 2 + hi) * 16);
+      const float *cb_i = cbA + (size_t)il * NT * KS * 64 + lane;
+      const float4 *sa_i = reinterpret_cast<const float4 *>(saL + ((size_t)il * NT * 2 + hi) * 16);
 #pragma unroll 1
       for (int t = 0; t < NT; ++t) {
         f32x16 acc;
@@ -150,12 +154,12 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_kernel(EncParams p) {
     }
     if (hi == 0 && row0 + j < p.n) {
       uint8_t *o = p.codes + (size_t)(row0 + j) * m;
-      if ((m & 7) == 0) {
+      if ((m & 7) == 0 && mg == m) {
 #pragma unroll
         for (int w = 0; w < 4; ++w)
           if (w * 8 < m) reinterpret_cast<uint64_t *>(o)[w] = cw[w];
       } else {
-        for (int i = 0; i < m; ++i) o[i] = (uint8_t)(cw[i >> 3] >> (8 * (i & 7)));
+        for (int i = i0; i < p.i1; ++i) o[i] = (uint8_t)(cw[i >> 3] >> (8 * (i & 7)));
       }
     }
   }
@@ -246,19 +250,28 @@ __global__ void widen_codes_kernel(int16_t *out1, const uint8_t *codes, size_t n
 
 // ------------------------------------------------------------------------------------------
 template <int KS, int NWAVES>
-static int launch_encode(const EncParams &p, int num_cu, hipStream_t stream) {
-  const size_t lds = ((size_t)p.m * p.NT * KS * 64 + (size_t)p.m * p.NT * 32 +
-                      (size_t)NWAVES * 2 * KS * XS_STRIDE) * sizeof(float);
-  if (lds > 160 * 1024)
-    return fail(RQ_EUNSUPPORTED, "codebooks need %zu B of LDS (> 160 KiB): m=%d h=%d ksteps=%d", lds,
-                p.m, p.h, KS);
+static int launch_encode(EncParams p, int num_cu, hipStream_t stream) {
+  // All m sub-codebooks in LDS when they fit (SIFT: 128 KiB, Deep: 96 KiB); otherwise the
+  // sub-quantizers are encoded in groups, one launch per group (X is re-read per group).
+  const size_t per_sub = ((size_t)p.NT * KS * 64 + (size_t)p.NT * 32) * sizeof(float);
+  const size_t fixed = (size_t)NWAVES * 2 * KS * XS_STRIDE * sizeof(float);
+  const size_t budget = 160 * 1024;
+  if (per_sub + fixed > budget)
+    return fail(RQ_EUNSUPPORTED, "one sub-codebook needs %zu B of LDS (> 160 KiB): h=%d ksteps=%d",
+                per_sub + fixed, p.h, KS);
+  const int gmax = (int)std::min<size_t>((budget - fixed) / per_sub, (size_t)p.m);
   auto kern = encode_pq_kernel<KS, NWAVES>;
-  RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t ntiles = (p.n + 31) / 32;
   const int grid = (int)std::min<int64_t>(num_cu, (ntiles + NWAVES - 1) / NWAVES);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, p);
-  RQ_HIP(hipGetLastError());
+  for (int i0 = 0; i0 < p.m; i0 += gmax) {
+    p.i0 = i0;
+    p.i1 = std::min(p.m, i0 + gmax);
+    const size_t lds = per_sub * (size_t)(p.i1 - p.i0) + fixed;
+    RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, p);
+    RQ_HIP(hipGetLastError());
+  }
   return RQ_OK;
 }
 

@@ -182,35 +182,32 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
       for (int q = 0; q < QG; ++q) tau[q] = ctrl->tau[q];
 
       const uint32_t row0 = base + (uint32_t)tid * RPT;
-      uint32_t w[RPT * Cfg::ROW_WORDS];
+      // the thread's RPT rows as one packed little-endian byte string: byte (r*M + k) of w
+      static_assert((RPT * M) % 16 == 0, "a thread's rows are a whole number of 16-byte loads");
+      uint32_t w[RPT * M / 4];
       if (row0 + RPT <= r_end) {
-        if constexpr ((RPT * M) % 16 == 0) {
-          const uint4 *src = reinterpret_cast<const uint4 *>(p.codes + (size_t)row0 * M);
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.codes + (size_t)row0 * M);
 #pragma unroll
-          for (int i = 0; i < RPT * M / 16; ++i) {
-            const uint4 v = src[i];
-            w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < RPT * M / 4; ++i)
-            w[i] = reinterpret_cast<const uint32_t *>(p.codes + (size_t)row0 * M)[i];
+        for (int i = 0; i < RPT * M / 16; ++i) {
+          const uint4 v = src[i];
+          w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
         }
       } else {
+        // ragged end of the slice: row by row, never touching bytes past row r_end-1
+#pragma unroll
+        for (int i = 0; i < RPT * M / 4; ++i) w[i] = 0;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
+          if (row0 + r < r_end) {
+            if constexpr (M % 4 == 0) {
 #pragma unroll
-          for (int i = 0; i < Cfg::ROW_WORDS; ++i) {
-            uint32_t v = 0;
-            if (row0 + r < r_end) {
-              if constexpr (M % 4 == 0) {
-                v = reinterpret_cast<const uint32_t *>(p.codes + (size_t)(row0 + r) * M)[i];
-              } else {
-                for (int b = 0; b < 4 && i * 4 + b < M; ++b)
-                  v |= (uint32_t)p.codes[(size_t)(row0 + r) * M + i * 4 + b] << (8 * b);
-              }
+              for (int i = 0; i < M / 4; ++i)
+                w[r * (M / 4) + i] = reinterpret_cast<const uint32_t *>(p.codes + (size_t)(row0 + r) * M)[i];
+            } else {
+#pragma unroll
+              for (int k = 0; k < M; ++k)
+                w[(r * M + k) >> 2] |= (uint32_t)p.codes[(size_t)(row0 + r) * M + k] << (8 * ((r * M + k) & 3));
             }
-            w[r * Cfg::ROW_WORDS + i] = v;
           }
         }
       }
@@ -220,10 +217,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
         float acc[QG];
 #pragma unroll
         for (int k = 0; k < M; ++k) {
-          uint32_t word;
-          if constexpr (M % 4 == 0) word = w[(r * M + k) >> 2];
-          else word = w[r * Cfg::ROW_WORDS + (k >> 2)];
-          const uint32_t byte = (word >> (8 * (k & 3))) & 0xffu;
+          const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
 #pragma unroll
           for (int quad = 0; quad < NQUAD; ++quad) {
             const float4 t = lut4[(k * NQUAD + quad) * 256 + byte];
