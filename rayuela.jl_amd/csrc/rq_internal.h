@@ -44,7 +44,7 @@ enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_ENC = 4, WS_SLOT
 struct ScanPlan {
   int qg, blk;
   uint32_t ngroups, nslices, rows_per_slice;
-  uint32_t cap, trigger, p2, scratch_keys, grid;
+  uint32_t cap, trigger, p2, scratch_keys, grid, sample;
   size_t cand_bytes;
   bool lds_ok;
 };

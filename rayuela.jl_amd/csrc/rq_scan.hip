@@ -30,6 +30,13 @@ namespace rq {
 
 constexpr int SCAN_THREADS = 1024;
 
+// v_writelane_b32 (no clang builtin in ROCm 7.2): lane `L` of `old` <- wave-uniform `val`
+template <class T>
+__device__ __forceinline__ uint32_t writelane_u32(uint32_t old, T val, int L) {
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(L));
+  return old;
+}
+
 template <int M>
 struct ScanCfg {
   static constexpr int QG = (M <= 8) ? 8 : 4;      // queries per group
@@ -47,7 +54,8 @@ struct ScanCtrl {
   uint32_t cnt[QG];
   uint32_t sel[QG];     // which half of the candidate ping-pong buffer is current
   uint32_t item;
-  uint32_t pad[3];
+  uint32_t selmask;     // bit q == sel[q] (one LDS word the hot loop reads per block)
+  uint32_t pad[2];
   SelState<QG> st;
 };
 
@@ -64,6 +72,8 @@ struct ScanParams {
   uint32_t trigger;         // compact when cnt > trigger  (cap - BLK >= trigger >= K)
   uint32_t p2;              // next_pow2(K)
   uint32_t scratch_keys;    // LDS sort scratch capacity in keys
+  uint32_t sample;          // rows sampled per slice to initialise tau (0 = off)
+  uint32_t srank_mul;       // target survivors per slice = srank_mul * K (3; 0 forces the fallback, tests)
   uint32_t *work_counter;
   uint64_t *cand;           // [gridDim][QG][2][cap]
   // outputs: direct (nslices == 1 && keys == nullptr) or packed keys [nq][nslices][K]
@@ -105,6 +115,45 @@ __device__ __forceinline__ void build_lut(float *lut, const float *qstage, const
   }
 }
 
+// ADC distances of row r of the packed byte string w for the QG queries of the group:
+// acc_q = ((T_q[0][b0] + T_q[1][b1]) + ...)  -- deps/src/linscan_aqd.cpp:85-87, sequential f32.
+template <int M>
+__device__ __forceinline__ void row_dists(const uint32_t *w, int r, const float4 *lut4,
+                                          float (&acc)[ScanCfg<M>::QG]) {
+  constexpr int NQUAD = ScanCfg<M>::NQUAD;
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
+#pragma unroll
+    for (int quad = 0; quad < NQUAD; ++quad) {
+      const float4 t = lut4[(k * NQUAD + quad) * 256 + byte];
+      if (k == 0) {
+        acc[quad * 4 + 0] = t.x; acc[quad * 4 + 1] = t.y;
+        acc[quad * 4 + 2] = t.z; acc[quad * 4 + 3] = t.w;
+      } else {
+        acc[quad * 4 + 0] = acc[quad * 4 + 0] + t.x;
+        acc[quad * 4 + 1] = acc[quad * 4 + 1] + t.y;
+        acc[quad * 4 + 2] = acc[quad * 4 + 2] + t.z;
+        acc[quad * 4 + 3] = acc[quad * 4 + 3] + t.w;
+      }
+    }
+  }
+}
+
+// one row's M code bytes into w[0 .. M/4) (packed like the hot loop's byte string, r = 0)
+template <int M>
+__device__ __forceinline__ void load_row(uint32_t *w, const uint8_t *codes, uint32_t row) {
+  if constexpr (M % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < M / 4; ++i) w[i] = reinterpret_cast<const uint32_t *>(codes + (size_t)row * M)[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < (M + 3) / 4; ++i) w[i] = 0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) w[k >> 2] |= (uint32_t)codes[(size_t)row * M + k] << (8 * (k & 3));
+  }
+}
+
 // Cut the candidate buffers of the flagged queries back to exactly K keys and refresh tau.
 template <int M>
 __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg,
@@ -121,6 +170,7 @@ __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, ui
   if (need && gi == 0) {
     ctrl->cnt[g] = ctrl->st.newcnt[g];  // == K (keys are unique)
     ctrl->sel[g] = sel ^ 1u;
+    atomicXor(&ctrl->selmask, 1u << g);
     ctrl->tau[g] = key_dist(tau_key);
   }
   __syncthreads();
@@ -129,7 +179,7 @@ __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, ui
 template <int M>
 __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
   using Cfg = ScanCfg<M>;
-  constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD, RPT = Cfg::RPT, BLK = Cfg::BLK;
+  constexpr int QG = Cfg::QG, RPT = Cfg::RPT, BLK = Cfg::BLK;
   constexpr int TPG = SCAN_THREADS / QG;
   constexpr int CTRL_BYTES = (sizeof(ScanCtrl<QG>) + 15) & ~15;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -159,19 +209,54 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
       const uint32_t qq = min(q0 + (uint32_t)q, p.nq - 1u);  // ragged last group: repeat a query
       qstage[e] = p.queries[(size_t)qq * p.d + c];
     }
+    __syncthreads();
+    build_lut<M>(lut, qstage, p.centers, p.sub, p.d, tid);
+    const uint32_t r_begin = slice * p.rows_per_slice;
+    const uint32_t r_end = min(p.n, r_begin + p.rows_per_slice);
+    const uint32_t rows = r_end - r_begin;
+    const float4 *lut4 = reinterpret_cast<const float4 *>(lut);
+    // Threshold initialisation.  attempt 0: tau = the `srank`-th smallest distance of a stratified
+    // sample of S rows, srank ~ 2*K*S/rows + 8, so about 2-3K rows survive the whole slice instead of
+    // K*(1+ln(rows/K)) and no cut is needed before the end.  That tau is an estimate: if fewer
+    // than K rows beat it (needs a sample ~3x off) attempt 1 redoes the slice with tau = +inf,
+    // which is exact by construction.  Either way the answer is exact: whenever >= K rows beat
+    // tau, the K best rows are among them.
+    const uint32_t S = p.sample;
+    uint32_t srank = 0;
+    bool sampled = false;
+    if (S > 0 && p.K >= 256 && rows >= 8u * S && (uint64_t)rows >= 16ull * (uint64_t)p.K) {
+      srank = (uint32_t)(((uint64_t)p.srank_mul * (uint64_t)p.K * S + rows - 1) / rows) + 8u;
+      sampled = srank * 4u <= S;
+    }
+#pragma unroll 1
+    for (int attempt = sampled ? 0 : 1; attempt < 2; ++attempt) {
+    __syncthreads();
     if (tid < QG) {
       ctrl->tau[tid] = __uint_as_float(0x7f800000u);  // +inf: everything passes until the first cut
       ctrl->cnt[tid] = 0;
       ctrl->sel[tid] = 0;
+      if (tid == 0) ctrl->selmask = 0;
     }
     __syncthreads();
-    build_lut<M>(lut, qstage, p.centers, p.sub, p.d, tid);
-    __syncthreads();
+    if (attempt == 0) {
+      const uint32_t step = rows / S;
+#pragma unroll 1
+      for (uint32_t i = tid; i < S; i += SCAN_THREADS) {
+        const uint32_t row = r_begin + i * step + ((i * 2654435761u) >> 8) % step;
+        uint32_t w1[(M + 3) / 4];
+        load_row<M>(w1, p.codes, row);
+        float acc[QG];
+        row_dists<M>(w1, 0, lut4, acc);
+#pragma unroll
+        for (int q = 0; q < QG; ++q) cand_wg[((size_t)q * 2 + 1) * p.cap + i] = make_key(acc[q], row);
+      }
+      __syncthreads();
+      radix_select<QG, TPG, 4>(&ctrl->st, cand_wg + ((size_t)g * 2 + 1) * p.cap, S, srank, true, g, gi);
+      if (gi == 0) ctrl->tau[g] = key_dist(ctrl->st.prefix[g]);
+      __syncthreads();
+    }
 
     // ---- stream the slice -----------------------------------------------------------------------
-    const uint32_t r_begin = slice * p.rows_per_slice;
-    const uint32_t r_end = min(p.n, r_begin + p.rows_per_slice);
-    const float4 *lut4 = reinterpret_cast<const float4 *>(lut);
 #pragma unroll 1
     for (uint32_t base = r_begin; base < r_end; base += BLK) {
       // capacity invariant: cnt[q] + BLK <= cap for every q when a block starts
@@ -180,6 +265,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
       float tau[QG];
 #pragma unroll
       for (int q = 0; q < QG; ++q) tau[q] = ctrl->tau[q];
+      const uint32_t selmask = __builtin_amdgcn_readfirstlane(ctrl->selmask);
 
       const uint32_t row0 = base + (uint32_t)tid * RPT;
       // the thread's RPT rows as one packed little-endian byte string: byte (r*M + k) of w
@@ -215,41 +301,32 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         float acc[QG];
-#pragma unroll
-        for (int k = 0; k < M; ++k) {
-          const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
-#pragma unroll
-          for (int quad = 0; quad < NQUAD; ++quad) {
-            const float4 t = lut4[(k * NQUAD + quad) * 256 + byte];
-            if (k == 0) {
-              acc[quad * 4 + 0] = t.x; acc[quad * 4 + 1] = t.y;
-              acc[quad * 4 + 2] = t.z; acc[quad * 4 + 3] = t.w;
-            } else {
-              acc[quad * 4 + 0] = acc[quad * 4 + 0] + t.x;
-              acc[quad * 4 + 1] = acc[quad * 4 + 1] + t.y;
-              acc[quad * 4 + 2] = acc[quad * 4 + 2] + t.z;
-              acc[quad * 4 + 3] = acc[quad * 4 + 3] + t.w;
-            }
-          }
-        }
+        row_dists<M>(w, r, lut4, acc);
+        // ---- survivors: rows whose distance beats the query's threshold ------------------------
         const bool valid = row0 + r < r_end;
-        bool hit = false;
+        uint64_t mk[QG];
+        uint64_t any = 0;
 #pragma unroll
-        for (int q = 0; q < QG; ++q) hit |= acc[q] < tau[q];
-        if (__any(hit && valid)) {
-          // survivor path: wave-aggregated append, one LDS atomic per (wave, query)
+        for (int q = 0; q < QG; ++q) {
+          mk[q] = __ballot(valid && (acc[q] < tau[q]));
+          any |= mk[q];
+        }
+        if (any) {
+          // ONE LDS atomic for all QG queries: lane q reserves popc(mk[q]) slots of query q
+          uint32_t want = 0;
+#pragma unroll
+          for (int q = 0; q < QG; ++q)
+            want = writelane_u32(want, (uint32_t)__popcll(mk[q]), q);
+          uint32_t got = 0;
+          if (lane < QG && want) got = atomicAdd(&ctrl->cnt[lane], want);
 #pragma unroll
           for (int q = 0; q < QG; ++q) {
-            const bool pq = valid && (acc[q] < tau[q]);
-            const uint64_t mask = __ballot(pq);
-            if (mask) {
-              const int leader = __ffsll((unsigned long long)mask) - 1;
-              uint32_t pos = 0;
-              if (lane == leader) pos = atomicAdd(&ctrl->cnt[q], (uint32_t)__popcll(mask));
-              pos = __shfl(pos, leader);
-              if (pq) {
-                pos += __popcll(mask & ((1ull << lane) - 1ull));
-                uint64_t *buf = cand_wg + ((size_t)q * 2 + ctrl->sel[q]) * p.cap;
+            if (mk[q]) {
+              const uint32_t basep = __builtin_amdgcn_readlane(got, q);
+              if ((mk[q] >> lane) & 1ull) {
+                const uint32_t pos = basep + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32),
+                                              __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
+                uint64_t *buf = cand_wg + ((size_t)q * 2 + ((selmask >> q) & 1u)) * p.cap;
                 buf[pos] = make_key(acc[q], row0 + r + p.id_offset);
               }
             }
@@ -260,10 +337,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
     }
 
     // ---- finish the item: cut to K, sort, write ----------------------------------------------
+    if (attempt == 0) {
+      // the sampled tau must have let at least min(K, rows) rows through for EVERY query
+      const bool shortfall = ctrl->cnt[g] < min((uint32_t)p.K, rows);
+      if (__syncthreads_or(shortfall)) continue;  // exact fallback: redo the slice from tau = +inf
+    }
     {
       bool need = ctrl->cnt[g] > (uint32_t)p.K;
       if (__syncthreads_or(need)) compact_group<M>(ctrl, cand_wg, p, need, g, gi);
     }
+    break;
+    }  // attempts
     // sort `nconc` queries at a time in LDS (scratch aliases the LUT, which is dead now)
     uint32_t nconc = p.scratch_keys / p.p2;
     if (nconc > (uint32_t)QG) nconc = QG;
@@ -362,7 +446,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_topk_kernel(MergeParams p
         const int leader = __ffsll((unsigned long long)mask) - 1;
         uint32_t basep = 0;
         if (lane == leader) basep = atomicAdd(&ctrl->st.newcnt[0], (uint32_t)__popcll(mask));
-        basep = __shfl(basep, leader);
+        basep = __builtin_amdgcn_readlane(basep, leader);
         if (take) {
           const uint32_t pos = basep + __popcll(mask & ((1ull << lane) - 1ull));
           if (pos < p.p2) a[pos] = key;
@@ -453,9 +537,14 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   ns = (n + rps - 1) / rps;
   pl.nslices = (uint32_t)ns;
   pl.rows_per_slice = (uint32_t)rps;
-  const uint32_t slack = std::max<uint32_t>((uint32_t)K, 1024u);
+  // slack between cuts: with the sampled tau about 2-3K rows survive a slice, so a slack of 4K means
+  // "no cut before the end"; the exact fallback (tau from +inf) cuts every `slack` survivors.
+  int slack_i = tuning("SCAN_SLACK", 0);
+  if (slack_i <= 0) slack_i = std::min(std::max(4 * K, 1024), 16384);
+  const uint32_t slack = (uint32_t)slack_i;
   pl.trigger = (uint32_t)K + slack;
-  pl.cap = pl.trigger + Cfg::BLK;
+  pl.sample = (uint32_t)tuning("SCAN_SAMPLE", 8192);
+  pl.cap = std::max<uint32_t>(pl.trigger + Cfg::BLK, pl.sample);
   pl.p2 = next_pow2((uint32_t)K);
   // LDS scratch for the final sort: at least one query, at most QG, within 160 KiB total
   const size_t lds_max = 160 * 1024 - CTRL_BYTES;
@@ -496,6 +585,8 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.id_offset = id_offset; p.id_base = id_base;
   p.nslices = pl.nslices; p.rows_per_slice = pl.rows_per_slice; p.ngroups = pl.ngroups;
   p.cap = pl.cap; p.trigger = pl.trigger; p.p2 = pl.p2; p.scratch_keys = pl.scratch_keys;
+  p.sample = pl.sample;
+  p.srank_mul = (uint32_t)tuning("SCAN_SRANK_MUL", 2);
   p.work_counter = work_counter; p.cand = cand;
   p.dists = dists; p.ids = ids; p.keys = keys;
   RQ_HIP(hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream));

@@ -55,7 +55,9 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 
 // k-th smallest (1-based k) of src[0..cnt) for query-lane g; result in st->prefix[g].
 // `active`, `cnt`, `src`, `k` must be uniform inside a query-lane; cnt >= k when active.
-template <int G, int TPG>
+// NPASS = 8 resolves the full 64-bit key; NPASS = 4 only its distance half (prefix then holds
+// the k-th smallest distance in its top 32 bits, zeros below) -- enough for a threshold estimate.
+template <int G, int TPG, int NPASS = 8>
 __device__ __forceinline__ void radix_select(SelState<G> *st, const uint64_t *__restrict__ src,
                                              uint32_t cnt, uint32_t k, bool active, int g,
                                              int gi) {
@@ -65,16 +67,27 @@ __device__ __forceinline__ void radix_select(SelState<G> *st, const uint64_t *__
     st->krem[g] = k;
   }
 #pragma unroll 1
-  for (int pass = 0; pass < 8; ++pass) {
+  for (int pass = 0; pass < NPASS; ++pass) {
     const int shift = 56 - 8 * pass;
     for (int b = gi; b < 256; b += TPG) st->hist[g][b] = 0;
     __syncthreads();
     if (active) {
       const uint64_t pfx = st->prefix[g];
-      for (uint32_t idx = gi; idx < cnt; idx += TPG) {
-        const uint64_t key = src[idx];
-        const bool match = (pass == 0) || ((key >> (shift + 8)) == (pfx >> (shift + 8)));
-        if (match) atomicAdd(&st->hist[g][(uint32_t)(key >> shift) & 255u], 1u);
+      // 8 independent loads in flight per thread: the keys live in L2, latency-bound otherwise
+      constexpr int U = 8;
+      for (uint32_t idx0 = gi; idx0 < cnt; idx0 += U * TPG) {
+        uint64_t key[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t idx = idx0 + u * TPG;
+          key[u] = idx < cnt ? src[idx] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool match = (idx0 + u * TPG < cnt) &&
+                             ((pass == 0) || ((key[u] >> (shift + 8)) == (pfx >> (shift + 8))));
+          if (match) atomicAdd(&st->hist[g][(uint32_t)(key[u] >> shift) & 255u], 1u);
+        }
       }
     }
     __syncthreads();
@@ -116,7 +129,7 @@ __device__ __forceinline__ void compact_leq(SelState<G> *st, const uint64_t *__r
         const int leader = __ffsll((unsigned long long)mask) - 1;
         uint32_t base = 0;
         if (lane == leader) base = atomicAdd(&st->newcnt[g], (uint32_t)__popcll(mask));
-        base = __shfl(base, leader);
+        base = __builtin_amdgcn_readlane(base, leader);
         if (take) dst[base + __popcll(mask & ((1ull << lane) - 1ull))] = key;
       }
     }

@@ -1,0 +1,116 @@
+"""Row-sharded ADC search over the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm).
+
+The reference has no distributed path; its only "scale the long axis" device is the 1e7-row chunking
+with a carried top-k inside one query (deps/src/linscan_aqd.cpp:52-53,78-92).  The multi-GPU analogue:
+
+  shard     rank r holds rows [offset_r, offset_r + n_r) of the base as resident uint8 codes
+  scan      every rank scans its shard for ALL queries (queries are replicated) and keeps its local
+            top-k as sorted packed keys  (ordered(dist) << 32 | global id)        -- no communication
+  exchange  all_to_all: rank r receives, from every rank, the key lists of the queries it OWNS
+            (queries are split in W contiguous blocks).  Per rank that is (W-1)/W * nq*k*8 bytes in and
+            out over W-1 distinct xGMI links -- versus W times that for an all_gather of everything.
+  merge     each rank merges W sorted lists per owned query (rq_dev_merge_topk).  Keys are totally
+            ordered, so the result is bit-identical to a single-GPU scan of the whole base.
+  gather    the owned results (nq/W * k * 8 bytes per rank) are gathered to rank 0, which returns the
+            arrays the reference API returns.
+
+`scan_fn` / `merge_fn` default to the HIP entry points.  They are injectable ONLY so the exchange
+logic can be exercised on CPU with the gloo backend in tests/ (where the oracle plays the kernels);
+the product never substitutes them.
+"""
+import torch
+import torch.distributed as dist
+
+KEY_MAX = -1  # 0xFFFFFFFFFFFFFFFF as int64
+
+
+def _hip_scan(codes, centers, queries, k, id_offset):
+    from . import device
+    return device.linscan(codes, centers, queries, k, id_offset=id_offset, want_keys=True)
+
+
+def _hip_merge(keys, k, id_base):
+    from . import device
+    return device.merge_topk(keys, k, id_base=id_base)
+
+
+def shard_bounds(n_total, world):
+    """Contiguous row shards, sizes differing by at most one row."""
+    per, extra = divmod(n_total, world)
+    bounds = [0]
+    for r in range(world):
+        bounds.append(bounds[-1] + per + (1 if r < extra else 0))
+    return bounds
+
+
+class ShardedIndex:
+    def __init__(self, codes_local, centers, id_offset, group=None, scan_fn=None, merge_fn=None):
+        self.codes = codes_local          # [n_local][m] uint8, resident on this rank's device
+        self.centers = centers            # [m][256][sub] float32, replicated
+        self.id_offset = int(id_offset)
+        self.group = group
+        self.scan_fn = scan_fn or _hip_scan
+        self.merge_fn = merge_fn or _hip_merge
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def local_keys(self, queries, k):
+        """[nq][k] int64 sorted keys of this shard, padded with KEY_MAX when the shard has < k rows."""
+        n_local = self.codes.shape[0]
+        nq = queries.shape[0]
+        k_local = min(k, n_local)
+        if k_local == 0:
+            return torch.full((nq, k), KEY_MAX, dtype=torch.int64, device=queries.device)
+        keys = self.scan_fn(self.codes, self.centers, queries, k_local, self.id_offset)
+        if k_local < k:
+            pad = torch.full((nq, k - k_local), KEY_MAX, dtype=torch.int64, device=keys.device)
+            keys = torch.cat([keys, pad], dim=1)
+        return keys.contiguous()
+
+    def search_owned(self, queries, k, id_base=0):
+        """Scan + exchange + merge.  Returns (q_lo, q_hi, dists, ids) for the queries this rank owns."""
+        W, r = self.world, self.rank
+        nq = queries.shape[0]
+        keys = self.local_keys(queries, k)
+        per = (nq + W - 1) // W
+        if W == 1:
+            d, i = self.merge_fn(keys.view(nq, 1, k), k, id_base)
+            return 0, nq, d, i
+        if per * W != nq:  # equal splits for all_to_all_single: pad the query axis
+            pad = torch.full((per * W - nq, k), KEY_MAX, dtype=torch.int64, device=keys.device)
+            keys = torch.cat([keys, pad], dim=0)
+        recv = torch.empty_like(keys)                      # [W][per][k]: block s = rank s's lists of MY queries
+        dist.all_to_all_single(recv, keys, group=self.group)
+        mine = recv.view(W, per, k).permute(1, 0, 2).contiguous()   # [per][W][k]
+        d, i = self.merge_fn(mine, k, id_base)
+        q_lo = min(nq, r * per)
+        q_hi = min(nq, (r + 1) * per)
+        return q_lo, q_hi, d, i
+
+    def search(self, queries, k, id_base=0):
+        """On rank 0: (dists [nq][k] float32, ids [nq][k] int32 bit patterns of uint32); None elsewhere."""
+        W = self.world
+        nq = queries.shape[0]
+        q_lo, q_hi, d, i = self.search_owned(queries, k, id_base)
+        if W == 1:
+            return d, i
+        per = d.shape[0]
+        if self.rank == 0:
+            gd = [torch.empty_like(d) for _ in range(W)]
+            gi = [torch.empty_like(i) for _ in range(W)]
+        else:
+            gd = gi = None
+        if dist.get_backend(self.group) == "nccl":
+            # RCCL has no native gather-to-root in torch's ProcessGroupNCCL for lists on all versions;
+            # all_gather of the small per-rank result block (nq/W*k*8 B) is the portable form.
+            gd = [torch.empty_like(d) for _ in range(W)]
+            gi = [torch.empty_like(i) for _ in range(W)]
+            dist.all_gather(gd, d, group=self.group)
+            dist.all_gather(gi, i, group=self.group)
+        else:
+            dist.gather(d, gd, dst=0, group=self.group)
+            dist.gather(i, gi, dst=0, group=self.group)
+        if self.rank != 0:
+            return None
+        return torch.cat(gd, dim=0)[:nq].contiguous(), torch.cat(gi, dim=0)[:nq].contiguous()

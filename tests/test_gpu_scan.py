@@ -86,6 +86,28 @@ def test_scan_vs_oracle_random(rq, oracle, n, m, sub, nq, K):
     assert _eq_bits(d0, d1)
 
 
+@pytest.mark.parametrize("knob,value", [("SCAN_SAMPLE", 0), ("SCAN_SRANK_MUL", 0), ("SCAN_SLACK", 64)])
+def test_threshold_strategies_are_all_exact(rq, oracle, knob, value):
+    """The sampled initial threshold is an optimisation only: with sampling off, with a sample that
+    is forced to be far too tight (exact fallback path) and with a tiny cut slack (many radix cuts)
+    the answer stays bit-identical."""
+    import rayuela_jl_amd.synth as synth
+    n, m, sub, nq, K = 300_000, 8, 16, 16, 1000
+    rng = np.random.default_rng(11)
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=123)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    default = {"SCAN_SAMPLE": 8192, "SCAN_SRANK_MUL": 2, "SCAN_SLACK": 0}[knob]
+    rq.set_tuning(knob, value)
+    try:
+        d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+    finally:
+        rq.set_tuning(knob, default)
+    assert np.array_equal(i0, i1)
+    assert _eq_bits(d0, d1)
+
+
 def test_shard_merge_equals_single_scan(rq, oracle):
     """Row shards scanned separately (global ids via id_offset, packed keys out) and merged on the
     device give the single-scan answer bit for bit -- the multi-GPU data path on one GPU."""

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Quick kernel timings on resident synthetic data (development aid; bench.py is the contract).
+usage: python tools/perf.py [scan] [encode] [rotate] [--n 1000000] [--nq 10000] [--m 8] [--ks 1,100,1000]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rayuela_jl_amd as rq  # noqa: E402
+from rayuela_jl_amd import device as rqd  # noqa: E402
+
+
+def bench(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+ap = argparse.ArgumentParser()
+ap.add_argument("what", nargs="*", default=["scan", "encode", "rotate"])
+ap.add_argument("--n", type=int, default=1_000_000)
+ap.add_argument("--nq", type=int, default=10_000)
+ap.add_argument("--m", type=int, default=8)
+ap.add_argument("--d", type=int, default=128)
+ap.add_argument("--ks", default="1,100,1000")
+ap.add_argument("--iters", type=int, default=5)
+a = ap.parse_args()
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(1)
+n, nq, m, d = a.n, a.nq, a.m, a.d
+sub = d // m
+if "scan" in a.what:
+    codes = rqd.synth_codes(n, m, seed=1234)
+    centers = torch.randn((m, 256, sub), generator=g, device=dev) * 10
+    queries = torch.randn((nq, d), generator=g, device=dev) * 10
+    for K in [int(x) for x in a.ks.split(",")]:
+        out = (torch.empty((nq, K), dtype=torch.float32, device=dev), torch.empty((nq, K), dtype=torch.int32, device=dev))
+        ms = bench(lambda: rqd.linscan(codes, centers, queries, K, out=out), a.iters)
+        print("scan   n=%d nq=%d m=%d K=%-5d %8.3f ms  %10.0f q/s  %7.1f GB/s-alg" % (n, nq, m, K, ms, nq / ms * 1e3, nq * n * m / ms / 1e6))
+if "encode" in a.what:
+    X = torch.randint(0, 200, (n, d), generator=g, device=dev).float()
+    C = torch.randint(0, 200, (256 * d,), generator=g, device=dev).float()
+    out = torch.empty((n, m), dtype=torch.uint8, device=dev)
+    for w in (4, 8):
+        rq.set_tuning("ENC_WAVES", w)
+        ms = bench(lambda: rqd.encode_pq(X, C, m, 256, out=out), a.iters)
+        print("encode n=%d d=%d m=%d waves=%d %8.3f ms  %12.0f vec/s  %6.1f TF" % (n, d, m, w, ms, n / ms * 1e3, 2.0 * d * 256 * n / ms / 1e9))
+    rq.set_tuning("ENC_WAVES", 4)
+if "rotate" in a.what:
+    X = torch.randn((n, d), generator=g, device=dev)
+    R = torch.randn((d, d), generator=g, device=dev)
+    out = torch.empty_like(X)
+    ms = bench(lambda: rqd.rotate_T(R, X, out=out), a.iters)
+    print("rotate n=%d d=%d %8.3f ms  %6.1f TF  %7.1f GB/s" % (n, d, ms, 2.0 * d * d * n / ms / 1e9, 8.0 * d * n / ms / 1e6))
