@@ -41,10 +41,76 @@ struct EncParams {
 
 constexpr int XS_STRIDE = 33;
 
-template <int KS, int NWAVES>
+// One 32-centroid x 32-vector tile of inner products: KS chained 32x32x2 MFMAs (= the fmaf chain
+// s = 0..2KS-1 of the oracle; padded k-steps multiply 0 by 0 and leave the chain untouched).
+template <int KS>
+__device__ __forceinline__ f32x16 tile_dots(const float *cb_tile, const float (&b)[KS]) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cb_tile[kk * 64], b[kk], acc, 0, 0, 0);
+  return acc;
+}
+
+// Epilogue of one tile on the lane's 16 accumulator registers (16 centroids of ONE vector):
+//   u_r = fl(fl(sa_r + sb) - 2 g_r)           (fma(-2, g, t) has the same bits: 2g is exact)
+//   the tile's clamped minimum is cm = max(min_r u_r, 0).
+// f32 MFMA and f32 VALU share the SIMD's FP32 lanes on gfx950 (measured: busy cycles add up, they
+// do not overlap), so every VALU instruction here is paid in full.  Per tile we therefore only
+// keep the running best value and, for the lanes that improved (strict '<': the earliest tile wins
+// ties), a copy of the tile's 16 u values (one shared mask, 16 v_cndmask).  The first-index search
+// runs ONCE per sub-quantizer on that copy (argmin_finish) instead of once per tile.
+struct ArgminState {
+  float best_v;   // clamped minimum so far
+  int best_t;     // tile that holds it
+  float ub[16];   // that tile's u values
+};
+
+__device__ __forceinline__ void tile_argmin(const f32x16 &acc, const float4 *sa4, float sb, int t,
+                                            ArgminState &st) {
+  float u[16];
+  sa4 = reinterpret_cast<const float4 *>(__builtin_assume_aligned(sa4, 16));
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const float4 sav = sa4[g4];
+    u[g4 * 4 + 0] = __builtin_fmaf(-2.0f, acc[g4 * 4 + 0], sav.x + sb);
+    u[g4 * 4 + 1] = __builtin_fmaf(-2.0f, acc[g4 * 4 + 1], sav.y + sb);
+    u[g4 * 4 + 2] = __builtin_fmaf(-2.0f, acc[g4 * 4 + 2], sav.z + sb);
+    u[g4 * 4 + 3] = __builtin_fmaf(-2.0f, acc[g4 * 4 + 3], sav.w + sb);
+  }
+  float m01 = __builtin_fminf(__builtin_fminf(u[0], u[1]), u[2]);
+  float m02 = __builtin_fminf(__builtin_fminf(u[3], u[4]), u[5]);
+  float m03 = __builtin_fminf(__builtin_fminf(u[6], u[7]), u[8]);
+  float m04 = __builtin_fminf(__builtin_fminf(u[9], u[10]), u[11]);
+  float m05 = __builtin_fminf(__builtin_fminf(u[12], u[13]), u[14]);
+  float mm = __builtin_fminf(__builtin_fminf(m01, m02), m03);
+  mm = __builtin_fminf(__builtin_fminf(mm, m04), m05);
+  mm = __builtin_fminf(mm, u[15]);
+  const float cm = __builtin_fmaxf(mm, 0.0f);
+  const bool better = cm < st.best_v;
+  st.best_v = better ? cm : st.best_v;
+  st.best_t = better ? t : st.best_t;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st.ub[r] = better ? u[r] : st.ub[r];
+}
+
+// First index of the clamped minimum inside the winning tile: the first r with u_r <= cm (for
+// cm > 0 that is the first minimum; for cm == 0 the first value the reference's max(.,0) clamps).
+__device__ __forceinline__ int argmin_finish(const ArgminState &st, int hi) {
+  int rf = 15;
+#pragma unroll
+  for (int r = 14; r >= 0; --r) rf = (st.ub[r] <= st.best_v) ? r : rf;
+  return st.best_t * 32 + 4 * hi + 8 * (rf >> 2) + (rf & 3);
+}
+
+// NT = number of 32-centroid tiles (compile time so the whole subspace is straight-line code and
+// the scheduler can slide tile t's epilogue under tile t+1's MFMA chain); KS = k-steps.
+template <int KS, int NT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void encode_pq_kernel(EncParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int m = p.m, NT = p.NT, h = p.h, d = p.d;
+  const int m = p.m, h = p.h, d = p.d;
   const int i0 = p.i0, mg = p.i1 - p.i0;                        // this launch's group of sub-quantizers
   float *cbA = reinterpret_cast<float *>(smem);                 // mg*NT*KS*64
   float *saL = cbA + (size_t)mg * NT * KS * 64;                 // mg*NT*32
@@ -88,62 +154,98 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_kernel(EncParams p) {
 
   const int64_t ntiles = (p.n + 31) / 32;
   const int64_t total_waves = (int64_t)gridDim.x * NWAVES;
-  for (int64_t tile = (int64_t)blockIdx.x * NWAVES + wave; tile < ntiles; tile += total_waves) {
+  const int64_t tile0 = (int64_t)blockIdx.x * NWAVES + wave;
+
+  // X slice of (tile, sub-quantizer) in flight in registers: element e = lane + 64u of the
+  // 32 x sub slice, row-major -> coalesced runs of sub floats per row.  The (row, s) split of e
+  // needs an integer division by sub; it is hoisted: recomputed only when sub changes (uneven
+  // splits, src/utils.jl:179-203), i.e. never in the d % m == 0 case.
+  float xr[KS];
+  int xrow[KS], xs_off[KS];   // row of element u; its LDS offset s*33+row (or -1 past the slice)
+  int cur_sub = -1;
+  auto set_sub = [&](int sub) {
+    if (sub == cur_sub) return;
+    cur_sub = sub;
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      const int e = lane + 64 * u;
+      const int row = e / sub, sx = e - row * sub;
+      xrow[u] = row * d + sx;                       // offset inside the tile, before + off_i
+      xs_off[u] = (e < 32 * sub) ? sx * XS_STRIDE + row : -1;
+    }
+  };
+  auto gload = [&](int64_t tile, int il) {
+    const int i = i0 + il;
+    const int o = p.off[i], sub = p.off[i + 1] - o;
+    set_sub(sub);
+    const int64_t row0 = tile * 32;
+    const bool full = row0 + 32 <= p.n;
+    const float *base = p.X + row0 * d + o;
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      float v = 0.0f;
+      if (xs_off[u] >= 0) {
+        if (full) v = base[xrow[u]];
+        else {  // ragged last tile: clamp the row
+          const int e = lane + 64 * u;
+          int64_t gr = row0 + e / sub;
+          if (gr >= p.n) gr = p.n - 1;
+          v = p.X[gr * d + o + (e % sub)];
+        }
+      }
+      xr[u] = v;
+    }
+  };
+  if (tile0 < ntiles) gload(tile0, 0);
+
+  for (int64_t tile = tile0; tile < ntiles; tile += total_waves) {
     const int64_t row0 = tile * 32;
     uint64_t cw[4] = {0, 0, 0, 0};
+#pragma unroll 1
     for (int il = 0; il < mg; ++il) {
       const int i = i0 + il;
-      const int o = p.off[i], sub = p.off[i + 1] - o;
-      // stage the 32 x sub slice, transposed: xs[s][row]
+      const int sub = p.off[i + 1] - p.off[i];
+      // registers -> LDS, transposed: xs[s][row]   (xs_off still describes THIS slice: gload for
+      // the next one is issued below, after the write)
       wave_lds_sync();
-      for (int e = lane; e < 32 * sub; e += 64) {
-        const int row = e / sub, s = e - row * sub;
-        int64_t gr = row0 + row;
-        if (gr >= p.n) gr = p.n - 1;
-        xs[s * XS_STRIDE + row] = p.X[gr * d + o + s];
-      }
+#pragma unroll
+      for (int u = 0; u < KS; ++u)
+        if (xs_off[u] >= 0) xs[xs_off[u]] = xr[u];
       wave_lds_sync();
+      // next slice's global loads fly while this one is computed
+      if (il + 1 < mg) gload(tile, il + 1);
+      else if (tile + total_waves < ntiles) gload(tile + total_waves, 0);
       float b[KS];
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
-        const int s = 2 * kk + hi;
-        b[kk] = s < sub ? xs[s * XS_STRIDE + j] : 0.0f;
+        const int sx = 2 * kk + hi;
+        b[kk] = sx < sub ? xs[sx * XS_STRIDE + j] : 0.0f;
       }
+      // |x|^2 over the subspace, chain s = 0..sub-1 (padded steps add fma(0,0,sb) == sb)
+      float xv[2 * KS];
+#pragma unroll
+      for (int sx = 0; sx < 2 * KS; ++sx) xv[sx] = sx < sub ? xs[sx * XS_STRIDE + j] : 0.0f;
       float sb = 0.0f;
-      for (int s = 0; s < sub; ++s) {
-        const float xv = xs[s * XS_STRIDE + j];
-        sb = __builtin_fmaf(xv, xv, sb);
-      }
-      float best_v = __uint_as_float(0x7f800000u);
-      int best_i = 0;
+#pragma unroll
+      for (int sx = 0; sx < 2 * KS; ++sx) sb = __builtin_fmaf(xv[sx], xv[sx], sb);
+      ArgminState st;
+      st.best_v = __uint_as_float(0x7f800000u);
+      st.best_t = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st.ub[r] = 0.0f;
       const float *cb_i = cbA + (size_t)il * NT * KS * 64 + lane;
       const float4 *sa_i = reinterpret_cast<const float4 *>(saL + ((size_t)il * NT * 2 + hi) * 16);
-#pragma unroll 1
-      for (int t = 0; t < NT; ++t) {
-        f32x16 acc;
+      // two named accumulators: tile t+1's MFMA chain is in flight while tile t is reduced
+      f32x16 accA = tile_dots<KS>(cb_i, b), accB;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-          const float a = cb_i[(t * KS + kk) * 64];
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[kk], acc, 0, 0, 0);
-        }
-        const float4 *sa4 = sa_i + (size_t)t * 8;  // 2 halves * 16 floats = 8 float4 per tile
-        const int cbase = t * 32 + 4 * hi;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const float4 sav = sa4[g4];
-          const float sa[4] = {sav.x, sav.y, sav.z, sav.w};
-#pragma unroll
-          for (int r3 = 0; r3 < 4; ++r3) {
-            const float tt = sa[r3] + sb;
-            float v = tt - 2.0f * acc[g4 * 4 + r3];
-            v = v > 0.0f ? v : 0.0f;
-            const int idx = cbase + 8 * g4 + r3;
-            if (v < best_v) { best_v = v; best_i = idx; }
-          }
-        }
+      for (int t = 0; t < NT; t += 2) {
+        if (t + 1 < NT) accB = tile_dots<KS>(cb_i + (size_t)(t + 1) * KS * 64, b);
+        tile_argmin(accA, sa_i + (size_t)t * 8, sb, t, st);
+        if (t + 2 < NT) accA = tile_dots<KS>(cb_i + (size_t)(t + 2) * KS * 64, b);
+        if (t + 1 < NT) tile_argmin(accB, sa_i + (size_t)(t + 1) * 8, sb, t + 1, st);
       }
+      float best_v = st.best_v;
+      int best_i = argmin_finish(st, hi);
       // the two half-waves hold disjoint centroid subsets of the same vector
       const float ov = __shfl_xor(best_v, 32);
       const int oi = __shfl_xor(best_i, 32);
@@ -249,8 +351,9 @@ __global__ void widen_codes_kernel(int16_t *out1, const uint8_t *codes, size_t n
 }
 
 // ------------------------------------------------------------------------------------------
-template <int KS, int NWAVES>
+template <int KS, int NT, int NWAVES>
 static int launch_encode(EncParams p, int num_cu, hipStream_t stream) {
+  p.NT = NT;  // centroids are padded to NT*32 (+inf norms, zero rows)
   // All m sub-codebooks in LDS when they fit (SIFT: 128 KiB, Deep: 96 KiB); otherwise the
   // sub-quantizers are encoded in groups, one launch per group (X is re-read per group).
   const size_t per_sub = ((size_t)p.NT * KS * 64 + (size_t)p.NT * 32) * sizeof(float);
@@ -260,7 +363,7 @@ static int launch_encode(EncParams p, int num_cu, hipStream_t stream) {
     return fail(RQ_EUNSUPPORTED, "one sub-codebook needs %zu B of LDS (> 160 KiB): h=%d ksteps=%d",
                 per_sub + fixed, p.h, KS);
   const int gmax = (int)std::min<size_t>((budget - fixed) / per_sub, (size_t)p.m);
-  auto kern = encode_pq_kernel<KS, NWAVES>;
+  auto kern = encode_pq_kernel<KS, NT, NWAVES>;
   const int64_t ntiles = (p.n + 31) / 32;
   const int grid = (int)std::min<int64_t>(num_cu, (ntiles + NWAVES - 1) / NWAVES);
   for (int i0 = 0; i0 < p.m; i0 += gmax) {
@@ -294,11 +397,19 @@ int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int
   }
   p.off[m] = pos;
   const int ks = (maxsub + 1) / 2;
-  const int nw = tuning("ENC_WAVES", 4);
+  const int nw = tuning("ENC_WAVES", 8);
+  const int nt = (h + 31) / 32;
+#define RQ_ENC_NT(KSV, NW)                                                  \
+  do {                                                                     \
+    if (nt <= 1) return launch_encode<KSV, 1, NW>(p, num_cu, stream);       \
+    if (nt <= 2) return launch_encode<KSV, 2, NW>(p, num_cu, stream);       \
+    if (nt <= 4) return launch_encode<KSV, 4, NW>(p, num_cu, stream);       \
+    return launch_encode<KSV, 8, NW>(p, num_cu, stream);                    \
+  } while (0)
 #define RQ_ENC_CASE(KSV)                                                   \
   if (ks <= KSV) {                                                         \
-    if (nw == 8) return launch_encode<KSV, 8>(p, num_cu, stream);          \
-    return launch_encode<KSV, 4>(p, num_cu, stream);                       \
+    if (nw == 4) RQ_ENC_NT(KSV, 4);                                         \
+    RQ_ENC_NT(KSV, 8);                                                      \
   }
   RQ_ENC_CASE(1)
   RQ_ENC_CASE(2)
@@ -308,6 +419,7 @@ int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int
   RQ_ENC_CASE(8)
   RQ_ENC_CASE(16)
   RQ_ENC_CASE(32)
+#undef RQ_ENC_NT
 #undef RQ_ENC_CASE
   return fail(RQ_EUNSUPPORTED, "sub-space dimension %d > 64 not covered by the encode kernels", maxsub);
 }
