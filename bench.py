@@ -53,10 +53,11 @@ def make_data(n, nq, d, kind, rank, device):
     gq = torch.Generator(device=device).manual_seed(4321)
     gc = torch.Generator(device=device).manual_seed(99)
     if kind == "sift":
-        cent = torch.randint(0, 128, (1024, d), generator=gc, device=device).float()
+        ncent = 65536   # ~15 base vectors per centre at 1e6 rows: near-duplicates like SIFT, but resolvable
+        cent = torch.randint(0, 128, (ncent, d), generator=gc, device=device).float()
 
         def gen(rows, gen_):
-            cid = torch.randint(0, 1024, (rows,), generator=gen_, device=device)
+            cid = torch.randint(0, ncent, (rows,), generator=gen_, device=device)
             noise = torch.randint(-16, 17, (rows, d, 4), generator=gen_, device=device).sum(-1).float()
             return (cent[cid] + noise).clamp_(0, 255).contiguous()
     else:
@@ -216,7 +217,7 @@ def main():
         dt1 = time.perf_counter() - t0
         same = bool(np.array_equal(i_cpu, out[1][:s1].cpu().numpy().view(np.uint32)) and
                     np.array_equal(d_cpu.view(np.uint32), out[0][:s1].cpu().numpy().view(np.uint32)))
-        ne = min(n, 100_000)
+        ne = min(n, 1_000_000)
         Xh = (rqd.rotate_T(R, X[:ne]) if use_R else X[:ne]).cpu().numpy()
         t0 = time.perf_counter()
         c_cpu = oracle.encode_pq(Xh, synth.cat_codebooks(C), m, h)
@@ -227,7 +228,7 @@ def main():
                          "g++ -O3 -fopenmp as in deps/build.jl:23" % (s1, nq, K, dt1),
                "gpu_matches_cpu_bit_exact": same,
                "encode": {"value": round(ne / dte, 1), "unit": "vectors/s", "kind": "port", "cores": oracle.num_threads(),
-                          "sample": "%d vectors (%.1f s), oracle/rq_oracle.c" % (ne, dte),
+                          "sample": "%d vectors (%.2f s), oracle/rq_oracle.c" % (ne, dte),
                           "codes_match": bool(np.array_equal(c_cpu, codes[:ne].cpu().numpy()))}}
 
     line = {

@@ -1,0 +1,105 @@
+# RayuelaHIP.jl -- drop-in bodies for Rayuela.jl's PQ/OPQ encode and ADC linear scan on MI355X.
+#
+# Host code stays Julia; every body is a `ccall` into librayuela_hip.so (include/rayuela_hip.h).
+# Signatures, defaults, return types and index bases are those of the reference:
+#   quantize_pq   src/PQ.jl:18-48        quantize_opq  src/OPQ.jl:19-27
+#   linscan_pq    src/Linscan.jl:5-37    linscan_opq   src/Linscan.jl:93-115
+# Julia's column-major arrays are passed as they are: a d-by-n Matrix{Float32} is the C array
+# [n][d] the library expects, an m-by-n Matrix{UInt8} is [n][m], k-by-nq outputs are [nq][k].
+#
+# NOTE: this image has no Julia toolchain, so this file has not been executed here; the identical
+# C ABI is exercised through ctypes by tests/ (rayuela.jl_amd/*.py mirrors this file line by line).
+module RayuelaHIP
+
+export quantize_pq, quantize_opq, linscan_pq, linscan_opq
+
+# deps/build.jl:64-67 writes the library paths into deps/deps.jl; here one constant / env var.
+const librayuela_hip = get(ENV, "RAYUELA_HIP_LIB",
+                           joinpath(@__DIR__, "..", "rayuela.jl_amd", "librayuela_hip.so"))
+
+function _check(status::Cint)
+  if status != 0
+    msg = unsafe_string(ccall((:rq_last_error, librayuela_hip), Cstring, ()))
+    error("librayuela_hip status $status: $msg")
+  end
+  nothing
+end
+
+# cat(C..., dims=3) for even splits; plain concatenation of the column-major blocks otherwise
+_cat_codebooks(C::Vector{Matrix{Float32}}) = vcat([vec(Ci) for Ci in C]...)
+
+"""
+    quantize_pq(X, C, V=false) -> B     (src/PQ.jl:18-48)
+`B::Matrix{Int16}`, m-by-n, one-based.
+"""
+function quantize_pq(X::Matrix{Float32}, C::Vector{Matrix{Float32}}, V::Bool=false)
+  d, n = size(X)
+  m    = length(C)
+  h    = size(C[1], 2)
+  B    = Matrix{Int16}(undef, m, n)
+  if V print("Encoding on $m codebooks with librayuela_hip... ") end
+  _check(ccall((:rq_encode_pq_i16, librayuela_hip), Cint,
+    (Ptr{Int16}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cint, Cint, Cint),
+    B, X, _cat_codebooks(C), Int64(n), Cint(d), Cint(m), Cint(h)))
+  if V println("done") end
+  return B
+end
+
+"""
+    quantize_opq(X, R, C, V=false) -> B     (src/OPQ.jl:19-27) == quantize_pq(R' * X, C, V)
+"""
+function quantize_opq(X::Matrix{Float32}, R::Matrix{Float32}, C::Vector{Matrix{Float32}}, V::Bool=false)
+  d, n = size(X)
+  m    = length(C)
+  h    = size(C[1], 2)
+  B    = Matrix{Int16}(undef, m, n)
+  _check(ccall((:rq_encode_opq_i16, librayuela_hip), Cint,
+    (Ptr{Int16}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cint, Cint, Cint),
+    B, X, R, _cat_codebooks(C), Int64(n), Cint(d), Cint(m), Cint(h)))
+  return B
+end
+
+"""
+    linscan_pq(B, X, C, b, k=10000) -> dists, idx     (src/Linscan.jl:5-26)
+`B::Matrix{UInt8}` zero-based m-by-n; returns k-by-nq `dists::Matrix{Cfloat}` (ascending) and
+`idx::Matrix{Cuint}` ONE-based (the reference's `res .+= 1` is folded into the kernel: id_base = 1).
+"""
+function linscan_pq(B::Matrix{UInt8}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat}}, b::Int, k::Int=10000)
+  m, n  = size(B)
+  d, nq = size(X)
+  @show k, nq
+  dists = zeros(Cfloat, k, nq)
+  res   = zeros(Cuint,  k, nq)
+  _check(ccall((:rq_linscan_pq, librayuela_hip), Cint,
+    (Ptr{Cfloat}, Ptr{Cuint}, Ptr{Cuchar}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Int64, Cint, Cint, Cint, Cint),
+    dists, res, B, cat(C..., dims=3), X, Int64(n), Int64(nq), Cint(b ÷ 8), Cint(d), Cint(k), Cint(1)))
+  return dists, res
+end
+
+function linscan_pq(B::Matrix{T}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat}}, b::Int, k::Int=10000) where T <: Integer
+  B_uint8 = convert(Matrix{UInt8}, B .- 1)      # src/Linscan.jl:35
+  return linscan_pq(B_uint8, X, C, b, k)
+end
+
+"""
+    linscan_opq(B, X, C, b, R, k=10000)     (src/Linscan.jl:93-115) == linscan_pq(B, R' * X, C, b, k)
+"""
+function linscan_opq(B::Matrix{UInt8}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat}}, b::Int,
+                     R::Matrix{Cfloat}, k::Int=10000)
+  m, n  = size(B)
+  d, nq = size(X)
+  dists = zeros(Cfloat, k, nq)
+  res   = zeros(Cuint,  k, nq)
+  _check(ccall((:rq_linscan_opq, librayuela_hip), Cint,
+    (Ptr{Cfloat}, Ptr{Cuint}, Ptr{Cuchar}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Int64, Cint, Cint, Cint, Cint),
+    dists, res, B, cat(C..., dims=3), X, R, Int64(n), Int64(nq), Cint(b ÷ 8), Cint(d), Cint(k), Cint(1)))
+  return dists, res
+end
+
+function linscan_opq(B::Matrix{T}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat}}, b::Int,
+                     R::Matrix{Cfloat}, k::Int=10000) where T <: Integer
+  B_uint8 = convert(Matrix{UInt8}, B .- 1)
+  return linscan_opq(B_uint8, X, C, b, R, k)
+end
+
+end # module

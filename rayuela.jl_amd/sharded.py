@@ -95,20 +95,17 @@ class ShardedIndex:
         q_lo, q_hi, d, i = self.search_owned(queries, k, id_base)
         if W == 1:
             return d, i
-        per = d.shape[0]
-        if self.rank == 0:
-            gd = [torch.empty_like(d) for _ in range(W)]
-            gi = [torch.empty_like(i) for _ in range(W)]
-        else:
-            gd = gi = None
+        # rank 0 collects the owned blocks (nq/W * k * 8 bytes per rank).  ProcessGroupNCCL has no
+        # gather-to-root for tensor lists on every torch version; an all_gather of these small
+        # blocks is the portable RCCL form, gloo (CPU tests) uses a true gather.
         if dist.get_backend(self.group) == "nccl":
-            # RCCL has no native gather-to-root in torch's ProcessGroupNCCL for lists on all versions;
-            # all_gather of the small per-rank result block (nq/W*k*8 B) is the portable form.
             gd = [torch.empty_like(d) for _ in range(W)]
             gi = [torch.empty_like(i) for _ in range(W)]
             dist.all_gather(gd, d, group=self.group)
             dist.all_gather(gi, i, group=self.group)
         else:
+            gd = [torch.empty_like(d) for _ in range(W)] if self.rank == 0 else None
+            gi = [torch.empty_like(i) for _ in range(W)] if self.rank == 0 else None
             dist.gather(d, gd, dst=0, group=self.group)
             dist.gather(i, gi, dst=0, group=self.group)
         if self.rank != 0:
