@@ -42,7 +42,9 @@ struct ScanCfg {
   static constexpr int QG = (M <= 8) ? 8 : 4;      // queries per group
   static constexpr int NQUAD = QG / 4;
   static constexpr int RPT = 32 / (M * NQUAD);      // rows per thread per block
-  static constexpr int BLK = SCAN_THREADS * RPT;    // rows per workgroup block
+  static constexpr int SUB = SCAN_THREADS * RPT;    // rows per sub-step (one 16/32-byte load per lane)
+  static constexpr int U = (M <= 8) ? 4 : 2;        // sub-steps per block: loads of a block fly together
+  static constexpr int BLK = SUB * U;               // rows per workgroup block (barrier / tau refresh period)
   static constexpr int LUT_BYTES = M * QG * 1024;
   static constexpr int ROW_WORDS = (M + 3) / 4;
   static_assert(RPT >= 1, "M too large for this tiling");
@@ -267,37 +269,46 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
       for (int q = 0; q < QG; ++q) tau[q] = ctrl->tau[q];
       const uint32_t selmask = __builtin_amdgcn_readfirstlane(ctrl->selmask);
 
-      const uint32_t row0 = base + (uint32_t)tid * RPT;
-      // the thread's RPT rows as one packed little-endian byte string: byte (r*M + k) of w
+      // the thread's rows of this block: U sub-steps of RPT rows, each one packed little-endian
+      // byte string (byte (r*M + k) of w[u]); all U loads are issued before the first gather
       static_assert((RPT * M) % 16 == 0, "a thread's rows are a whole number of 16-byte loads");
-      uint32_t w[RPT * M / 4];
-      if (row0 + RPT <= r_end) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.codes + (size_t)row0 * M);
+      uint32_t wu[Cfg::U][RPT * M / 4];
 #pragma unroll
-        for (int i = 0; i < RPT * M / 16; ++i) {
-          const uint4 v = src[i];
-          w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-        }
-      } else {
-        // ragged end of the slice: row by row, never touching bytes past row r_end-1
+      for (int u = 0; u < Cfg::U; ++u) {
+        uint32_t *w = wu[u];
+        const uint32_t row0 = base + (uint32_t)u * Cfg::SUB + (uint32_t)tid * RPT;
+        if (row0 + RPT <= r_end) {
+          const uint4 *src = reinterpret_cast<const uint4 *>(p.codes + (size_t)row0 * M);
 #pragma unroll
-        for (int i = 0; i < RPT * M / 4; ++i) w[i] = 0;
+          for (int i = 0; i < RPT * M / 16; ++i) {
+            const uint4 v = src[i];
+            w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+          }
+        } else {
+          // ragged end of the slice: row by row, never touching bytes past row r_end-1
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-          if (row0 + r < r_end) {
-            if constexpr (M % 4 == 0) {
+          for (int i = 0; i < RPT * M / 4; ++i) w[i] = 0;
 #pragma unroll
-              for (int i = 0; i < M / 4; ++i)
-                w[r * (M / 4) + i] = reinterpret_cast<const uint32_t *>(p.codes + (size_t)(row0 + r) * M)[i];
-            } else {
+          for (int r = 0; r < RPT; ++r) {
+            if (row0 + r < r_end) {
+              if constexpr (M % 4 == 0) {
 #pragma unroll
-              for (int k = 0; k < M; ++k)
-                w[(r * M + k) >> 2] |= (uint32_t)p.codes[(size_t)(row0 + r) * M + k] << (8 * ((r * M + k) & 3));
+                for (int i = 0; i < M / 4; ++i)
+                  w[r * (M / 4) + i] = reinterpret_cast<const uint32_t *>(p.codes + (size_t)(row0 + r) * M)[i];
+              } else {
+#pragma unroll
+                for (int k = 0; k < M; ++k)
+                  w[(r * M + k) >> 2] |= (uint32_t)p.codes[(size_t)(row0 + r) * M + k] << (8 * ((r * M + k) & 3));
+              }
             }
           }
         }
       }
 
+#pragma unroll
+      for (int u = 0; u < Cfg::U; ++u) {
+      const uint32_t *w = wu[u];
+      const uint32_t row0 = base + (uint32_t)u * Cfg::SUB + (uint32_t)tid * RPT;
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         float acc[QG];
@@ -333,6 +344,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
           }
         }
       }
+      }  // sub-steps
       __syncthreads();
     }
 
