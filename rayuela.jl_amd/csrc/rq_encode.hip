@@ -345,6 +345,94 @@ __global__ __launch_bounds__(NWAVES * 64) void rotate_kernel(RotParams p) {
   }
 }
 
+// lanes 32-63 of a  <->  lanes 0-31 of b   (v_permlane32_swap_b32)
+__device__ __forceinline__ void swap32(float &a, float &b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+
+// Rotation, fast path for d % 8 == 0 (KK = d/2 compile time): the 32 x d tile of X never touches
+// LDS.  Lane (j, hi) loads the 16-byte pieces X[j][8q + 4hi .. +3]; two v_permlane32_swap per piece
+// pair turn them into the B fragments of k-steps 4q..4q+3 (lanes 0-31 the even, 32-63 the odd
+// dimension of each step).  R stays in LDS in A-fragment order, so LDS holds only d*d*4 bytes and a
+// workgroup can run 8-16 wavefronts; loads of the next tile are issued before the MFMA chains.
+template <int KK, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void rotate_kernel_v2(RotParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int D = 2 * KK, NT = (D + 31) / 32, NP = D / 8;   // NP 16-byte pieces per lane
+  float *RA = reinterpret_cast<float *>(smem);                 // NT*KK*64
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  for (int idx = tid; idx < NT * KK * 64; idx += NWAVES * 64) {
+    const int l = idx & 63;
+    const int kk = (idx >> 6) % KK, t = (idx >> 6) / KK;
+    const int i = t * 32 + (l & 31), k = 2 * kk + (l >> 5);
+    RA[idx] = (i < D) ? p.R[(size_t)i * D + k] : 0.0f;
+  }
+  __syncthreads();
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t total_waves = (int64_t)gridDim.x * NWAVES;
+  const int64_t tile0 = (int64_t)blockIdx.x * NWAVES + wave;
+  float4 nx[NP];
+  auto gload = [&](int64_t tile) {
+    int64_t gr = tile * 32 + j;
+    if (gr >= p.n) gr = p.n - 1;
+    const float4 *src = reinterpret_cast<const float4 *>(p.X + gr * D + 4 * hi);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) nx[q] = src[2 * q];
+  };
+  if (tile0 < ntiles) gload(tile0);
+  for (int64_t tile = tile0; tile < ntiles; tile += total_waves) {
+    const int64_t row0 = tile * 32;
+    float b[KK];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      float x = nx[q].x, y = nx[q].y, z = nx[q].z, w = nx[q].w;
+      swap32(x, y);   // x: dims (8q, 8q+1) = k-step 4q      y: dims (8q+4, 8q+5) = k-step 4q+2
+      swap32(z, w);   // z: dims (8q+2, 8q+3) = k-step 4q+1  w: dims (8q+6, 8q+7) = k-step 4q+3
+      b[4 * q + 0] = x; b[4 * q + 1] = z; b[4 * q + 2] = y; b[4 * q + 3] = w;
+    }
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+      // next tile's loads go out under the last chain of this one (keeps nx's live range short)
+      if (t == NT - 1 && tile + total_waves < ntiles) gload(tile + total_waves);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      const float *ra = RA + (size_t)t * KK * 64 + lane;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk * 64], b[kk], acc, 0, 0, 0);
+      if (row0 + j < p.n) {
+        float *o = p.RX + (size_t)(row0 + j) * D;
+        const int ibase = t * 32 + 4 * hi;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int i0 = ibase + 8 * g4;
+          if (i0 < D)
+            *reinterpret_cast<float4 *>(o + i0) =
+                make_float4(acc[g4 * 4 + 0], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]);
+        }
+      }
+    }
+  }
+}
+
+template <int KK>
+static int launch_rotate_v2(const RotParams &p, int num_cu, hipStream_t stream) {
+  constexpr int NW = 8;
+  constexpr int NT = (2 * KK + 31) / 32;
+  const size_t lds = (size_t)NT * KK * 64 * sizeof(float);
+  auto kern = rotate_kernel_v2<KK, NW>;
+  RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int grid = (int)std::min<int64_t>(num_cu, (ntiles + NW - 1) / NW);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, p);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
 __global__ void widen_codes_kernel(int16_t *out1, const uint8_t *codes, size_t nelem) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nelem) out1[i] = (int16_t)((int)codes[i] + 1);  // src/PQ.jl:45-47: Int16, one-based
@@ -431,6 +519,15 @@ int rotate_launch(float *RX, const float *R, const float *X, int d, int64_t n, i
   p.R = R; p.X = X; p.RX = RX; p.n = n; p.d = d;
   p.NT = (d + 31) / 32;
   p.KK = (d + 1) / 2;
+  if (tuning("ROT_V2", 1) && ((uintptr_t)X & 15) == 0) {
+    switch (d) {
+      case 32: return launch_rotate_v2<16>(p, num_cu, stream);
+      case 64: return launch_rotate_v2<32>(p, num_cu, stream);
+      case 96: return launch_rotate_v2<48>(p, num_cu, stream);
+      case 128: return launch_rotate_v2<64>(p, num_cu, stream);
+      default: break;   // other d: generic LDS-staged kernel below
+    }
+  }
   constexpr int NW = 4;
   const size_t lds = ((size_t)p.NT * p.KK * 64 + (size_t)NW * 2 * p.KK * XS_STRIDE) * sizeof(float);
   if (lds > 160 * 1024) return fail(RQ_EUNSUPPORTED, "rotation with d=%d needs %zu B LDS (> 160 KiB)", d, lds);
