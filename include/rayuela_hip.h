@@ -122,6 +122,10 @@ void rq_index_destroy(rq_index *ix);
  *   SCAN_SLICES  force the number of row slices per shard (0 = automatic)
  *   ENC_WAVES    wavefronts per encode workgroup (4 or 8) */
 int rq_set_tuning(const char *key, int value);
+/* Diagnostics: with tuning SCAN_STATS=1, summed shader-clock cycles (thread 0 of every workgroup) of the
+ * last scan: [0] LUT build [1] threshold sample [2] streaming [3] in-stream cuts [4] final cut [5] sort+write,
+ * [6] number of in-stream cuts, [7] number of exact fallbacks, [8] the row part of [1]; out has 12 slots. */
+int rq_scan_stats(unsigned long long *out12);
 
 /* Milliseconds spent in the last host-pointer call on this thread: total wall, H2D, kernels
  * (hipEvent), D2H -- so the PCIe-inclusive and the resident rates can both be reported. */

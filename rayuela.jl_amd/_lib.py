@@ -46,6 +46,7 @@ SIGNATURES = {
     "rq_index_search": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rq_index_destroy": (None, [_vp]),
     "rq_set_tuning": (_i32, [C.c_char_p, _i32]),
+    "rq_scan_stats": (_i32, [_vp]),
     "rq_last_timing": (_i32, [_vp, _vp, _vp, _vp]),
 }
 
@@ -84,6 +85,13 @@ def check(status):
 
 def set_tuning(key, value):
     check(lib().rq_set_tuning(key.encode(), int(value)))
+
+
+def scan_stats():
+    out = (C.c_uint64 * 12)()
+    check(lib().rq_scan_stats(C.cast(out, C.c_void_p)))
+    names = ["lut", "sample", "stream", "cuts", "final_cut", "sort_write", "n_cuts", "n_fallbacks", "sample_rows", "sort_load", "sort_stages", "sort_out"]
+    return dict(zip(names, [int(x) for x in out]))
 
 
 def last_timing():

@@ -282,6 +282,15 @@ int rq_set_tuning(const char *key, int value) {
   return RQ_OK;
 }
 
+int rq_scan_stats(unsigned long long *out8) {
+  // diagnostics: phase cycle counters of the last scan launched with tuning SCAN_STATS=1
+  void *counter = nullptr;
+  RQ_TRY(workspace(WS_COUNTER, 256, &counter));
+  RQ_HIP(hipDeviceSynchronize());
+  RQ_HIP(hipMemcpy(out8, (char *)counter + 64, 96, hipMemcpyDeviceToHost));
+  return RQ_OK;
+}
+
 int rq_last_timing(double *total_ms, double *h2d_ms, double *kernel_ms, double *d2h_ms) {
   if (total_ms) *total_ms = g_t_total;
   if (h2d_ms) *h2d_ms = g_t_h2d;

@@ -77,6 +77,7 @@ struct ScanParams {
   uint32_t sample;          // rows sampled per slice to initialise tau (0 = off)
   uint32_t srank_mul;       // target survivors per slice = srank_mul * K (3; 0 forces the fallback, tests)
   uint32_t *work_counter;
+  unsigned long long *stats;  // optional [8]: cycles in lut, sample, stream, cuts, final cut, sort; #cuts; #fallbacks
   uint64_t *cand;           // [gridDim][QG][2][cap]
   // outputs: direct (nslices == 1 && keys == nullptr) or packed keys [nq][nslices][K]
   float *dists;
@@ -178,6 +179,11 @@ __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, ui
   __syncthreads();
 }
 
+// phase accounting (diagnostics only; p.stats == nullptr in normal runs)
+#define RQ_STAT_T() ((p.stats && threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull)
+#define RQ_STAT_ADD(slot, t0) do { if (p.stats && threadIdx.x == 0) atomicAdd(&p.stats[slot], (unsigned long long)clock64() - (t0)); } while (0)
+#define RQ_STAT_INC(slot) do { if (p.stats && threadIdx.x == 0) atomicAdd(&p.stats[slot], 1ull); } while (0)
+
 template <int M>
 __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
   using Cfg = ScanCfg<M>;
@@ -212,7 +218,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
       qstage[e] = p.queries[(size_t)qq * p.d + c];
     }
     __syncthreads();
+    unsigned long long t_ph = RQ_STAT_T();
     build_lut<M>(lut, qstage, p.centers, p.sub, p.d, tid);
+    __syncthreads();
+    RQ_STAT_ADD(0, t_ph);
     const uint32_t r_begin = slice * p.rows_per_slice;
     const uint32_t r_end = min(p.n, r_begin + p.rows_per_slice);
     const uint32_t rows = r_end - r_begin;
@@ -240,6 +249,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
       if (tid == 0) ctrl->selmask = 0;
     }
     __syncthreads();
+    if (attempt == 1 && sampled) RQ_STAT_INC(7);
+    t_ph = RQ_STAT_T();
     if (attempt == 0) {
       const uint32_t step = rows / S;
 #pragma unroll 1
@@ -253,17 +264,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
         for (int q = 0; q < QG; ++q) cand_wg[((size_t)q * 2 + 1) * p.cap + i] = make_key(acc[q], row);
       }
       __syncthreads();
+      RQ_STAT_ADD(8, t_ph);
       radix_select<QG, TPG, 4>(&ctrl->st, cand_wg + ((size_t)g * 2 + 1) * p.cap, S, srank, true, g, gi);
       if (gi == 0) ctrl->tau[g] = key_dist(ctrl->st.prefix[g]);
       __syncthreads();
+      RQ_STAT_ADD(1, t_ph);
     }
+    t_ph = RQ_STAT_T();
 
     // ---- stream the slice -----------------------------------------------------------------------
 #pragma unroll 1
     for (uint32_t base = r_begin; base < r_end; base += BLK) {
       // capacity invariant: cnt[q] + BLK <= cap for every q when a block starts
       bool need = ctrl->cnt[g] > p.trigger;
-      if (__syncthreads_or(need)) compact_group<M>(ctrl, cand_wg, p, need, g, gi);
+      if (__syncthreads_or(need)) {
+        const unsigned long long t_c = RQ_STAT_T();
+        compact_group<M>(ctrl, cand_wg, p, need, g, gi);
+        RQ_STAT_ADD(3, t_c);
+        RQ_STAT_INC(6);
+      }
       float tau[QG];
 #pragma unroll
       for (int q = 0; q < QG; ++q) tau[q] = ctrl->tau[q];
@@ -348,6 +367,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
       __syncthreads();
     }
 
+    RQ_STAT_ADD(2, t_ph);
+    t_ph = RQ_STAT_T();
     // ---- finish the item: cut to K, sort, write ----------------------------------------------
     if (attempt == 0) {
       // the sampled tau must have let at least min(K, rows) rows through for EVERY query
@@ -360,6 +381,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
     }
     break;
     }  // attempts
+    RQ_STAT_ADD(4, t_ph);
+    t_ph = RQ_STAT_T();
     // sort `nconc` queries at a time in LDS (scratch aliases the LUT, which is dead now)
     uint32_t nconc = p.scratch_keys / p.p2;
     if (nconc > (uint32_t)QG) nconc = QG;
@@ -374,24 +397,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
       const uint32_t cnt = act ? ctrl->cnt[q] : 0;
       const uint64_t *src = cand_wg + ((size_t)(act ? q : 0) * 2 + (act ? ctrl->sel[q] : 0)) * p.cap;
       __syncthreads();
+      unsigned long long t_s = RQ_STAT_T();
       if (act)
         for (uint32_t i = sgi; i < p.p2; i += tps) a[i] = i < cnt ? src[i] : KEY_MAX;
       __syncthreads();
-      // bitonic network, generic thread-group width
-      for (uint32_t k = 2; k <= p.p2; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-          if (act) {
-            for (uint32_t i = sgi; i < (p.p2 >> 1); i += tps) {
-              const uint32_t lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-              const uint32_t hi = lo | j;
-              const bool up = (lo & k) == 0;
-              const uint64_t x = a[lo], y = a[hi];
-              if ((x > y) == up) { a[lo] = y; a[hi] = x; }
-            }
-          }
-          __syncthreads();
-        }
-      }
+      RQ_STAT_ADD(9, t_s);
+      t_s = RQ_STAT_T();
+      bitonic_sort_tiled(a, p.p2, tps / 64, sgi / 64, sgi & 63, act);
+      RQ_STAT_ADD(10, t_s);
+      t_s = RQ_STAT_T();
       const uint32_t qq = q0 + q;
       if (act && qq < p.nq) {
         if (p.keys) {
@@ -407,7 +421,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
           }
         }
       }
+      __syncthreads();
+      RQ_STAT_ADD(11, t_s);
     }
+    RQ_STAT_ADD(5, t_ph);
   }
 }
 
@@ -467,7 +484,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_topk_kernel(MergeParams p
     }
   }
   __syncthreads();
-  bitonic_sort<MERGE_THREADS>(a, p.p2, true, tid);
+  bitonic_sort_tiled(a, p.p2, MERGE_THREADS / 64, tid / 64, tid & 63, true);
   for (uint32_t i = tid; i < (uint32_t)p.K; i += MERGE_THREADS) {
     const uint64_t key = a[i];
     if (p.keys_out) p.keys_out[(size_t)q * p.K + i] = key;
@@ -600,8 +617,9 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.sample = pl.sample;
   p.srank_mul = (uint32_t)tuning("SCAN_SRANK_MUL", 2);
   p.work_counter = work_counter; p.cand = cand;
+  p.stats = tuning("SCAN_STATS", 0) ? reinterpret_cast<unsigned long long *>(work_counter + 16) : nullptr;
   p.dists = dists; p.ids = ids; p.keys = keys;
-  RQ_HIP(hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream));
+  RQ_HIP(hipMemsetAsync(work_counter, 0, p.stats ? 256 : sizeof(uint32_t), stream));
   switch (m) {
     case 2: return launch_scan<2>(p, pl, stream);
     case 4: return launch_scan<4>(p, pl, stream);

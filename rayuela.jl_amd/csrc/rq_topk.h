@@ -53,6 +53,22 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
   return v;
 }
 
+// hist[digit] += 1 for every lane with `on`.  Keys that share their high bytes (distances of one
+// query, ids below 2^24) put a whole wavefront on ONE bin, and same-address LDS atomics serialise
+// 64-way; that common case is detected with one ballot and served by a single add.
+__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t digit, bool on) {
+  const uint64_t todo = __ballot(on);
+  if (!todo) return;
+  const int leader = __ffsll((unsigned long long)todo) - 1;
+  const uint32_t dl = __builtin_amdgcn_readlane(digit, leader);
+  const uint64_t same = __ballot(on && digit == dl);
+  if (same == todo) {            // the whole wavefront on one bin: one add of the population count
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[dl], (uint32_t)__popcll(same));
+  } else if (on) {
+    atomicAdd(&hist[digit], 1u);
+  }
+}
+
 // k-th smallest (1-based k) of src[0..cnt) for query-lane g; result in st->prefix[g].
 // `active`, `cnt`, `src`, `k` must be uniform inside a query-lane; cnt >= k when active.
 // NPASS = 8 resolves the full 64-bit key; NPASS = 4 only its distance half (prefix then holds
@@ -86,7 +102,7 @@ __device__ __forceinline__ void radix_select(SelState<G> *st, const uint64_t *__
         for (int u = 0; u < U; ++u) {
           const bool match = (idx0 + u * TPG < cnt) &&
                              ((pass == 0) || ((key[u] >> (shift + 8)) == (pfx >> (shift + 8))));
-          if (match) atomicAdd(&st->hist[g][(uint32_t)(key[u] >> shift) & 255u], 1u);
+          hist_add(&st->hist[g][0], (uint32_t)(key[u] >> shift) & 255u, match);
         }
       }
     }
@@ -137,28 +153,57 @@ __device__ __forceinline__ void compact_leq(SelState<G> *st, const uint64_t *__r
   __syncthreads();
 }
 
-// ascending bitonic sort of a[0..p2) (p2 a power of two, uniform over the workgroup).
-template <int TPG>
-__device__ __forceinline__ void bitonic_sort(uint64_t *a, uint32_t p2, bool active, int gi) {
+// one compare-exchange batch: comparators c0, c0+64, ... (up to 4 per lane), loads first
+__device__ __forceinline__ void bitonic_batch(uint64_t *a, uint32_t c0, uint32_t cend, uint32_t j, uint32_t k) {
+  uint32_t lo[4], hi[4];
+  uint64_t x[4], y[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t c = c0 + 64u * u;
+    lo[u] = ((c & ~(j - 1)) << 1) | (c & (j - 1));
+    hi[u] = lo[u] | j;
+    if (c < cend) { x[u] = a[lo[u]]; y[u] = a[hi[u]]; }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t c = c0 + 64u * u;
+    if (c < cend) {
+      const bool up = (lo[u] & k) == 0;
+      if ((x[u] > y[u]) == up) { a[lo[u]] = y[u]; a[hi[u]] = x[u]; }
+    }
+  }
+}
+
+// Ascending bitonic sort of a[0..p2) in LDS by a group of `nw` wavefronts (wave index w, lane).
+// p2 is a power of two and uniform over the WORKGROUP (every thread of the block must call this:
+// it contains __syncthreads()).  Wave w owns the segment [w*E, (w+1)*E), E = p2/nw_eff: every
+// stage whose comparator span 2j fits in a segment is done by the owning wave alone with no block
+// barrier (LDS operations of one wavefront complete in order), only the log2(nw_eff)*(...) wide
+// stages synchronise the workgroup -- 1 of 55 stages at p2 = 1024 with 2 waves.
+__device__ __forceinline__ void bitonic_sort_tiled(uint64_t *a, uint32_t p2, uint32_t nw, uint32_t w,
+                                                   uint32_t lane, bool act) {
+  uint32_t nw_eff = nw;
+  while (nw_eff > 1 && p2 / nw_eff < 128) nw_eff >>= 1;   // keep >= 64 comparators per wave
+  const uint32_t E = p2 / nw_eff;
+  const bool mine = act && w < nw_eff;
+  bool prev_wide = true;   // the caller's fill of a[] came from other waves
 #pragma unroll 1
   for (uint32_t k = 2; k <= p2; k <<= 1) {
 #pragma unroll 1
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      if (active) {
-        for (uint32_t i = gi; i < (p2 >> 1); i += TPG) {
-          const uint32_t lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-          const uint32_t hi = lo | j;
-          const bool up = (lo & k) == 0;
-          const uint64_t x = a[lo], y = a[hi];
-          if ((x > y) == up) {
-            a[lo] = y;
-            a[hi] = x;
-          }
-        }
+      const bool wide = 2 * j > E;
+      if (wide || prev_wide) __syncthreads();
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (mine) {
+        // comparators [w*E/2, (w+1)*E/2) touch only this wave's segment when !wide; for wide stages
+        // the same split is simply a partition of all p2/2 comparators
+        const uint32_t cbeg = w * (E >> 1), cend = cbeg + (E >> 1);
+        for (uint32_t c0 = cbeg + lane; c0 < cend; c0 += 256) bitonic_batch(a, c0, cend, j, k);
       }
-      __syncthreads();
+      prev_wide = wide;
     }
   }
+  __syncthreads();
 }
 
 __host__ __device__ inline uint32_t next_pow2(uint32_t v) {

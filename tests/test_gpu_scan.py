@@ -182,6 +182,30 @@ def test_argument_errors_are_reported(rq):
         rq.linscan_pq(g["codes"], g["queries"], C, 8 * len(C), n + 1)
 
 
+def test_large_base_many_slices(rq, oracle):
+    """SIFT1B-shape proxy on one GPU: 2e8 rows (1.6 GB of codes), few queries -> the planner cuts the
+    base in row slices and merges them; ids above 2^27; oracle on two queries."""
+    import torch
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import device as rqd
+    n, m, sub, nq, K = 200_000_000, 8, 4, 24, 100
+    rng = np.random.default_rng(99)
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes_t = rqd.synth_codes(n, m, seed=77)
+    cen, qs = torch.from_numpy(centers).cuda(), torch.from_numpy(queries).cuda()
+    dists, ids = rqd.linscan(codes_t, cen, qs, K)
+    ids64 = ids.long() & 0xFFFFFFFF
+    dd = dists[:, 1:] - dists[:, :-1]
+    assert bool((dd >= 0).all())
+    assert bool((ids64 < n).all())
+    codes = codes_t.cpu().numpy()
+    sel = [0, 23]
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries[sel], K)
+    assert np.array_equal(ids.cpu().numpy().view(np.uint32)[sel], i0)
+    assert _eq_bits(dists.cpu().numpy()[sel], d0)
+
+
 def test_full_size_sift1m_properties(rq, oracle):
     """BASELINE.json size (n=1e6, m=8, nq=1e4 is the bench; here 512 queries, K=1000): size-independent
     properties on everything + the oracle on a few queries."""

@@ -46,6 +46,11 @@ if "scan" in a.what:
     for K in [int(x) for x in a.ks.split(",")]:
         out = (torch.empty((nq, K), dtype=torch.float32, device=dev), torch.empty((nq, K), dtype=torch.int32, device=dev))
         ms = bench(lambda: rqd.linscan(codes, centers, queries, K, out=out), a.iters)
+        if os.environ.get("RQ_SCAN_STATS"):
+            from rayuela_jl_amd import _lib
+            st = _lib.scan_stats()
+            tot = sum(st[k] for k in ("lut", "sample", "stream", "final_cut", "sort_write")) or 1
+            print("   phases(%%): " + " ".join("%s=%.1f" % (k, 100.0 * st[k] / tot) for k in ("lut", "sample", "stream", "cuts", "final_cut", "sort_write")) + " n_cuts=%d n_fallbacks=%d sample_rows=%.1f%% sort_load=%.1f%% sort_stages=%.1f%% sort_out=%.1f%%" % (st["n_cuts"], st["n_fallbacks"], 100.0 * st["sample_rows"] / tot, 100.0 * st["sort_load"] / tot, 100.0 * st["sort_stages"] / tot, 100.0 * st["sort_out"] / tot))
         print("scan   n=%d nq=%d m=%d K=%-5d %8.3f ms  %10.0f q/s  %7.1f GB/s-alg" % (n, nq, m, K, ms, nq / ms * 1e3, nq * n * m / ms / 1e6))
 if "encode" in a.what:
     X = torch.randint(0, 200, (n, d), generator=g, device=dev).float()
