@@ -45,7 +45,7 @@ struct ScanPlan {
   int qg, blk;
   uint32_t ngroups, nslices, rows_per_slice;
   uint32_t cap, trigger, p2, scratch_keys, grid, sample;
-  size_t cand_bytes;
+  size_t cand_bytes, gtab_off;
   bool lds_ok;
 };
 int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_cu, int force_slices);

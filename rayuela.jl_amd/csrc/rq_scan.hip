@@ -43,9 +43,26 @@ struct ScanCfg {
   static constexpr int NQUAD = QG / 4;
   static constexpr int RPT = 32 / (M * NQUAD);      // rows per thread per block
   static constexpr int SUB = SCAN_THREADS * RPT;    // rows per sub-step (one 16/32-byte load per lane)
-  static constexpr int U = (M <= 8) ? 4 : 2;        // sub-steps per block: loads of a block fly together
+#ifndef RQ_SCAN_U8
+#define RQ_SCAN_U8 4
+#endif
+  static constexpr int U = (M <= 8) ? RQ_SCAN_U8 : 2;  // sub-steps per block: loads of a block fly together
   static constexpr int BLK = SUB * U;               // rows per workgroup block (barrier / tau refresh period)
   static constexpr int LUT_BYTES = M * QG * 1024;
+  // The LDS gather pipe is the kernel's bound (~11-12 cycles per 64-lane ds_read_b128 with random
+  // slots).  The vector-memory path can gather the same 16 bytes from an L1-resident table in ~29
+  // cycles per wavefront (tools/micro/gather_l1.hip) and runs beside the LDS, so the LAST KG
+  // sub-quantizers (~25 % of the gathers, <= 16 KiB of table) are looked up through L1 instead.
+#ifndef RQ_SCAN_KG_DISABLE
+#ifndef RQ_SCAN_KG8
+#define RQ_SCAN_KG8 2
+#endif
+  static constexpr int KG = (M == 8) ? RQ_SCAN_KG8 : (M == 16) ? 4 : (M == 32) ? 4 : (M == 4) ? 1 : 0;
+#else
+  static constexpr int KG = 0;
+#endif
+  static constexpr int KL = M - KG;                 // sub-quantizers [0, KL) gather from LDS
+  static constexpr int GTAB_F4 = KG * NQUAD * 256;  // float4 entries of the global (L1) table
   static constexpr int ROW_WORDS = (M + 3) / 4;
   static_assert(RPT >= 1, "M too large for this tiling");
 };
@@ -77,6 +94,7 @@ struct ScanParams {
   uint32_t sample;          // rows sampled per slice to initialise tau (0 = off)
   uint32_t srank_mul;       // target survivors per slice = srank_mul * K (3; 0 forces the fallback, tests)
   uint32_t *work_counter;
+  float4 *gtab;               // [gridDim][GTAB_F4] L1-gathered part of the LUT
   unsigned long long *stats;  // optional [8]: cycles in lut, sample, stream, cuts, final cut, sort; #cuts; #fallbacks
   uint64_t *cand;           // [gridDim][QG][2][cap]
   // outputs: direct (nslices == 1 && keys == nullptr) or packed keys [nq][nslices][K]
@@ -91,8 +109,8 @@ struct ScanParams {
 // three separately rounded f32 operations like the reference's x86-64 build.
 // ------------------------------------------------------------------------------------------
 template <int M>
-__device__ __forceinline__ void build_lut(float *lut, const float *qstage, const float *centers,
-                                          int sub, int d, int tid) {
+__device__ __forceinline__ void build_lut(float *lut, float4 *gtab, const float *qstage,
+                                          const float *centers, int sub, int d, int tid) {
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD;
   for (int e = tid; e < M * 256; e += SCAN_THREADS) {
@@ -113,7 +131,8 @@ __device__ __forceinline__ void build_lut(float *lut, const float *qstage, const
 #pragma unroll
     for (int quad = 0; quad < NQUAD; ++quad) {
       float4 v = make_float4(acc[quad * 4 + 0], acc[quad * 4 + 1], acc[quad * 4 + 2], acc[quad * 4 + 3]);
-      reinterpret_cast<float4 *>(lut)[(k * NQUAD + quad) * 256 + r] = v;
+      if (k < Cfg::KL) reinterpret_cast<float4 *>(lut)[(k * NQUAD + quad) * 256 + r] = v;
+      else gtab[((k - Cfg::KL) * NQUAD + quad) * 256 + r] = v;
     }
   }
 }
@@ -122,14 +141,22 @@ __device__ __forceinline__ void build_lut(float *lut, const float *qstage, const
 // acc_q = ((T_q[0][b0] + T_q[1][b1]) + ...)  -- deps/src/linscan_aqd.cpp:85-87, sequential f32.
 template <int M>
 __device__ __forceinline__ void row_dists(const uint32_t *w, int r, const float4 *lut4,
-                                          float (&acc)[ScanCfg<M>::QG]) {
-  constexpr int NQUAD = ScanCfg<M>::NQUAD;
+                                          const float4 *__restrict__ gtab, float (&acc)[ScanCfg<M>::QG]) {
+  constexpr int NQUAD = ScanCfg<M>::NQUAD, KL = ScanCfg<M>::KL;
+  // issue the L1 gathers of the last sub-quantizers first: their latency hides under the LDS ones
+  float4 tg[(ScanCfg<M>::KG > 0 ? ScanCfg<M>::KG : 1) * NQUAD];
+#pragma unroll
+  for (int k = KL; k < M; ++k) {
+    const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
+#pragma unroll
+    for (int quad = 0; quad < NQUAD; ++quad) tg[(k - KL) * NQUAD + quad] = gtab[((k - KL) * NQUAD + quad) * 256 + byte];
+  }
 #pragma unroll
   for (int k = 0; k < M; ++k) {
     const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
 #pragma unroll
     for (int quad = 0; quad < NQUAD; ++quad) {
-      const float4 t = lut4[(k * NQUAD + quad) * 256 + byte];
+      const float4 t = k < KL ? lut4[(k * NQUAD + quad) * 256 + byte] : tg[(k - KL) * NQUAD + quad];
       if (k == 0) {
         acc[quad * 4 + 0] = t.x; acc[quad * 4 + 1] = t.y;
         acc[quad * 4 + 2] = t.z; acc[quad * 4 + 3] = t.w;
@@ -200,6 +227,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
   const int lane = tid & 63;
   const int g = tid / TPG, gi = tid % TPG;  // query-lane view used by select / sort
   uint64_t *cand_wg = p.cand + (size_t)blockIdx.x * QG * 2 * p.cap;
+  float4 *gtab = p.gtab + (size_t)blockIdx.x * (Cfg::GTAB_F4 > 0 ? Cfg::GTAB_F4 : 1);
   const uint32_t nitems = p.ngroups * p.nslices;
 
   for (;;) {
@@ -219,8 +247,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
     }
     __syncthreads();
     unsigned long long t_ph = RQ_STAT_T();
-    build_lut<M>(lut, qstage, p.centers, p.sub, p.d, tid);
+    build_lut<M>(lut, gtab, qstage, p.centers, p.sub, p.d, tid);
     __syncthreads();
+    // the L1 part of the table was written by other wavefronts (and the previous item's lines may
+    // still sit in this CU's L1): drop them before the first gather
+    if (Cfg::KG > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     RQ_STAT_ADD(0, t_ph);
     const uint32_t r_begin = slice * p.rows_per_slice;
     const uint32_t r_end = min(p.n, r_begin + p.rows_per_slice);
@@ -259,7 +290,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
         uint32_t w1[(M + 3) / 4];
         load_row<M>(w1, p.codes, row);
         float acc[QG];
-        row_dists<M>(w1, 0, lut4, acc);
+        row_dists<M>(w1, 0, lut4, gtab, acc);
 #pragma unroll
         for (int q = 0; q < QG; ++q) cand_wg[((size_t)q * 2 + 1) * p.cap + i] = make_key(acc[q], row);
       }
@@ -331,7 +362,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         float acc[QG];
-        row_dists<M>(w, r, lut4, acc);
+        row_dists<M>(w, r, lut4, gtab, acc);
         // ---- survivors: rows whose distance beats the query's threshold ------------------------
         const bool valid = row0 + r < r_end;
         uint64_t mk[QG];
@@ -586,6 +617,8 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   const uint64_t items = (uint64_t)pl.ngroups * pl.nslices;
   pl.grid = (uint32_t)std::min<uint64_t>(items, (uint64_t)num_cu);
   pl.cand_bytes = (size_t)pl.grid * Cfg::QG * 2 * pl.cap * sizeof(uint64_t);
+  pl.gtab_off = pl.cand_bytes;   // the L1-gathered LUT parts live behind the candidate buffers
+  pl.cand_bytes += (size_t)pl.grid * (Cfg::GTAB_F4 > 0 ? Cfg::GTAB_F4 : 1) * sizeof(float4);
   pl.lds_ok = ((size_t)pl.p2 * 8 <= lds_max) &&
               ((size_t)Cfg::LUT_BYTES + (size_t)Cfg::QG * d * 4 <= lds_max);
 }
@@ -617,6 +650,7 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.sample = pl.sample;
   p.srank_mul = (uint32_t)tuning("SCAN_SRANK_MUL", 2);
   p.work_counter = work_counter; p.cand = cand;
+  p.gtab = reinterpret_cast<float4 *>(reinterpret_cast<char *>(cand) + pl.gtab_off);
   p.stats = tuning("SCAN_STATS", 0) ? reinterpret_cast<unsigned long long *>(work_counter + 16) : nullptr;
   p.dists = dists; p.ids = ids; p.keys = keys;
   RQ_HIP(hipMemsetAsync(work_counter, 0, p.stats ? 256 : sizeof(uint32_t), stream));
