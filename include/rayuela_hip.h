@@ -61,6 +61,27 @@ void linscan_aqd_query(float *dists, unsigned int *res, unsigned char *codes, fl
                        float *queries, int N, unsigned int NQ, int B, int K, int dim1codes,
                        int dim1queries, int subdim);
 
+/* ---- the same scan for non-orthogonal (additive) quantizers ----------------
+ * Signature-identical to deps/src/linscan_aqd_pairwise_byte.cpp:179-198 (what src/Linscan.jl:145-153 and
+ * :173-181 ccall).  codebooks = hcat(C...) i.e. C [m*h][d], h = 256; ids come back ONE-based like the
+ * reference (:76).  LSQ: T = -2<q,c> per entry, dist = sum_k T[k][b_k] + dbnorms[row].  CQ: T = |q-c|^2. */
+void linscan_aqd_query_extra_byte(float *dists, int *idx, unsigned char *codes, float *queries,
+                                  float *codebooks, float *dbnorms, int nqueries, int ncodes, int m, int h,
+                                  int d, int nn);
+void linscan_aqd_cq_query_extra_byte(float *dists, int *idx, unsigned char *codes, float *queries,
+                                     float *codebooks, int nqueries, int ncodes, int m, int h, int d, int nn);
+/* linscan_lsq (src/Linscan.jl:118-157; R may be NULL = no rotation) and linscan_cq (:160-193). */
+int rq_linscan_lsq(float *dists, uint32_t *ids, const uint8_t *codes, const float *queries,
+                   const float *codebooks, const float *dbnorms, const float *R, int64_t n, int64_t nq,
+                   int m, int h, int d, int k, int id_base);
+int rq_linscan_cq(float *dists, uint32_t *ids, const uint8_t *codes, const float *queries,
+                  const float *codebooks, int64_t n, int64_t nq, int m, int h, int d, int k, int id_base);
+/* device-pointer form; lut_mode 1 = LSQ (dbnorms required), 2 = CQ */
+int rq_dev_linscan_aq(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes,
+                      const float *codebooks, const float *queries, const float *dbnorms, int64_t n,
+                      int64_t nq, int m, int d, int k, int lut_mode, uint32_t id_offset, int id_base,
+                      void *stream);
+
 /* ---- host-pointer entry points (what the julia/ shims ccall) ---------------------------------- */
 /* linscan_pq (src/Linscan.jl:5-26).  id_base = 1 folds Julia's `res .+= 1` into the kernel. */
 int rq_linscan_pq(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers,

@@ -4,6 +4,7 @@
 # Signatures, defaults, return types and index bases are those of the reference:
 #   quantize_pq   src/PQ.jl:18-48        quantize_opq  src/OPQ.jl:19-27
 #   linscan_pq    src/Linscan.jl:5-37    linscan_opq   src/Linscan.jl:93-115
+#   linscan_lsq   src/Linscan.jl:118-157 linscan_cq    src/Linscan.jl:160-193   (SURVEY 8f rank 2)
 # Julia's column-major arrays are passed as they are: a d-by-n Matrix{Float32} is the C array
 # [n][d] the library expects, an m-by-n Matrix{UInt8} is [n][m], k-by-nq outputs are [nq][k].
 #
@@ -11,7 +12,7 @@
 # C ABI is exercised through ctypes by tests/ (rayuela.jl_amd/*.py mirrors this file line by line).
 module RayuelaHIP
 
-export quantize_pq, quantize_opq, linscan_pq, linscan_opq
+export quantize_pq, quantize_opq, linscan_pq, linscan_opq, linscan_lsq, linscan_cq
 
 # deps/build.jl:64-67 writes the library paths into deps/deps.jl; here one constant / env var.
 const librayuela_hip = get(ENV, "RAYUELA_HIP_LIB",
@@ -100,6 +101,48 @@ function linscan_opq(B::Matrix{T}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat}},
                      R::Matrix{Cfloat}, k::Int=10000) where T <: Integer
   B_uint8 = convert(Matrix{UInt8}, B .- 1)
   return linscan_opq(B_uint8, X, C, b, R, k)
+end
+
+"""
+    linscan_lsq(B, X, C, dbnorms, R, k=10000) -> dists, idx     (src/Linscan.jl:118-157)
+ADC search for additive quantizers, database norms passed apart; `idx` is ONE-based as in the reference.
+"""
+function linscan_lsq(B::Matrix{UInt8}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat}},
+                     dbnorms::Vector{Cfloat}, R::Matrix{Cfloat}, k::Int=10000)
+  m, n  = size(B)
+  d, nq = size(X)
+  _, h  = size(C[1])
+  dists = zeros(Cfloat, k, nq)
+  res   = zeros(Cuint,  k, nq)
+  _check(ccall((:rq_linscan_lsq, librayuela_hip), Cint,
+    (Ptr{Cfloat}, Ptr{Cuint}, Ptr{Cuchar}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat},
+     Int64, Int64, Cint, Cint, Cint, Cint, Cint),
+    dists, res, B, X, hcat(C...), dbnorms, R, Int64(n), Int64(nq), Cint(m), Cint(h), Cint(d), Cint(k), Cint(1)))
+  return dists, res
+end
+
+function linscan_lsq(B::Matrix{T}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat}},
+                     dbnorms::Vector{Cfloat}, R::Matrix{Cfloat}, k::Int=10000) where T <: Integer
+  return linscan_lsq(convert(Matrix{UInt8}, B .- 1), X, C, dbnorms, R, k)
+end
+
+"""
+    linscan_cq(B, X, C, k=10000) -> dists, idx     (src/Linscan.jl:160-193)
+"""
+function linscan_cq(B::Matrix{UInt8}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat}}, k::Int=10000)
+  m, n  = size(B)
+  d, nq = size(X)
+  _, h  = size(C[1])
+  dists = zeros(Cfloat, k, nq)
+  res   = zeros(Cuint,  k, nq)
+  _check(ccall((:rq_linscan_cq, librayuela_hip), Cint,
+    (Ptr{Cfloat}, Ptr{Cuint}, Ptr{Cuchar}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Int64, Cint, Cint, Cint, Cint, Cint),
+    dists, res, B, X, hcat(C...), Int64(n), Int64(nq), Cint(m), Cint(h), Cint(d), Cint(k), Cint(1)))
+  return dists, res
+end
+
+function linscan_cq(B::Matrix{T}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat}}, k::Int=10000) where T <: Integer
+  return linscan_cq(convert(Matrix{UInt8}, B .- 1), X, C, k)
 end
 
 end # module

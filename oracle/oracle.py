@@ -61,6 +61,8 @@ def lib():
         _LIB.oracle_splitarray.restype = None
         _LIB.oracle_splitarray.argtypes = [C.c_int, C.c_int, C.c_void_p]
         _LIB.oracle_num_threads.restype = C.c_int
+        _LIB.oracle_linscan_aq.restype = None
+        _LIB.oracle_linscan_aq.argtypes = [C.c_void_p] * 6 + [C.c_int] * 7
     return _LIB
 
 
@@ -78,6 +80,66 @@ def ref():
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
             C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     return _REF
+
+
+_REF_AQ = None
+
+
+def ref_aq_available():
+    return os.path.isfile(os.path.join(_HERE, "_ref", "linscan_aqd_pairwise_byte.so"))
+
+
+def ref_aq():
+    """The compiled reference linscan_aqd_pairwise_byte.so (deps/src/linscan_aqd_pairwise_byte.cpp:179-198)."""
+    global _REF_AQ
+    if _REF_AQ is None:
+        _REF_AQ = C.CDLL(os.path.join(_HERE, "_ref", "linscan_aqd_pairwise_byte.so"))
+        _REF_AQ.linscan_aqd_query_extra_byte.restype = None
+        _REF_AQ.linscan_aqd_query_extra_byte.argtypes = [C.c_void_p] * 6 + [C.c_int] * 6
+        _REF_AQ.linscan_aqd_cq_query_extra_byte.restype = None
+        _REF_AQ.linscan_aqd_cq_query_extra_byte.argtypes = [C.c_void_p] * 5 + [C.c_int] * 6
+    return _REF_AQ
+
+
+def _aq_args(codes, codebooks, queries, dbnorms):
+    codes = _c(codes, np.uint8)
+    codebooks = _c(codebooks, np.float32)     # [m*h][d]
+    queries = _c(queries, np.float32)
+    n, m = codes.shape
+    nq, d = queries.shape
+    h = codebooks.shape[0] // m
+    assert codebooks.shape == (m * h, d)
+    if dbnorms is not None:
+        dbnorms = _c(dbnorms, np.float32)
+        assert dbnorms.shape == (n,)
+    return codes, codebooks, queries, dbnorms, n, m, nq, d, h
+
+
+def linscan_lsq(codes, codebooks, queries, dbnorms, K, use_ref=False):
+    """LSQ scan (restatement, or the real reference with use_ref).  ids ONE-based int32."""
+    codes, codebooks, queries, dbnorms, n, m, nq, d, h = _aq_args(codes, codebooks, queries, dbnorms)
+    dists = np.zeros((nq, K), dtype=np.float32)
+    idx = np.zeros((nq, K), dtype=np.int32)
+    if use_ref:
+        ref_aq().linscan_aqd_query_extra_byte(_ptr(dists), _ptr(idx), _ptr(codes), _ptr(queries), _ptr(codebooks),
+                                              _ptr(dbnorms), nq, n, m, h, d, K)
+    else:
+        lib().oracle_linscan_aq(_ptr(dists), _ptr(idx), _ptr(codes), _ptr(queries), _ptr(codebooks), _ptr(dbnorms),
+                                nq, n, m, h, d, K, 1)
+    return dists, idx
+
+
+def linscan_cq(codes, codebooks, queries, K, use_ref=False):
+    codes, codebooks, queries, _, n, m, nq, d, h = _aq_args(codes, codebooks, queries, None)
+    dists = np.zeros((nq, K), dtype=np.float32)
+    idx = np.zeros((nq, K), dtype=np.int32)
+    if use_ref:
+        ref_aq().linscan_aqd_cq_query_extra_byte(_ptr(dists), _ptr(idx), _ptr(codes), _ptr(queries), _ptr(codebooks),
+                                                 nq, n, m, h, d, K)
+    else:
+        lib().oracle_linscan_aq(_ptr(dists), _ptr(idx), _ptr(codes), _ptr(queries), _ptr(codebooks), None,
+                                nq, n, m, h, d, K, 2)
+    return dists, idx
 
 
 def _c(a, dt):

@@ -154,6 +154,67 @@ void oracle_linscan_aqd_query(float *dists, uint32_t *res, const uint8_t *codes,
   }
 }
 
+/* ------------------------------------------------------------------------- */
+/* deps/src/linscan_aqd_pairwise_byte.cpp:14-94 (mode 1, LSQ: T -= (2 q_k) c_k over the full  */
+/* dimension, dist = sum_k T[h*k + b_k] then + dbnorms[row]) and :97-176 (mode 2, CQ:          */
+/* T += (q_k - c_k)^2, no norms).  codebooks [m*h][d]; ids ONE-based (:76); top-k = the nn       */
+/* smallest (dist, id) pairs in lexicographic order, as partial_sort on pair<float,int> gives.  */
+/* ------------------------------------------------------------------------- */
+void oracle_linscan_aq(float *dists, int *idx, const uint8_t *codes, const float *queries,
+                       const float *codebooks, const float *dbnorms, int nqueries, int ncodes, int m,
+                       int h, int d, int nn, int mode) {
+#pragma omp parallel
+  {
+    float *t = (float *)malloc(sizeof(float) * (size_t)m * h);
+    oracle_pair *heap = (oracle_pair *)malloc(sizeof(oracle_pair) * (size_t)nn);
+#pragma omp for schedule(dynamic, 1)
+    for (int qi = 0; qi < nqueries; qi++) {
+      const float *q = queries + (size_t)qi * d;
+      for (int j = 0; j < m * h; j++) {
+        const float *c = codebooks + (size_t)j * d;
+        float acc = 0.0f;
+        if (mode == 1) {
+          for (int k = 0; k < d; k++) {
+            float two_q = 2 * q[k];
+            float prod = two_q * c[k];
+            acc = acc - prod;
+          }
+        } else {
+          for (int k = 0; k < d; k++) {
+            float diff = q[k] - c[k];
+            float sq = diff * diff;
+            acc = acc + sq;
+          }
+        }
+        t[j] = acc;
+      }
+      int filled = 0;
+      const uint8_t *pc = codes;
+      for (int j = 0; j < ncodes; j++, pc += m) {
+        float acc = 0.0f;
+        for (int k = 0; k < m; k++) acc = acc + t[h * k + pc[k]];
+        if (dbnorms) acc = acc + dbnorms[j];
+        oracle_pair p = {acc, (uint32_t)(j + 1)};
+        if (filled < nn) {
+          heap[filled++] = p;
+          if (filled == nn)
+            for (int i = nn / 2 - 1; i >= 0; i--) heap_sift_down(heap, nn, i);
+        } else if (pair_less(p, heap[0])) {
+          heap[0] = p;
+          heap_sift_down(heap, nn, 0);
+        }
+      }
+      qsort(heap, (size_t)filled, sizeof(oracle_pair), pair_cmp_qsort);
+      for (int j = 0; j < filled; j++) {
+        dists[(size_t)qi * nn + j] = heap[j].dist;
+        idx[(size_t)qi * nn + j] = (int)heap[j].id;
+      }
+    }
+    free(t);
+    free(heap);
+  }
+}
+
 /* Full ADC distance row for one query (no top-K) -- used by tests to check     */
 /* distances of arbitrary ids and by the merge tests.                            */
 void oracle_adc_distances(float *out, const uint8_t *codes, const float *centers,

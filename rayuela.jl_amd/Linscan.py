@@ -67,6 +67,71 @@ def linscan_opq(B, X, C, b, R, k=10000):
     return dists, idx
 
 
+def _hcat(C, m, d):
+    arr = np.concatenate([_as_f32(c, "C[i]") for c in C], axis=0)   # hcat(C...) == [m*h][d] in memory
+    if arr.shape != (m * 256, d):
+        raise ValueError("linscan_lsq/cq need m codebooks of shape (256, d); got %s" % (arr.shape,))
+    return np.ascontiguousarray(arr)
+
+
+def linscan_lsq(B, X, C, dbnorms, R, k=10000):
+    """linscan_lsq(B, X, C, dbnorms, R, k=10000) -> dists, idx      (src/Linscan.jl:118-157)
+
+    ADC search for additive (non-orthogonal) quantizers with the database norms passed apart:
+    table T = -2<R'x, c> per codebook entry, dist = sum_k T[k][b_k] + dbnorms[row].
+    B (n, m) uint8 zero-based (or other ints one-based); C list of m (256, d) full-dimensional codebooks;
+    dbnorms (n,) float32; R (d, d).  idx ONE-based (the C code already returns them so, :76)."""
+    Bu = _codes_u8(B)
+    X = _as_f32(X, "X")
+    R = _as_f32(R, "R")
+    n, m = Bu.shape
+    nq, d = X.shape
+    cb = _hcat(C, m, d)
+    nrm = np.ascontiguousarray(dbnorms, dtype=np.float32)
+    if nrm.shape != (n,):
+        raise ValueError("dbnorms must have one entry per database row")
+    dists = np.zeros((nq, k), dtype=np.float32)
+    idx = np.zeros((nq, k), dtype=np.uint32)
+    _lib.check(_lib.lib().rq_linscan_lsq(dists.ctypes.data, idx.ctypes.data, Bu.ctypes.data, X.ctypes.data,
+                                         cb.ctypes.data, nrm.ctypes.data, R.ctypes.data, n, nq, m, 256, d, k, 1))
+    return dists, idx
+
+
+def linscan_cq(B, X, C, k=10000):
+    """linscan_cq(B, X, C, k=10000) -> dists, idx      (src/Linscan.jl:160-193): T = |x - c|^2 per entry."""
+    Bu = _codes_u8(B)
+    X = _as_f32(X, "X")
+    n, m = Bu.shape
+    nq, d = X.shape
+    cb = _hcat(C, m, d)
+    dists = np.zeros((nq, k), dtype=np.float32)
+    idx = np.zeros((nq, k), dtype=np.uint32)
+    _lib.check(_lib.lib().rq_linscan_cq(dists.ctypes.data, idx.ctypes.data, Bu.ctypes.data, X.ctypes.data,
+                                        cb.ctypes.data, n, nq, m, 256, d, k, 1))
+    return dists, idx
+
+
+def linscan_aqd_query_extra_byte(codes, queries, codebooks, dbnorms, K):
+    """Raw C symbol of deps/src/linscan_aqd_pairwise_byte.cpp:181-188 (ids ONE-based int32)."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    queries = np.ascontiguousarray(queries, dtype=np.float32)
+    codebooks = np.ascontiguousarray(codebooks, dtype=np.float32)
+    n, m = codes.shape
+    nq, d = queries.shape
+    h = codebooks.shape[0] // m
+    dists = np.zeros((nq, K), dtype=np.float32)
+    idx = np.zeros((nq, K), dtype=np.int32)
+    if dbnorms is None:
+        _lib.lib().linscan_aqd_cq_query_extra_byte(dists.ctypes.data, idx.ctypes.data, codes.ctypes.data,
+                                                   queries.ctypes.data, codebooks.ctypes.data, nq, n, m, h, d, K)
+    else:
+        dbnorms = np.ascontiguousarray(dbnorms, dtype=np.float32)
+        _lib.lib().linscan_aqd_query_extra_byte(dists.ctypes.data, idx.ctypes.data, codes.ctypes.data,
+                                                queries.ctypes.data, codebooks.ctypes.data, dbnorms.ctypes.data,
+                                                nq, n, m, h, d, K)
+    return dists, idx
+
+
 def linscan_aqd_query(codes, centers, queries, K):
     """The raw C symbol of deps/src/linscan_aqd.cpp:105-114 (zero-based ids), as Linscan.jl ccalls it."""
     codes = np.ascontiguousarray(codes, dtype=np.uint8)

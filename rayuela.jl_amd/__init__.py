@@ -9,6 +9,8 @@ from ._lib import RayuelaHipError, lib, lib_path, set_tuning, last_timing  # noq
 from .utils import splitarray, cat_codebooks  # noqa: F401
 from .PQ import quantize_pq, quantize_pq_u8  # noqa: F401
 from .OPQ import quantize_opq, rotate  # noqa: F401
-from .Linscan import linscan_pq, linscan_opq, linscan_aqd_query, eval_recall  # noqa: F401
+from .Linscan import (linscan_pq, linscan_opq, linscan_lsq, linscan_cq, linscan_aqd_query,  # noqa: F401
+                      linscan_aqd_query_extra_byte, eval_recall)
 
-__all__ = ["quantize_pq", "quantize_opq", "linscan_pq", "linscan_opq", "eval_recall", "splitarray"]
+__all__ = ["quantize_pq", "quantize_opq", "linscan_pq", "linscan_opq", "linscan_lsq", "linscan_cq",
+           "eval_recall", "splitarray"]

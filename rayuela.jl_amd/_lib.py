@@ -27,6 +27,11 @@ SIGNATURES = {
     "rq_device_count": (_i32, []),
     "rq_set_device": (_i32, [_i32]),
     "linscan_aqd_query": (None, [_vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i32, _i32, _i32, _i32, _i32]),
+    "linscan_aqd_query_extra_byte": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "linscan_aqd_cq_query_extra_byte": (None, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "rq_linscan_lsq": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32]),
+    "rq_linscan_cq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32]),
+    "rq_dev_linscan_aq": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _u32, _i32, _vp]),
     "rq_linscan_pq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32]),
     "rq_linscan_opq": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32]),
     "rq_encode_pq": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32]),

@@ -119,10 +119,11 @@ struct Timer {
 // ---- shared implementation of the scan on device pointers --------------------------------------------
 static int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes, const float *centers,
                        const float *queries, int64_t n, int64_t nq, int m, int d, int k, uint32_t id_offset,
-                       int id_base, hipStream_t stream) {
+                       int id_base, hipStream_t stream, int lut_mode = LUT_PQ, const float *row_bias = nullptr) {
   if (nq <= 0) return RQ_OK;
   if (n < 1 || n >= (1LL << 31)) return fail(RQ_EINVAL, "n=%lld must be in [1, 2^31)", (long long)n);
-  if (m < 1 || d < m || d % m != 0)
+  if (lut_mode < LUT_PQ || lut_mode > LUT_CQ) return fail(RQ_EINVAL, "lut_mode=%d", lut_mode);
+  if (m < 1 || d < 1 || (lut_mode == LUT_PQ && (d < m || d % m != 0)))
     return fail(RQ_EINVAL, "scan needs d %% m == 0 (src/Linscan.jl:23 Cint(d/m)); got d=%d m=%d", d, m);
   if (k < 1 || k > RQ_MAX_K) return fail(RQ_EUNSUPPORTED, "k=%d outside [1, %d]", k, RQ_MAX_K);
   if (k > n) return fail(RQ_EINVAL, "k=%d > n=%lld (undefined in the reference, deps/src/linscan_aqd.cpp:91)", k, (long long)n);
@@ -142,16 +143,16 @@ static int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_
     // one slice: the scan kernel writes the final answer itself
     if (keys && (dists || ids)) {
       RQ_TRY(scan_launch(pl, nullptr, nullptr, keys, codes, centers, queries, n, nq, m, d, k, id_offset, id_base,
-                         (uint32_t *)counter, (uint64_t *)cand, stream));
+                         (uint32_t *)counter, (uint64_t *)cand, stream, lut_mode, row_bias));
       return merge_launch(dists, ids, nullptr, keys, nq, 1, k, id_base, stream);
     }
     return scan_launch(pl, dists, ids, keys, codes, centers, queries, n, nq, m, d, k, id_offset, id_base,
-                       (uint32_t *)counter, (uint64_t *)cand, stream);
+                       (uint32_t *)counter, (uint64_t *)cand, stream, lut_mode, row_bias);
   }
   void *part = nullptr;
   RQ_TRY(workspace(WS_KEYS, (size_t)nq * pl.nslices * k * sizeof(uint64_t), &part));
   RQ_TRY(scan_launch(pl, nullptr, nullptr, (uint64_t *)part, codes, centers, queries, n, nq, m, d, k, id_offset,
-                     id_base, (uint32_t *)counter, (uint64_t *)cand, stream));
+                     id_base, (uint32_t *)counter, (uint64_t *)cand, stream, lut_mode, row_bias));
   return merge_launch(dists, ids, keys, (const uint64_t *)part, nq, (int)pl.nslices, k, id_base, stream);
 }
 
@@ -186,6 +187,54 @@ static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const
   }
   RQ_TRY(dev_linscan(dd.as<float>(), di_.as<uint32_t>(), nullptr, dcodes.as<uint8_t>(), dcent.as<float>(), qdev,
                      n, nq, m, d, k, 0, id_base, nullptr));
+  RQ_HIP(hipDeviceSynchronize());
+  g_t_kernel = t2.ms();
+  Timer t3;
+  RQ_HIP(hipMemcpy(dists, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+  RQ_HIP(hipMemcpy(ids, di_.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+  g_t_d2h = t3.ms();
+  g_t_total = tt.ms();
+  return RQ_OK;
+}
+
+// linscan_lsq / linscan_cq on host pointers (src/Linscan.jl:118-193): codebooks [m*h][d], h = 256
+static int host_linscan_aq(float *dists, uint32_t *ids, const uint8_t *codes, const float *queries,
+                           const float *codebooks, const float *dbnorms, const float *R, int64_t n, int64_t nq,
+                           int m, int h, int d, int k, int id_base, int lut_mode) {
+  Timer tt;
+  g_t_h2d = g_t_kernel = g_t_d2h = 0;
+  if (nq <= 0) return RQ_OK;
+  if (h != 256) return fail(RQ_EUNSUPPORTED, "the scan kernels cover h = 256 (uint8 codes); got h=%d", h);
+  if (n < 1 || m < 1 || d < 1) return fail(RQ_EINVAL, "bad shape n=%lld m=%d d=%d", (long long)n, m, d);
+  if (k < 1 || k > n) return fail(RQ_EINVAL, "k=%d must be in [1, n=%lld]", k, (long long)n);
+  if (lut_mode == LUT_LSQ && !dbnorms) return fail(RQ_EINVAL, "dbnorms is NULL");
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  DevBuf dcodes, dcb, dq, dn, dr, drq, dd, di_;
+  const size_t cb = (size_t)n * m, ce = (size_t)m * 256 * d * 4, qb = (size_t)nq * d * 4;
+  RQ_TRY(dcodes.alloc(cb)); RQ_TRY(dcb.alloc(ce)); RQ_TRY(dq.alloc(qb));
+  RQ_TRY(dd.alloc((size_t)nq * k * 4)); RQ_TRY(di_.alloc((size_t)nq * k * 4));
+  Timer t1;
+  RQ_HIP(hipMemcpy(dcodes.p, codes, cb, hipMemcpyHostToDevice));
+  RQ_HIP(hipMemcpy(dcb.p, codebooks, ce, hipMemcpyHostToDevice));
+  RQ_HIP(hipMemcpy(dq.p, queries, qb, hipMemcpyHostToDevice));
+  if (dbnorms) {
+    RQ_TRY(dn.alloc((size_t)n * 4));
+    RQ_HIP(hipMemcpy(dn.p, dbnorms, (size_t)n * 4, hipMemcpyHostToDevice));
+  }
+  const float *qdev = dq.as<float>();
+  if (R) {
+    RQ_TRY(dr.alloc((size_t)d * d * 4)); RQ_TRY(drq.alloc(qb));
+    RQ_HIP(hipMemcpy(dr.p, R, (size_t)d * d * 4, hipMemcpyHostToDevice));
+  }
+  g_t_h2d = t1.ms();
+  Timer t2;
+  if (R) {
+    RQ_TRY(rotate_launch(drq.as<float>(), dr.as<float>(), dq.as<float>(), d, nq, di.num_cu, nullptr));
+    qdev = drq.as<float>();
+  }
+  RQ_TRY(dev_linscan(dd.as<float>(), di_.as<uint32_t>(), nullptr, dcodes.as<uint8_t>(), dcb.as<float>(), qdev, n, nq,
+                     m, d, k, 0, id_base, nullptr, lut_mode, dbnorms ? dn.as<float>() : nullptr));
   RQ_HIP(hipDeviceSynchronize());
   g_t_kernel = t2.ms();
   Timer t3;
@@ -312,6 +361,40 @@ void linscan_aqd_query(float *dists, unsigned int *res, unsigned char *codes, fl
     rc = host_linscan(dists, res, codes, centers, queries, nullptr, N, NQ, m, dim1queries, K, 0);
   }
   if (rc != RQ_OK) fprintf(stderr, "librayuela_hip: linscan_aqd_query failed (%d): %s\n", rc, g_err);
+}
+
+void linscan_aqd_query_extra_byte(float *dists, int *idx, unsigned char *codes, float *queries, float *codebooks,
+                                  float *dbnorms, int nqueries, int ncodes, int m, int h, int d, int nn) {
+  const int rc = host_linscan_aq(dists, (uint32_t *)idx, codes, queries, codebooks, dbnorms, nullptr, ncodes, nqueries,
+                                 m, h, d, nn, 1, LUT_LSQ);   // ids ONE-based (linscan_aqd_pairwise_byte.cpp:76)
+  if (rc != RQ_OK) fprintf(stderr, "librayuela_hip: linscan_aqd_query_extra_byte failed (%d): %s\n", rc, g_err);
+}
+
+void linscan_aqd_cq_query_extra_byte(float *dists, int *idx, unsigned char *codes, float *queries, float *codebooks,
+                                     int nqueries, int ncodes, int m, int h, int d, int nn) {
+  const int rc = host_linscan_aq(dists, (uint32_t *)idx, codes, queries, codebooks, nullptr, nullptr, ncodes, nqueries,
+                                 m, h, d, nn, 1, LUT_CQ);
+  if (rc != RQ_OK) fprintf(stderr, "librayuela_hip: linscan_aqd_cq_query_extra_byte failed (%d): %s\n", rc, g_err);
+}
+
+int rq_linscan_lsq(float *dists, uint32_t *ids, const uint8_t *codes, const float *queries, const float *codebooks,
+                   const float *dbnorms, const float *R, int64_t n, int64_t nq, int m, int h, int d, int k,
+                   int id_base) {
+  return host_linscan_aq(dists, ids, codes, queries, codebooks, dbnorms, R, n, nq, m, h, d, k, id_base, LUT_LSQ);
+}
+
+int rq_linscan_cq(float *dists, uint32_t *ids, const uint8_t *codes, const float *queries, const float *codebooks,
+                  int64_t n, int64_t nq, int m, int h, int d, int k, int id_base) {
+  return host_linscan_aq(dists, ids, codes, queries, codebooks, nullptr, nullptr, n, nq, m, h, d, k, id_base, LUT_CQ);
+}
+
+int rq_dev_linscan_aq(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes, const float *codebooks,
+                      const float *queries, const float *dbnorms, int64_t n, int64_t nq, int m, int d, int k,
+                      int lut_mode, uint32_t id_offset, int id_base, void *stream) {
+  if (lut_mode != LUT_LSQ && lut_mode != LUT_CQ) return fail(RQ_EINVAL, "lut_mode must be 1 (LSQ) or 2 (CQ)");
+  if (lut_mode == LUT_LSQ && !dbnorms) return fail(RQ_EINVAL, "dbnorms is NULL");
+  return dev_linscan(dists, ids, keys, codes, codebooks, queries, n, nq, m, d, k, id_offset, id_base,
+                     (hipStream_t)stream, lut_mode, lut_mode == LUT_LSQ ? dbnorms : nullptr);
 }
 
 int rq_linscan_pq(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers, const float *queries,

@@ -52,7 +52,8 @@ int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_
 int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes,
                 const float *centers, const float *queries, int64_t n, int64_t nq, int m, int d, int K,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
-                hipStream_t stream);
+                hipStream_t stream, int lut_mode = 0, const float *row_bias = nullptr);
+enum { LUT_PQ = 0, LUT_LSQ = 1, LUT_CQ = 2 };
 int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t *keys_in, int64_t nq,
                  int P, int K, int id_base, hipStream_t stream);
 int lut_launch(float *lut, const float *centers, const float *queries, int64_t nq, int m, int sub,

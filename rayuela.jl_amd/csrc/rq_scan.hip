@@ -84,6 +84,8 @@ struct ScanParams {
   const float *queries;     // [nq][d]
   uint32_t n, nq;
   int sub, d, K;
+  int lut_mode;             // 0 PQ sub-space (c-q)^2 | 1 LSQ -2<q,c> full-dim | 2 CQ (q-c)^2 full-dim
+  const float *row_bias;    // LSQ: dbnorms[n], added after the table sum; else nullptr
   uint32_t id_offset;
   int id_base;
   uint32_t nslices, rows_per_slice, ngroups;
@@ -104,28 +106,45 @@ struct ScanParams {
 };
 
 // ------------------------------------------------------------------------------------------
-// LUT construction, one (k, r) entry at a time for all QG queries of the group.
-// deps/src/linscan_aqd.cpp:66-74; compiled with -ffp-contract=off so (c-q), square and add stay
-// three separately rounded f32 operations like the reference's x86-64 build.
+// LUT construction, one (k, r) entry at a time for all QG queries of the group; compiled with
+// -ffp-contract=off so every product, square and add stays a separately rounded f32 operation
+// like the reference's x86-64 builds.
+//   mode 0  deps/src/linscan_aqd.cpp:66-74                 T = sum_s (c[s] - q[k*sub+s])^2, s < sub
+//   mode 1  deps/src/linscan_aqd_pairwise_byte.cpp:42-49   T = T - (2*q[s])*c[s],            s < d
+//   mode 2  deps/src/linscan_aqd_pairwise_byte.cpp:126-133 T = T + (q[s]-c[s])^2,            s < d
 // ------------------------------------------------------------------------------------------
 template <int M>
 __device__ __forceinline__ void build_lut(float *lut, float4 *gtab, const float *qstage,
-                                          const float *centers, int sub, int d, int tid) {
+                                          const float *centers, int sub, int d, int mode, int tid) {
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD;
+  const int cdim = mode == 0 ? sub : d;
   for (int e = tid; e < M * 256; e += SCAN_THREADS) {
     const int k = e >> 8, r = e & 255;
-    const float *c = centers + (size_t)e * sub;
+    const float *c = centers + (size_t)e * cdim;
+    const int qoff = mode == 0 ? k * sub : 0;
     float acc[QG];
 #pragma unroll
     for (int q = 0; q < QG; ++q) acc[q] = 0.0f;
-    for (int s = 0; s < sub; ++s) {
-      const float cs = c[s];
+    if (mode == 1) {
+      for (int s = 0; s < cdim; ++s) {
+        const float cs = c[s];
 #pragma unroll
-      for (int q = 0; q < QG; ++q) {
-        const float diff = cs - qstage[q * d + k * sub + s];
-        const float sq = diff * diff;
-        acc[q] = acc[q] + sq;
+        for (int q = 0; q < QG; ++q) {
+          const float two_q = 2.0f * qstage[q * d + s];
+          const float prod = two_q * cs;
+          acc[q] = acc[q] - prod;
+        }
+      }
+    } else {
+      for (int s = 0; s < cdim; ++s) {
+        const float cs = c[s];
+#pragma unroll
+        for (int q = 0; q < QG; ++q) {
+          const float diff = cs - qstage[q * d + qoff + s];   // (q-c)^2 has the same bits
+          const float sq = diff * diff;
+          acc[q] = acc[q] + sq;
+        }
       }
     }
 #pragma unroll
@@ -211,7 +230,7 @@ __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, ui
 #define RQ_STAT_ADD(slot, t0) do { if (p.stats && threadIdx.x == 0) atomicAdd(&p.stats[slot], (unsigned long long)clock64() - (t0)); } while (0)
 #define RQ_STAT_INC(slot) do { if (p.stats && threadIdx.x == 0) atomicAdd(&p.stats[slot], 1ull); } while (0)
 
-template <int M>
+template <int M, bool BIAS>
 __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, RPT = Cfg::RPT, BLK = Cfg::BLK;
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
     }
     __syncthreads();
     unsigned long long t_ph = RQ_STAT_T();
-    build_lut<M>(lut, gtab, qstage, p.centers, p.sub, p.d, tid);
+    build_lut<M>(lut, gtab, qstage, p.centers, p.sub, p.d, p.lut_mode, tid);
     __syncthreads();
     // the L1 part of the table was written by other wavefronts (and the previous item's lines may
     // still sit in this CU's L1): drop them before the first gather
@@ -291,6 +310,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
         load_row<M>(w1, p.codes, row);
         float acc[QG];
         row_dists<M>(w1, 0, lut4, gtab, acc);
+        if (BIAS) {
+          const float bias = p.row_bias[row];
+#pragma unroll
+          for (int q = 0; q < QG; ++q) acc[q] = acc[q] + bias;
+        }
 #pragma unroll
         for (int q = 0; q < QG; ++q) cand_wg[((size_t)q * 2 + 1) * p.cap + i] = make_key(acc[q], row);
       }
@@ -363,6 +387,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
       for (int r = 0; r < RPT; ++r) {
         float acc[QG];
         row_dists<M>(w, r, lut4, gtab, acc);
+        if (BIAS) {   // deps/src/linscan_aqd_pairwise_byte.cpp:74  pairs[j].first += dbnorms[normidx]
+          const float bias = (row0 + r < r_end) ? p.row_bias[row0 + r] : 0.0f;
+#pragma unroll
+          for (int q = 0; q < QG; ++q) acc[q] = acc[q] + bias;
+        }
         // ---- survivors: rows whose distance beats the query's threshold ------------------------
         const bool valid = row0 + r < r_end;
         uint64_t mk[QG];
@@ -569,7 +598,7 @@ static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) 
   constexpr int CTRL_BYTES = (sizeof(ScanCtrl<Cfg::QG>) + 15) & ~15;
   size_t lds = CTRL_BYTES + (size_t)std::max<size_t>(Cfg::LUT_BYTES + (size_t)Cfg::QG * p.d * 4,
                                                      (size_t)p.scratch_keys * 8);
-  auto kern = adc_scan_kernel<M>;
+  auto kern = p.row_bias ? adc_scan_kernel<M, true> : adc_scan_kernel<M, false>;
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(SCAN_THREADS), lds, stream, p);
@@ -640,10 +669,11 @@ int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_
 int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes,
                 const float *centers, const float *queries, int64_t n, int64_t nq, int m, int d, int K,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
-                hipStream_t stream) {
+                hipStream_t stream, int lut_mode, const float *row_bias) {
   ScanParams p;
   p.codes = codes; p.centers = centers; p.queries = queries;
   p.n = (uint32_t)n; p.nq = (uint32_t)nq; p.sub = d / m; p.d = d; p.K = K;
+  p.lut_mode = lut_mode; p.row_bias = row_bias;
   p.id_offset = id_offset; p.id_base = id_base;
   p.nslices = pl.nslices; p.rows_per_slice = pl.rows_per_slice; p.ngroups = pl.ngroups;
   p.cap = pl.cap; p.trigger = pl.trigger; p.p2 = pl.p2; p.scratch_keys = pl.scratch_keys;

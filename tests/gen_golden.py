@@ -63,6 +63,24 @@ def scan_case(name, n, m, sub, nq, Ks, kind):
     print(name, codes.shape, Ks)
 
 
+def aq_case(name, n, m, d, nq, Ks, seed):
+    """LSQ / CQ scans: outputs of the REAL reference linscan_aqd_pairwise_byte.so."""
+    rng = np.random.default_rng(seed)
+    codebooks = (rng.standard_normal((m * 256, d)) * 3).astype(np.float32)
+    queries = (rng.standard_normal((nq, d)) * 3).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=seed)
+    codes[n // 2:n // 2 + 40] = codes[7]                     # duplicate rows -> exact distance ties
+    recon = sum(codebooks[k * 256 + codes[:, k].astype(np.int64)] for k in range(m))
+    dbnorms = (recon.astype(np.float64) ** 2).sum(1).astype(np.float32)
+    data = dict(codes=codes, codebooks=codebooks, queries=queries, dbnorms=dbnorms, Ks=np.asarray(Ks, np.int32))
+    for K in Ks:
+        dl, il = oracle.linscan_lsq(codes, codebooks, queries, dbnorms, K, use_ref=True)
+        dc, ic = oracle.linscan_cq(codes, codebooks, queries, K, use_ref=True)
+        data.update({"lsq_d%d" % K: dl, "lsq_i%d" % K: il, "cq_d%d" % K: dc, "cq_i%d" % K: ic})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **data)
+    print(name, codes.shape, Ks)
+
+
 def encode64(X, C, m):
     """float64 evaluation of the same formula (independent of the f32 order)."""
     n, d = X.shape
@@ -143,3 +161,6 @@ if __name__ == "__main__":
     encode_case("encode_uneven", 512, 10, 4, 64, "sift", with_R=False)   # splitarray -> 3,3,2,2
     encode_case("encode_h100", 512, 32, 4, 100, "deep", with_R=False)    # h not a multiple of 32
     recall_case()
+    assert oracle.ref_aq_available(), "make -C oracle ref"
+    aq_case("aq_mini_m8", 3000, 8, 32, 6, [1, 100, 1000], seed=41)
+    aq_case("aq_mini_m4", 1500, 4, 16, 5, [10, 1500], seed=42)

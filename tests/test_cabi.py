@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     src = open(os.path.join(ROOT, "include", "rayuela_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b(rq_[A-Za-z0-9_]+|linscan_aqd_query)\s*\(", src)
+    names = re.findall(r"\b(rq_[A-Za-z0-9_]+|linscan_aqd_[a-z_]*query[a-z_]*)\s*\(", src)
     return sorted(set(names))
 
 
