@@ -137,6 +137,21 @@ def test_shard_merge_equals_single_scan(rq, oracle):
     assert _eq_bits(dists.cpu().numpy(), d0)
 
 
+def test_sharded_index_single_rank_uses_hip_kernels(rq, oracle):
+    """ShardedIndex with its default (HIP) scan/merge functions, world size 1: keys out of the scan,
+    through rq_dev_merge_topk, equal the direct answer."""
+    import torch
+    from rayuela_jl_amd.sharded import ShardedIndex
+    g = golden("scan_sift_mini")
+    codes = torch.from_numpy(g["codes"]).cuda()
+    cen = torch.from_numpy(g["centers"]).cuda()
+    qs = torch.from_numpy(g["queries"]).cuda()
+    ix = ShardedIndex(codes, cen, id_offset=0)
+    d, i = ix.search(qs, 100, id_base=0)
+    assert np.array_equal(i.cpu().numpy().view(np.uint32), g["ids_K100"])
+    assert _eq_bits(d.cpu().numpy(), g["dists_K100"])
+
+
 def test_linscan_opq_vs_oracle(rq, oracle):
     g = golden("encode_sift_mini")
     import rayuela_jl_amd.synth as synth
