@@ -130,6 +130,22 @@ int rq_dev_merge_topk(float *dists, uint32_t *ids, uint64_t *keys_out, const uin
 /* code[i][j] = splitmix64(seed ^ ((row0+i)*m+j)) >> 56 : SIFT1B-shape synthetic shard. */
 int rq_dev_synth_codes(uint8_t *codes, int64_t n, int m, uint64_t seed, int64_t row0, void *stream);
 
+/* ---- the reductions of the PQ / OPQ training loops (device pointers) ----------
+ * The assignment step of train_pq / train_opq is rq_dev_encode_pq and R'X is rq_dev_rotate_T; these add:
+ *   update_centers  Clustering.update_centers! as called at src/OPQ.jl:121: C_i[k] <- mean of the
+ *                   sub-vectors with code k; counts [m][h] out; an EMPTY cluster keeps its old centre
+ *                   (the reference multiplies by 1/0 there)
+ *   reconstruct     CB[j][subdims_i] = C_i[:, b_ji]                        (src/OPQ.jl:101,128)
+ *   qerror          *acc = sum_j |X_j - CB_j|^2 in double (divide by n on the host; src/OPQ.jl:108)
+ *   gram            G[a][b] = sum_j X[j][a] * CB[j][b], the d x d input of the SVD at src/OPQ.jl:112
+ * Float summation orders differ from the reference's sequential loops: tolerance parity (tests/). */
+int rq_dev_update_centers(float *C, uint32_t *counts, const float *X, const uint8_t *codes, int64_t n,
+                          int d, int m, int h, void *stream);
+int rq_dev_reconstruct(float *CB, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h,
+                       void *stream);
+int rq_dev_qerror(double *acc, const float *X, const float *CB, int64_t n, int d, void *stream);
+int rq_dev_gram(float *G, const float *X, const float *CB, int64_t n, int d, void *stream);
+
 /* ---- device-resident index handle (codes uploaded once; used by the Julia shim's
  * optional fast path and by multi-GPU deployments, one handle per process/GPU) ------------- */
 typedef struct rq_index rq_index;

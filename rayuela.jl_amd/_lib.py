@@ -46,6 +46,10 @@ SIGNATURES = {
     "rq_dev_linscan": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _u32, _i32, _vp]),
     "rq_dev_merge_topk": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rq_dev_synth_codes": (_i32, [_vp, _i64, _i32, _u64, _i64, _vp]),
+    "rq_dev_update_centers": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "rq_dev_reconstruct": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "rq_dev_qerror": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "rq_dev_gram": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "rq_index_create": (_vp, [_i32, _i32, _vp]),
     "rq_index_set_codes": (_i32, [_vp, _vp, _i64, _u32]),
     "rq_index_search": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32]),

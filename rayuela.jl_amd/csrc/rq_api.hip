@@ -484,6 +484,29 @@ int rq_dev_synth_codes(uint8_t *codes, int64_t n, int m, uint64_t seed, int64_t 
   return synth_codes_launch(codes, n, m, seed, row0, (hipStream_t)stream);
 }
 
+int rq_dev_update_centers(float *C, uint32_t *counts, const float *X, const uint8_t *codes, int64_t n, int d, int m,
+                          int h, void *stream) {
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  return update_centers_launch(C, counts, X, codes, n, d, m, h, di.num_cu, (hipStream_t)stream);
+}
+
+int rq_dev_reconstruct(float *CB, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h, void *stream) {
+  return reconstruct_launch(CB, codes, C, n, d, m, h, (hipStream_t)stream);
+}
+
+int rq_dev_qerror(double *acc, const float *X, const float *CB, int64_t n, int d, void *stream) {
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  return qerror_launch(acc, X, CB, n, d, di.num_cu, (hipStream_t)stream);
+}
+
+int rq_dev_gram(float *G, const float *X, const float *CB, int64_t n, int d, void *stream) {
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  return gram_launch(G, X, CB, n, d, di.num_cu, (hipStream_t)stream);
+}
+
 rq_index *rq_index_create(int m, int d, const float *centers_host) {
   if (m < 1 || d < m || d % m) { fail(RQ_EINVAL, "index: d %% m != 0"); return nullptr; }
   rq_index *ix = new rq_index();

@@ -67,4 +67,13 @@ int rotate_launch(float *RX, const float *R, const float *X, int d, int64_t n, i
                   hipStream_t stream);
 int widen_codes_launch(int16_t *out1, const uint8_t *codes, int64_t nelem, hipStream_t stream);
 
+// ---- training reductions (rq_train.hip) --------------------------------------------------------
+int update_centers_launch(float *C, unsigned int *counts, const float *X, const uint8_t *codes, int64_t n, int d,
+                          int m, int h, int num_cu, hipStream_t stream);
+int reconstruct_launch(float *CB, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h,
+                       hipStream_t stream);
+int qerror_launch(double *acc_dev, const float *X, const float *CB, int64_t n, int d, int num_cu,
+                  hipStream_t stream);
+int gram_launch(float *G, const float *X, const float *CB, int64_t n, int d, int num_cu, hipStream_t stream);
+
 }  // namespace rq

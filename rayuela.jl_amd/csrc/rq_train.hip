@@ -1,0 +1,236 @@
+// rq_train.hip -- device pieces of the PQ / OPQ training loops.
+//
+// train_opq (src/OPQ.jl:49-139) iterates   obj -> SVD(X CB') -> R'X -> update_centers! ->
+// pairwise + update_assignments! -> CB;  train_pq (src/PQ.jl:68-99) is Lloyd's k-means per subspace.
+// The assignment step IS the encode kernel (rq_encode.hip) and R'X the rotation kernel; this file
+// adds the three reductions around them and the reconstruction:
+//   update_centers   C_i[k] = mean of the sub-vectors assigned to k     (Clustering.update_centers!,
+//                    call sites src/OPQ.jl:121)                          segment sum, LDS accumulators
+//   reconstruct      CB[j][off_i + s] = C_i[b_ji][s]                     (src/OPQ.jl:101,128)
+//   qerror           sum_j |RX_j - CB_j|^2                               (src/OPQ.jl:108, src/qerrors.jl:77-90;
+//                    same value as |R CB - X|^2 because R is orthonormal)
+//   gram             G = X' CB  (d x d, reduced over the n rows)         (src/OPQ.jl:112, input of the host SVD)
+//                    f32 MFMA, one 32x32 output tile pair per wavefront, split over row slices
+// Summation orders differ from the sequential CPU loops of the reference (which are themselves not
+// pinned by any reference test): parity for these is a float tolerance, stated in tests/.
+#include "rq_internal.h"
+
+namespace rq {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+
+struct TrainParams {
+  const float *X;        // [n][d]  (already rotated for OPQ)
+  const uint8_t *codes;  // [n][m]
+  float *C;              // concat of [h][sub_i]
+  float *partial;        // [grid][h*d] sums  then  [grid][m*h] counts (as float)
+  float *CB;             // [n][d]
+  double *acc;           // scalar accumulator
+  unsigned int *counts;  // [m][h] out
+  int64_t n;
+  int d, m, h;
+  int off[33];
+};
+
+// ---- update_centers, pass 1: per-workgroup partial sums in LDS --------------------------------------
+// LDS: sums [h][d] (column i of sub-quantizer q lives at [code][off_q + s]) + counts [m][h].
+__global__ __launch_bounds__(1024) void centers_partial_kernel(TrainParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *sums = reinterpret_cast<float *>(smem);              // h*d
+  float *cnts = sums + (size_t)p.h * p.d;                      // m*h
+  const int tid = threadIdx.x;
+  const int hd = p.h * p.d, mh = p.m * p.h;
+  for (int i = tid; i < hd + mh; i += 1024) sums[i] = 0.0f;
+  __syncthreads();
+  const int64_t rows_per = (p.n + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(p.n, r0 + rows_per);
+  // one wavefront-lane per dimension group: thread t handles dimension (t % d) of rows t/d, t/d + 1024/d ...
+  // (d <= 1024); every lane of a wavefront touches a different LDS word unless two rows share a code
+  const int dim = tid % p.d, rsub = tid / p.d, rstep = 1024 / p.d;
+  int q = 0;
+  while (q + 1 < p.m && dim >= p.off[q + 1]) ++q;
+  if (rsub < rstep) {
+    for (int64_t r = r0 + rsub; r < r1; r += rstep) {
+      const int code = p.codes[r * p.m + q];
+      atomicAdd(&sums[(size_t)code * p.d + dim], p.X[r * p.d + dim]);
+      if (dim == p.off[q]) atomicAdd(&cnts[q * p.h + code], 1.0f);
+    }
+  }
+  __syncthreads();
+  float *out = p.partial + (size_t)blockIdx.x * (hd + mh);
+  for (int i = tid; i < hd + mh; i += 1024) out[i] = sums[i];
+}
+
+// pass 2: fixed-order sum over the workgroup partials, mean, write C (empty clusters keep their value)
+__global__ void centers_finish_kernel(TrainParams p, int nparts) {
+  const int hd = p.h * p.d, mh = p.m * p.h;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hd) return;
+  const int code = i / p.d, dim = i % p.d;
+  int q = 0;
+  while (q + 1 < p.m && dim >= p.off[q + 1]) ++q;
+  float s = 0.0f, c = 0.0f;
+  for (int w = 0; w < nparts; ++w) {
+    const float *part = p.partial + (size_t)w * (hd + mh);
+    s += part[i];
+    c += part[hd + q * p.h + code];
+  }
+  const int sub = p.off[q + 1] - p.off[q];
+  if (c > 0.0f) p.C[(size_t)p.h * p.off[q] + (size_t)code * sub + (dim - p.off[q])] = s * (1.0f / c);
+  if (dim == p.off[q]) p.counts[q * p.h + code] = (unsigned int)c;
+}
+
+// ---- reconstruction ----------------------------------------------------------------------------------
+__global__ void reconstruct_kernel(TrainParams p) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.n * p.d) return;
+  const int64_t r = e / p.d;
+  const int dim = (int)(e - r * p.d);
+  int q = 0;
+  while (q + 1 < p.m && dim >= p.off[q + 1]) ++q;
+  const int sub = p.off[q + 1] - p.off[q];
+  const int code = p.codes[r * p.m + q];
+  p.CB[e] = p.C[(size_t)p.h * p.off[q] + (size_t)code * sub + (dim - p.off[q])];
+}
+
+// ---- quantisation error: sum (X - CB)^2 in double ----------------------------------------------------
+__global__ __launch_bounds__(256) void qerror_kernel(TrainParams p) {
+  __shared__ double red[256];
+  const int64_t total = p.n * p.d;
+  double s = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const double df = (double)p.X[e] - (double)p.CB[e];
+    s += df * df;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(p.acc, red[0]);
+}
+
+// ---- G = X' CB  (d x d), reduced over rows ---------------------------------------------------------------
+// Output tile (a, b) = 32 x 32 block G[32a.., 32b..].  A workgroup owns a row slice; its wavefronts split
+// the (d/32)^2 output tiles; per 2 rows one 32x32x2 MFMA per tile: A[i][k] = X[row0+k][32a+i],
+// B[k][j] = CB[row0+k][32b+j].  Partial tiles go to `partial`, a second kernel sums the slices.
+struct GramParams {
+  const float *X, *CB;
+  float *partial;   // [grid][d*d]
+  float *G;         // [d][d]
+  int64_t n;
+  int d, NT;
+};
+
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void gram_partial_kernel(GramParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  const int d = p.d, NT = p.NT, ntile = NT * NT;
+  const int64_t rows_per = ((p.n + gridDim.x - 1) / gridDim.x + 1) & ~(int64_t)1;  // even
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(p.n, r0 + rows_per);
+  float *out = p.partial + (size_t)blockIdx.x * d * d;
+  for (int t = wave; t < ntile; t += NWAVES) {
+    const int a = t / NT, b = t % NT;
+    const int ia = 32 * a + j, ib = 32 * b + j;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int64_t r = r0; r < r1; r += 2) {
+      const int64_t row = r + hi;
+      float av = 0.0f, bv = 0.0f;
+      if (row < r1) {
+        if (ia < d) av = p.X[row * d + ia];
+        if (ib < d) bv = p.CB[row * d + ib];
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi, jj = 32 * b + j;
+      if (i < d && jj < d) out[(size_t)i * d + jj] = acc[r];
+    }
+  }
+}
+
+__global__ void gram_finish_kernel(GramParams p, int nparts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.d * p.d) return;
+  float s = 0.0f;
+  for (int w = 0; w < nparts; ++w) s += p.partial[(size_t)w * p.d * p.d + i];
+  p.G[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+static void fill_offsets(int *off, int d, int m) {
+  const int per = d / m, extra = d % m;
+  int pos = 0;
+  for (int i = 0; i < m; ++i) { off[i] = pos; pos += per + (i < extra ? 1 : 0); }
+  off[m] = pos;
+}
+
+int update_centers_launch(float *C, unsigned int *counts, const float *X, const uint8_t *codes, int64_t n, int d,
+                          int m, int h, int num_cu, hipStream_t stream) {
+  if (n <= 0) return RQ_OK;
+  if (m < 1 || m > 32 || d < m || d > 1024 || h < 1 || h > 256)
+    return fail(RQ_EUNSUPPORTED, "update_centers covers m <= 32, d <= 1024, h <= 256 (got m=%d d=%d h=%d)", m, d, h);
+  const size_t lds = ((size_t)h * d + (size_t)m * h) * sizeof(float);
+  if (lds > 160 * 1024) return fail(RQ_EUNSUPPORTED, "update_centers: h*d*4 = %zu B exceeds the LDS", lds);
+  TrainParams p{};
+  p.X = X; p.codes = codes; p.C = C; p.counts = counts; p.n = n; p.d = d; p.m = m; p.h = h;
+  fill_offsets(p.off, d, m);
+  const int grid = (int)std::min<int64_t>(num_cu, (n + 1023) / 1024);
+  void *part = nullptr;
+  RQ_TRY(workspace(WS_TMP, (size_t)grid * ((size_t)h * d + (size_t)m * h) * sizeof(float), &part));
+  p.partial = (float *)part;
+  RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(centers_partial_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(centers_partial_kernel, dim3(grid), dim3(1024), lds, stream, p);
+  RQ_HIP(hipGetLastError());
+  hipLaunchKernelGGL(centers_finish_kernel, dim3((h * d + 255) / 256), dim3(256), 0, stream, p, grid);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+int reconstruct_launch(float *CB, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h,
+                       hipStream_t stream) {
+  if (n <= 0) return RQ_OK;
+  if (m < 1 || m > 32 || d < m) return fail(RQ_EINVAL, "reconstruct: m=%d d=%d", m, d);
+  TrainParams p{};
+  p.codes = codes; p.C = const_cast<float *>(C); p.CB = CB; p.n = n; p.d = d; p.m = m; p.h = h;
+  fill_offsets(p.off, d, m);
+  const int64_t total = n * d;
+  hipLaunchKernelGGL(reconstruct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+int qerror_launch(double *acc_dev, const float *X, const float *CB, int64_t n, int d, int num_cu,
+                  hipStream_t stream) {
+  RQ_HIP(hipMemsetAsync(acc_dev, 0, sizeof(double), stream));
+  if (n <= 0) return RQ_OK;
+  TrainParams p{};
+  p.X = X; p.CB = const_cast<float *>(CB); p.acc = acc_dev; p.n = n; p.d = d;
+  hipLaunchKernelGGL(qerror_kernel, dim3(num_cu * 8), dim3(256), 0, stream, p);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+int gram_launch(float *G, const float *X, const float *CB, int64_t n, int d, int num_cu, hipStream_t stream) {
+  if (d < 1 || d > 1024) return fail(RQ_EUNSUPPORTED, "gram: d=%d", d);
+  GramParams p;
+  p.X = X; p.CB = CB; p.G = G; p.n = n; p.d = d; p.NT = (d + 31) / 32;
+  constexpr int NW = 8;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(num_cu, (n + 255) / 256));
+  void *part = nullptr;
+  RQ_TRY(workspace(WS_TMP, (size_t)grid * d * d * sizeof(float), &part));
+  p.partial = (float *)part;
+  hipLaunchKernelGGL(gram_partial_kernel<NW>, dim3(grid), dim3(NW * 64), 0, stream, p);
+  RQ_HIP(hipGetLastError());
+  hipLaunchKernelGGL(gram_finish_kernel, dim3((d * d + 255) / 256), dim3(256), 0, stream, p, grid);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+}  // namespace rq

@@ -95,3 +95,40 @@ def synth_codes(n, m, seed, row0=0, device="cuda"):
     codes = torch.empty((n, m), dtype=torch.uint8, device=device)
     _lib.check(_lib.lib().rq_dev_synth_codes(codes.data_ptr(), n, m, seed, row0, _stream()))
     return codes
+
+
+# ---- training reductions --------------------------------------------------------------
+def update_centers(Ccat, X, codes, m, h):
+    """In place: every non-empty cluster's centre <- mean of its sub-vectors.  Returns counts [m][h]."""
+    n, d = X.shape
+    counts = torch.zeros((m, h), dtype=torch.int32, device=X.device)
+    _lib.check(_lib.lib().rq_dev_update_centers(_chk(Ccat, torch.float32, "C"), counts.data_ptr(),
+                                                _chk(X, torch.float32, "X"), _chk(codes, torch.uint8, "codes"),
+                                                n, d, m, h, _stream()))
+    return counts
+
+
+def reconstruct(codes, Ccat, d, h, out=None):
+    n, m = codes.shape
+    out = torch.empty((n, d), dtype=torch.float32, device=codes.device) if out is None else out
+    _lib.check(_lib.lib().rq_dev_reconstruct(_chk(out, torch.float32, "CB"), _chk(codes, torch.uint8, "codes"),
+                                             _chk(Ccat, torch.float32, "C"), n, d, m, h, _stream()))
+    return out
+
+
+def qerror(X, CB):
+    """mean_j |X_j - CB_j|^2 (python float)."""
+    n, d = X.shape
+    acc = torch.zeros((1,), dtype=torch.float64, device=X.device)
+    _lib.check(_lib.lib().rq_dev_qerror(acc.data_ptr(), _chk(X, torch.float32, "X"), _chk(CB, torch.float32, "CB"),
+                                        n, d, _stream()))
+    return float(acc.item()) / n
+
+
+def gram(X, CB):
+    """G = X' CB, [d][d] with G[a][b] = sum_j X[j][a] CB[j][b]."""
+    n, d = X.shape
+    G = torch.empty((d, d), dtype=torch.float32, device=X.device)
+    _lib.check(_lib.lib().rq_dev_gram(G.data_ptr(), _chk(X, torch.float32, "X"), _chk(CB, torch.float32, "CB"),
+                                      n, d, _stream()))
+    return G

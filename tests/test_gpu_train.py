@@ -1,0 +1,82 @@
+"""GPU tests of the training reductions and loops.  Floating-point reductions in a
+different order than the CPU loops: tolerance 1e-5 relative for the reductions, 1e-4 on the objective
+curve (stated here, per the north star's float bar); reconstruction is exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n=20000, d=64, m=8, h=64, seed=0):
+    import torch
+    import rayuela_jl_amd.synth as synth
+    X = synth.sift_like(n, d, seed=seed + 1)
+    C = synth.codebooks(X, m, h, seed=seed + 2, iters=1, sample=2000)
+    return X, C
+
+
+def test_reductions_match_float64(rq, oracle):
+    import torch
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import device as rqd
+    from oracle import train_oracle as to
+    X, C = _setup()
+    n, d = X.shape
+    m, h = 8, 64
+    off = to.offsets(d, m)
+    codes = oracle.encode_pq(X, synth.cat_codebooks(C), m, h)
+    Xd, cd = torch.from_numpy(X).cuda(), torch.from_numpy(codes).cuda()
+    Ccat = torch.from_numpy(synth.cat_codebooks(C)).cuda()
+    # reconstruct: exact
+    CB = rqd.reconstruct(cd, Ccat, d, h)
+    CB0 = to.reconstruct(C, codes, off, d)
+    assert np.array_equal(CB.cpu().numpy(), CB0)
+    # qerror
+    e0 = ((X.astype(np.float64) - CB0) ** 2).sum() / n
+    assert abs(rqd.qerror(Xd, CB) - e0) <= 1e-9 * e0
+    # gram
+    G0 = X.astype(np.float64).T @ CB0.astype(np.float64)
+    G = rqd.gram(Xd, CB).cpu().numpy()
+    assert np.allclose(G, G0, rtol=1e-5, atol=1e-5 * np.abs(G0).max())
+    # update_centers (+ counts, + an artificially empty cluster keeps its centre)
+    codes2 = codes.copy()
+    codes2[codes2[:, 0] == 5, 0] = 6
+    C2 = torch.from_numpy(synth.cat_codebooks(C)).cuda()
+    counts = rqd.update_centers(C2, Xd, torch.from_numpy(codes2).cuda(), m, h).cpu().numpy()
+    Cn = to.update_centers(C, X, codes2, off, h)
+    got = C2.cpu().numpy()
+    assert np.allclose(got, synth.cat_codebooks(Cn), rtol=1e-5, atol=1e-4)
+    assert counts[0, 5] == 0 and counts.sum() == n * m
+    assert np.array_equal(counts, np.stack([np.bincount(codes2[:, i], minlength=h) for i in range(m)]))
+
+
+def test_train_opq_follows_the_oracle_loop(rq, oracle):
+    import rayuela_jl_amd.synth as synth
+    from oracle import train_oracle as to
+    X, C0 = _setup(n=12000, d=32, m=4, h=32, seed=3)
+    R0 = synth.rotation(32, seed=5)
+    C0r = synth.codebooks(oracle.rotate_T(R0, X), 4, 32, seed=9, iters=0, sample=2000)
+    niter = 4
+    C, B, R, obj = rq.train_opq(X, 4, 32, niter, "natural", R0=R0, C0=C0r)
+    Co, codes_o, Ro, obj_o = to.train_opq(X, 4, 32, niter, R0, C0r)
+    assert obj.shape == (niter + 1,)
+    assert np.allclose(obj, obj_o, rtol=1e-4)
+    assert (np.diff(obj) <= 1e-5 * obj[:-1]).all()          # the alternating minimisation never goes up
+    assert np.abs(R @ R.T - np.eye(32)).max() < 1e-5         # R stays orthonormal
+    assert (B - 1 != codes_o).mean() < 5e-3                  # same assignments up to float near-ties
+
+
+def test_train_pq_reduces_the_error(rq, oracle):
+    import rayuela_jl_amd.synth as synth
+    X, _ = _setup(n=30000, d=64, m=8, h=64, seed=7)
+    C1, B1, e1 = rq.train_pq(X, 8, 64, niter=1, seed=1)
+    C, B, e = rq.train_pq(X, 8, 64, niter=12, seed=1)
+    assert e < e1
+    assert B.dtype == np.int16 and B.min() >= 1 and B.max() <= 64
+    # the returned codes are the quantisation of X by the returned codebooks (quantize_pq contract)
+    assert np.array_equal(B, rq.quantize_pq(X, C))
+    # and the reported error is qerror_pq of exactly that pair
+    from oracle import train_oracle as to
+    CB = to.reconstruct(C, (B - 1).astype(np.uint8), to.offsets(64, 8), 64)
+    e0 = ((X.astype(np.float64) - CB) ** 2).sum() / X.shape[0]
+    assert abs(e - e0) <= 1e-6 * e0

@@ -67,3 +67,20 @@ if "rotate" in a.what:
     out = torch.empty_like(X)
     ms = bench(lambda: rqd.rotate_T(R, X, out=out), a.iters)
     print("rotate n=%d d=%d %8.3f ms  %6.1f TF  %7.1f GB/s" % (n, d, ms, 2.0 * d * d * n / ms / 1e9, 8.0 * d * n / ms / 1e6))
+
+if "train" in a.what:
+    import time
+    import numpy as np
+    X = torch.randint(0, 200, (n, d), generator=g, device=dev).float()
+    C = torch.randint(0, 200, (256 * d,), generator=g, device=dev).float()
+    R = torch.from_numpy(np.linalg.qr(np.random.default_rng(0).standard_normal((d, d)))[0].astype(np.float32)).to(dev)
+    codes = rqd.encode_pq(X, C, m, 256)
+    CB = rqd.reconstruct(codes, C, d, 256)
+    for name, fn in (("update_centers", lambda: rqd.update_centers(C, X, codes, m, 256)),
+                     ("reconstruct", lambda: rqd.reconstruct(codes, C, d, 256, out=CB)),
+                     ("qerror", lambda: rqd.qerror(X, CB)),
+                     ("gram X'CB", lambda: rqd.gram(X, CB))):
+        print("train  %-15s n=%d d=%d  %8.3f ms" % (name, n, d, bench(fn, a.iters)))
+    t0 = time.perf_counter()
+    U, S, Vt = np.linalg.svd(rqd.gram(X, CB).cpu().numpy().astype(np.float64))
+    print("train  host SVD %dx%d      %8.3f ms" % (d, d, (time.perf_counter() - t0) * 1e3))
