@@ -137,12 +137,28 @@ __global__ __launch_bounds__(NWAVES * 64) void gram_partial_kernel(GramParams p)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    for (int64_t r = r0; r < r1; r += 2) {
+    // 16 row pairs per trip: the 32 loads are issued together, then the 16 chained MFMAs
+    const bool ina = ia < d, inb = ib < d;
+    const float *xa = p.X + (ina ? ia : 0), *cb = p.CB + (inb ? ib : 0);
+    int64_t r = r0;
+    for (; r + 32 <= r1; r += 32) {
+      float av[16], bv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int64_t row = r + 2 * u + hi;
+        av[u] = xa[row * d];
+        bv[u] = cb[row * d];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ina ? av[u] : 0.0f, inb ? bv[u] : 0.0f, acc, 0, 0, 0);
+    }
+    for (; r < r1; r += 2) {
       const int64_t row = r + hi;
       float av = 0.0f, bv = 0.0f;
       if (row < r1) {
-        if (ia < d) av = p.X[row * d + ia];
-        if (ib < d) bv = p.CB[row * d + ib];
+        if (ina) av = xa[row * d];
+        if (inb) bv = cb[row * d];
       }
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
@@ -221,7 +237,7 @@ int gram_launch(float *G, const float *X, const float *CB, int64_t n, int d, int
   if (d < 1 || d > 1024) return fail(RQ_EUNSUPPORTED, "gram: d=%d", d);
   GramParams p;
   p.X = X; p.CB = CB; p.G = G; p.n = n; p.d = d; p.NT = (d + 31) / 32;
-  constexpr int NW = 8;
+  constexpr int NW = 16;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(num_cu, (n + 255) / 256));
   void *part = nullptr;
   RQ_TRY(workspace(WS_TMP, (size_t)grid * d * d * sizeof(float), &part));
