@@ -62,38 +62,46 @@ __device__ __forceinline__ f32x16 tile_dots(const float *cb_tile, const float (&
 // keep the running best value and, for the lanes that improved (strict '<': the earliest tile wins
 // ties), a copy of the tile's 16 u values (one shared mask, 16 v_cndmask).  The first-index search
 // runs ONCE per sub-quantizer on that copy (argmin_finish) instead of once per tile.
+using f32x2 = float __attribute__((ext_vector_type(2)));
+
 struct ArgminState {
   float best_v;   // clamped minimum so far
   int best_t;     // tile that holds it
-  float ub[16];   // that tile's u values
+  f32x2 ub[8];    // that tile's 16 u values (register pairs, as the packed ops leave them)
 };
 
 __device__ __forceinline__ void tile_argmin(const f32x16 &acc, const float4 *sa4, float sb, int t,
                                             ArgminState &st) {
-  float u[16];
+  // packed f32 arithmetic (v_pk_add_f32 / v_pk_fma_f32): two elements per VALU issue
+  f32x2 u[8];
   sa4 = reinterpret_cast<const float4 *>(__builtin_assume_aligned(sa4, 16));
+  const f32x2 sb2 = {sb, sb};
+  const f32x2 m2 = {-2.0f, -2.0f};
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) {
     const float4 sav = sa4[g4];
-    u[g4 * 4 + 0] = __builtin_fmaf(-2.0f, acc[g4 * 4 + 0], sav.x + sb);
-    u[g4 * 4 + 1] = __builtin_fmaf(-2.0f, acc[g4 * 4 + 1], sav.y + sb);
-    u[g4 * 4 + 2] = __builtin_fmaf(-2.0f, acc[g4 * 4 + 2], sav.z + sb);
-    u[g4 * 4 + 3] = __builtin_fmaf(-2.0f, acc[g4 * 4 + 3], sav.w + sb);
+    const f32x2 s01 = {sav.x, sav.y}, s23 = {sav.z, sav.w};
+    const f32x2 g01 = {acc[g4 * 4 + 0], acc[g4 * 4 + 1]}, g23 = {acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
+    u[g4 * 2 + 0] = __builtin_elementwise_fma(m2, g01, s01 + sb2);
+    u[g4 * 2 + 1] = __builtin_elementwise_fma(m2, g23, s23 + sb2);
   }
-  float m01 = __builtin_fminf(__builtin_fminf(u[0], u[1]), u[2]);
-  float m02 = __builtin_fminf(__builtin_fminf(u[3], u[4]), u[5]);
-  float m03 = __builtin_fminf(__builtin_fminf(u[6], u[7]), u[8]);
-  float m04 = __builtin_fminf(__builtin_fminf(u[9], u[10]), u[11]);
-  float m05 = __builtin_fminf(__builtin_fminf(u[12], u[13]), u[14]);
+  float m01 = __builtin_fminf(__builtin_fminf(u[0].x, u[0].y), u[1].x);
+  float m02 = __builtin_fminf(__builtin_fminf(u[1].y, u[2].x), u[2].y);
+  float m03 = __builtin_fminf(__builtin_fminf(u[3].x, u[3].y), u[4].x);
+  float m04 = __builtin_fminf(__builtin_fminf(u[4].y, u[5].x), u[5].y);
+  float m05 = __builtin_fminf(__builtin_fminf(u[6].x, u[6].y), u[7].x);
   float mm = __builtin_fminf(__builtin_fminf(m01, m02), m03);
   mm = __builtin_fminf(__builtin_fminf(mm, m04), m05);
-  mm = __builtin_fminf(mm, u[15]);
+  mm = __builtin_fminf(mm, u[7].y);
   const float cm = __builtin_fmaxf(mm, 0.0f);
-  const bool better = cm < st.best_v;
-  st.best_v = better ? cm : st.best_v;
-  st.best_t = better ? t : st.best_t;
+  // a real (exec-masked) branch: f32 MFMA and VALU do not overlap on this chip, so there is nothing to
+  // interleave the copy with, and under the mask it is 8 64-bit moves instead of 16 selects
+  if (cm < st.best_v) {
+    st.best_v = cm;
+    st.best_t = t;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) st.ub[r] = better ? u[r] : st.ub[r];
+    for (int r = 0; r < 8; ++r) st.ub[r] = u[r];
+  }
 }
 
 // First index of the clamped minimum inside the winning tile: the first r with u_r <= cm (for
@@ -101,7 +109,7 @@ __device__ __forceinline__ void tile_argmin(const f32x16 &acc, const float4 *sa4
 __device__ __forceinline__ int argmin_finish(const ArgminState &st, int hi) {
   int rf = 15;
 #pragma unroll
-  for (int r = 14; r >= 0; --r) rf = (st.ub[r] <= st.best_v) ? r : rf;
+  for (int r = 14; r >= 0; --r) rf = (((r & 1) ? st.ub[r >> 1].y : st.ub[r >> 1].x) <= st.best_v) ? r : rf;
   return st.best_t * 32 + 4 * hi + 8 * (rf >> 2) + (rf & 3);
 }
 
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_kernel(EncParams p) {
       st.best_v = __uint_as_float(0x7f800000u);
       st.best_t = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st.ub[r] = 0.0f;
+      for (int r = 0; r < 8; ++r) st.ub[r] = f32x2{0.0f, 0.0f};
       const float *cb_i = cbA + (size_t)il * NT * KS * 64 + lane;
       const float4 *sa_i = reinterpret_cast<const float4 *>(saL + ((size_t)il * NT * 2 + hi) * 16);
       // two named accumulators: tile t+1's MFMA chain is in flight while tile t is reduced
