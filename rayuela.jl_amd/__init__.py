@@ -7,6 +7,7 @@ ABI with `ccall` live in julia/.  No CPU fallback exists: without the HIP librar
 """
 from ._lib import RayuelaHipError, lib, lib_path, set_tuning, last_timing  # noqa: F401
 from .utils import splitarray, cat_codebooks  # noqa: F401
+from .xvecs import fvecs_read, ivecs_read, bvecs_read, fvecs_write, ivecs_write  # noqa: F401
 from .PQ import quantize_pq, quantize_pq_u8  # noqa: F401
 from .OPQ import quantize_opq, rotate  # noqa: F401
 

@@ -80,3 +80,25 @@ def test_train_pq_reduces_the_error(rq, oracle):
     CB = to.reconstruct(C, (B - 1).astype(np.uint8), to.offsets(64, 8), 64)
     e0 = ((X.astype(np.float64) - CB) ** 2).sum() / X.shape[0]
     assert abs(e - e0) <= 1e-6 * e0
+
+
+def test_experiment_opq_end_to_end(rq, oracle):
+    """experiment_opq (src/OPQ.jl:142-171) on synthetic data: train -> quantize_opq -> linscan_opq ->
+    eval_recall, all through the C ABI; the search leg must equal the oracle given the trained model."""
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd.experiments import experiment_opq
+    d, m, h, knn = 32, 4, 256, 50
+    Xb = synth.deep_like(20000, d, seed=1)
+    Xt = Xb[:8000]
+    Xq = synth.deep_like(64, d, seed=2)
+    dd = ((Xq.astype(np.float64)[:, None, :] - Xb.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+    gt = (dd.argmin(1) + 1).astype(np.uint32)                       # one-based like the ivecs ground truth
+    C, B, R, obj, B_base, recall = experiment_opq(Xt, Xb, Xq, gt, m, h, "natural", niter=5, knn=knn)
+    assert recall.shape == (knn,) and (np.diff(recall) >= 0).all() and recall[-1] > 0.5
+    assert (np.diff(obj) <= 1e-5 * obj[:-1]).all()
+    # search parity for the trained model: oracle encode + oracle scan on the rotated data
+    codes0 = oracle.encode_opq(Xb, R, synth.cat_codebooks(C), m, h)
+    assert np.array_equal(B_base, codes0.astype(np.int16) + 1)
+    d0, i0 = oracle.linscan_aqd_query(codes0, np.stack(C), oracle.rotate_T(R, Xq), knn)
+    rec0 = oracle.eval_recall(gt, i0 + 1, knn)
+    assert np.allclose(recall, rec0)
