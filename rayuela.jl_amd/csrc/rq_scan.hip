@@ -28,7 +28,11 @@
 
 namespace rq {
 
-constexpr int SCAN_THREADS = 1024;
+#ifndef RQ_SCAN_THREADS
+#define RQ_SCAN_THREADS 512
+#endif
+constexpr int SCAN_THREADS = RQ_SCAN_THREADS;       // 1024: one workgroup per CU; 512: two
+constexpr int SCAN_WGS_PER_CU = 1024 / SCAN_THREADS;
 
 // v_writelane_b32 (no clang builtin in ROCm 7.2): lane `L` of `old` <- wave-uniform `val`
 template <class T>
@@ -48,7 +52,7 @@ struct ScanCfg {
 #endif
   static constexpr int U = (M <= 8) ? RQ_SCAN_U8 : 2;  // sub-steps per block: loads of a block fly together
   static constexpr int BLK = SUB * U;               // rows per workgroup block (barrier / tau refresh period)
-  static constexpr int LUT_BYTES = M * QG * 1024;
+  static constexpr int LUT_BYTES = M * QG * 1024;   // full table; the LDS part is LUT_LDS_BYTES below
   // The LDS gather pipe is the kernel's bound (~11-12 cycles per 64-lane ds_read_b128 with random
   // slots).  The vector-memory path can gather the same 16 bytes from an L1-resident table in ~29
   // cycles per wavefront (tools/micro/gather_l1.hip) and runs beside the LDS, so the LAST KG
@@ -63,6 +67,7 @@ struct ScanCfg {
 #endif
   static constexpr int KL = M - KG;                 // sub-quantizers [0, KL) gather from LDS
   static constexpr int GTAB_F4 = KG * NQUAD * 256;  // float4 entries of the global (L1) table
+  static constexpr int LUT_LDS_BYTES = KL * QG * 1024;
   static constexpr int ROW_WORDS = (M + 3) / 4;
   static_assert(RPT >= 1, "M too large for this tiling");
 };
@@ -231,7 +236,7 @@ __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, ui
 #define RQ_STAT_INC(slot) do { if (p.stats && threadIdx.x == 0) atomicAdd(&p.stats[slot], 1ull); } while (0)
 
 template <int M, bool BIAS>
-__global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
+__global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p) {
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, RPT = Cfg::RPT, BLK = Cfg::BLK;
   constexpr int TPG = SCAN_THREADS / QG;
@@ -239,7 +244,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   ScanCtrl<QG> *ctrl = reinterpret_cast<ScanCtrl<QG> *>(smem);
   float *lut = reinterpret_cast<float *>(smem + CTRL_BYTES);
-  float *qstage = lut + Cfg::LUT_BYTES / 4;
+  float *qstage = lut + Cfg::LUT_LDS_BYTES / 4;
+  uint32_t *samp = reinterpret_cast<uint32_t *>(qstage + QG * p.d);   // [QG][SCAN_THREADS] sample minima
   uint64_t *scratch = reinterpret_cast<uint64_t *>(smem + CTRL_BYTES);  // aliases lut (dead by then)
 
   const int tid = threadIdx.x;
@@ -285,9 +291,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
     const uint32_t S = p.sample;
     uint32_t srank = 0;
     bool sampled = false;
-    if (S > 0 && p.K >= 256 && rows >= 8u * S && (uint64_t)rows >= 16ull * (uint64_t)p.K) {
+    if (S > 0 && p.K >= 8 && rows >= 8u * S && (uint64_t)rows >= 16ull * (uint64_t)p.K) {
       srank = (uint32_t)(((uint64_t)p.srank_mul * (uint64_t)p.K * S + rows - 1) / rows) + 8u;
-      sampled = srank * 4u <= S;
+      sampled = srank * 2u <= (uint32_t)SCAN_THREADS;
     }
 #pragma unroll 1
     for (int attempt = sampled ? 0 : 1; attempt < 2; ++attempt) {
@@ -302,7 +308,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
     if (attempt == 1 && sampled) RQ_STAT_INC(7);
     t_ph = RQ_STAT_T();
     if (attempt == 0) {
+      // every thread keeps the minimum of its S/SCAN_THREADS sample rows per query; the `srank`-th
+      // smallest of those minima (an upper bound of the srank-th smallest sample distance, and equal
+      // to it unless two of the srank best rows fell to one thread) is selected in LDS
       const uint32_t step = rows / S;
+      float smin[QG];
+#pragma unroll
+      for (int q = 0; q < QG; ++q) smin[q] = __uint_as_float(0x7f800000u);
 #pragma unroll 1
       for (uint32_t i = tid; i < S; i += SCAN_THREADS) {
         const uint32_t row = r_begin + i * step + ((i * 2654435761u) >> 8) % step;
@@ -316,12 +328,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void adc_scan_kernel(ScanParams p) {
           for (int q = 0; q < QG; ++q) acc[q] = acc[q] + bias;
         }
 #pragma unroll
-        for (int q = 0; q < QG; ++q) cand_wg[((size_t)q * 2 + 1) * p.cap + i] = make_key(acc[q], row);
+        for (int q = 0; q < QG; ++q) smin[q] = fminf(smin[q], acc[q]);
       }
+#pragma unroll
+      for (int q = 0; q < QG; ++q) samp[q * SCAN_THREADS + tid] = f2ord(smin[q] + 0.0f);
       __syncthreads();
       RQ_STAT_ADD(8, t_ph);
-      radix_select<QG, TPG, 4>(&ctrl->st, cand_wg + ((size_t)g * 2 + 1) * p.cap, S, srank, true, g, gi);
-      if (gi == 0) ctrl->tau[g] = key_dist(ctrl->st.prefix[g]);
+      const uint32_t tk = radix_select_lds<QG, TPG, uint32_t>(&ctrl->st, samp + g * SCAN_THREADS, SCAN_THREADS,
+                                                                srank, true, g, gi);
+      if (gi == 0) ctrl->tau[g] = ord2f(tk);
       __syncthreads();
       RQ_STAT_ADD(1, t_ph);
     }
@@ -596,7 +611,7 @@ template <int M>
 static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) {
   using Cfg = ScanCfg<M>;
   constexpr int CTRL_BYTES = (sizeof(ScanCtrl<Cfg::QG>) + 15) & ~15;
-  size_t lds = CTRL_BYTES + (size_t)std::max<size_t>(Cfg::LUT_BYTES + (size_t)Cfg::QG * p.d * 4,
+  size_t lds = CTRL_BYTES + (size_t)std::max<size_t>(Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * (p.d + SCAN_THREADS) * 4,
                                                      (size_t)p.scratch_keys * 8);
   auto kern = p.row_bias ? adc_scan_kernel<M, true> : adc_scan_kernel<M, false>;
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -633,23 +648,26 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   const uint32_t slack = (uint32_t)slack_i;
   pl.trigger = (uint32_t)K + slack;
   pl.sample = (uint32_t)tuning("SCAN_SAMPLE", 8192);
-  pl.cap = std::max<uint32_t>(pl.trigger + Cfg::BLK, pl.sample);
+  pl.cap = pl.trigger + Cfg::BLK;
   pl.p2 = next_pow2((uint32_t)K);
   // LDS scratch for the final sort: at least one query, at most QG, within 160 KiB total
   const size_t lds_max = 160 * 1024 - CTRL_BYTES;
   size_t want_keys = (size_t)pl.p2 * Cfg::QG;
-  size_t base_keys = ((size_t)Cfg::LUT_BYTES + (size_t)Cfg::QG * d * 4) / 8;
+  size_t base_keys = ((size_t)Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * (d + SCAN_THREADS) * 4) / 8;
   size_t keys = std::max(base_keys, std::min(want_keys, (size_t)64 * 1024 / 8 * 2));
   keys = std::max(keys, (size_t)pl.p2);
   keys = std::min(keys, lds_max / 8);
   pl.scratch_keys = (uint32_t)keys;
   const uint64_t items = (uint64_t)pl.ngroups * pl.nslices;
-  pl.grid = (uint32_t)std::min<uint64_t>(items, (uint64_t)num_cu);
+  // workgroups per CU: as many as the LDS request admits (2 x 512 threads when it is <= 80 KiB)
+  const size_t lds_req = CTRL_BYTES + std::max<size_t>(base_keys * 8, (size_t)pl.scratch_keys * 8);
+  const int wgs = std::max(1, std::min<int>(SCAN_WGS_PER_CU, (int)(160 * 1024 / lds_req)));
+  pl.grid = (uint32_t)std::min<uint64_t>(items, (uint64_t)num_cu * wgs);
   pl.cand_bytes = (size_t)pl.grid * Cfg::QG * 2 * pl.cap * sizeof(uint64_t);
   pl.gtab_off = pl.cand_bytes;   // the L1-gathered LUT parts live behind the candidate buffers
   pl.cand_bytes += (size_t)pl.grid * (Cfg::GTAB_F4 > 0 ? Cfg::GTAB_F4 : 1) * sizeof(float4);
   pl.lds_ok = ((size_t)pl.p2 * 8 <= lds_max) &&
-              ((size_t)Cfg::LUT_BYTES + (size_t)Cfg::QG * d * 4 <= lds_max);
+              ((size_t)Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * (d + SCAN_THREADS) * 4 <= lds_max);
 }
 
 int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_cu, int force_slices) {

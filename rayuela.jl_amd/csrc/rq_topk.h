@@ -127,6 +127,51 @@ __device__ __forceinline__ void radix_select(SelState<G> *st, const uint64_t *__
   }
 }
 
+// k-th smallest of keys[0..cnt) held in LDS (KeyT = uint32_t: NPASS 4, uint64_t: NPASS 8); same
+// lock-step protocol as radix_select, but every pass is a handful of LDS reads per thread.
+template <int G, int TPG, class KeyT>
+__device__ __forceinline__ KeyT radix_select_lds(SelState<G> *st, const KeyT *keys, uint32_t cnt, uint32_t k,
+                                                 bool active, int g, int gi) {
+  constexpr int NPASS = (int)sizeof(KeyT);
+  if (gi == 0 && active) {
+    st->prefix[g] = 0;
+    st->krem[g] = k;
+  }
+#pragma unroll 1
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int shift = 8 * (NPASS - 1 - pass);
+    for (int b = gi; b < 256; b += TPG) st->hist[g][b] = 0;
+    __syncthreads();
+    if (active) {
+      const KeyT pfx = (KeyT)st->prefix[g];
+      for (uint32_t idx = gi; idx < cnt; idx += TPG) {
+        const KeyT key = keys[idx];
+        const bool match = (pass == 0) || ((uint64_t)(key >> shift) >> 8) == ((uint64_t)(pfx >> shift) >> 8);
+        hist_add(&st->hist[g][0], (uint32_t)(key >> shift) & 255u, match);
+      }
+    }
+    __syncthreads();
+    if (active && gi < 64) {
+      const uint32_t c0 = st->hist[g][gi * 4 + 0], c1 = st->hist[g][gi * 4 + 1];
+      const uint32_t c2 = st->hist[g][gi * 4 + 2], c3 = st->hist[g][gi * 4 + 3];
+      const uint32_t s = c0 + c1 + c2 + c3;
+      const uint32_t incl = wave_incl_scan(s, gi);
+      const uint32_t excl = incl - s;
+      const uint32_t kk = st->krem[g];
+      if (excl < kk && kk <= incl) {
+        uint32_t r = kk - excl, b = 0;
+        if (r > c0) { r -= c0; b = 1;
+          if (r > c1) { r -= c1; b = 2;
+            if (r > c2) { r -= c2; b = 3; } } }
+        st->prefix[g] |= (uint64_t)(gi * 4 + b) << shift;
+        st->krem[g] = r;
+      }
+    }
+    __syncthreads();
+  }
+  return (KeyT)st->prefix[g];
+}
+
 // dst[0..) <- every key of src[0..cnt) that is <= tau (order not preserved); st->newcnt[g] = count.
 template <int G, int TPG>
 __device__ __forceinline__ void compact_leq(SelState<G> *st, const uint64_t *__restrict__ src,
