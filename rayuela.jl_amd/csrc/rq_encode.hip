@@ -275,6 +275,118 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_kernel(EncParams p) {
   }
 }
 
+// Fast path: every sub-quantizer spans exactly sub = 2*KS dimensions (d % m == 0, sub even).  The
+// 32 x sub slice of X never touches LDS: both half-lanes of vector j load its whole sub-vector straight
+// into registers (sub*4 contiguous bytes; the two lanes of a pair hit the same addresses, which the
+// memory pipe merges), take their B fragments by a per-lane select (even / odd dimension of each
+// k-step) and run the |x|^2 chain locally.  LDS then holds only the codebooks and their norms, no
+// intra-wave LDS hand-off (no s_waitcnt lgkmcnt drains) sits between two sub-quantizers, and the next
+// sub-vector is in flight during the MFMAs.
+template <int KS, int NT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void encode_pq_direct_kernel(EncParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int SUB = 2 * KS;
+  const int m = p.m, h = p.h, d = p.d;
+  const int i0 = p.i0, mg = p.i1 - p.i0;
+  float *cbA = reinterpret_cast<float *>(smem);                 // mg*NT*KS*64
+  float *saL = cbA + (size_t)mg * NT * KS * 64;                 // mg*NT*32
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  for (int idx = tid; idx < mg * NT * KS * 64; idx += NWAVES * 64) {
+    const int l = idx & 63;
+    int rest = idx >> 6;
+    const int kk = rest % KS; rest /= KS;
+    const int t = rest % NT;
+    const int i = i0 + rest / NT;
+    const int cen = t * 32 + (l & 31);
+    const int sx = 2 * kk + (l >> 5);
+    cbA[idx] = cen < h ? p.C[(size_t)h * SUB * i + (size_t)cen * SUB + sx] : 0.0f;
+  }
+  for (int idx = tid; idx < mg * NT * 32; idx += NWAVES * 64) {
+    const int c32 = idx & 31;
+    const int t = (idx >> 5) % NT;
+    const int il = (idx >> 5) / NT;
+    const int cen = t * 32 + c32;
+    float sa = __uint_as_float(0x7f800000u);
+    if (cen < h) {
+      const float *c = p.C + (size_t)h * SUB * (i0 + il) + (size_t)cen * SUB;
+      sa = 0.0f;
+#pragma unroll
+      for (int sx = 0; sx < SUB; ++sx) sa = __builtin_fmaf(c[sx], c[sx], sa);
+    }
+    const int hh = (c32 >> 2) & 1;
+    const int r = (c32 & 3) + 4 * (c32 >> 3);
+    saL[((size_t)(il * NT + t) * 2 + hh) * 16 + r] = sa;
+  }
+  __syncthreads();
+
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t total_waves = (int64_t)gridDim.x * NWAVES;
+  const int64_t tile0 = (int64_t)blockIdx.x * NWAVES + wave;
+  f32x2 xn[KS];   // the sub-vector in flight (next (tile, sub-quantizer))
+  auto gload = [&](int64_t tile, int il) {
+    int64_t gr = tile * 32 + j;
+    if (gr >= p.n) gr = p.n - 1;
+    const f32x2 *src = reinterpret_cast<const f32x2 *>(p.X + gr * d + (size_t)(i0 + il) * SUB);
+#pragma unroll
+    for (int u = 0; u < KS; ++u) xn[u] = src[u];
+  };
+  if (tile0 < ntiles) gload(tile0, 0);
+
+  for (int64_t tile = tile0; tile < ntiles; tile += total_waves) {
+    const int64_t row0 = tile * 32;
+    uint64_t cw[4] = {0, 0, 0, 0};
+#pragma unroll 1
+    for (int il = 0; il < mg; ++il) {
+      const int i = i0 + il;
+      float b[KS];
+      float sb = 0.0f;
+#pragma unroll
+      for (int u = 0; u < KS; ++u) {
+        const f32x2 v = xn[u];
+        b[u] = hi ? v.y : v.x;                 // k-step u: lanes 0-31 the even, 32-63 the odd dimension
+        sb = __builtin_fmaf(v.x, v.x, sb);     // chain s = 0..sub-1 in order
+        sb = __builtin_fmaf(v.y, v.y, sb);
+      }
+      if (il + 1 < mg) gload(tile, il + 1);
+      else if (tile + total_waves < ntiles) gload(tile + total_waves, 0);
+      ArgminState st;
+      st.best_v = __uint_as_float(0x7f800000u);
+      st.best_t = 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) st.ub[r] = f32x2{0.0f, 0.0f};
+      const float *cb_i = cbA + (size_t)il * NT * KS * 64 + lane;
+      const float4 *sa_i = reinterpret_cast<const float4 *>(saL + ((size_t)il * NT * 2 + hi) * 16);
+      f32x16 accA = tile_dots<KS>(cb_i, b), accB;
+#pragma unroll
+      for (int t = 0; t < NT; t += 2) {
+        if (t + 1 < NT) accB = tile_dots<KS>(cb_i + (size_t)(t + 1) * KS * 64, b);
+        tile_argmin(accA, sa_i + (size_t)t * 8, sb, t, st);
+        if (t + 2 < NT) accA = tile_dots<KS>(cb_i + (size_t)(t + 2) * KS * 64, b);
+        if (t + 1 < NT) tile_argmin(accB, sa_i + (size_t)(t + 1) * 8, sb, t + 1, st);
+      }
+      float best_v = st.best_v;
+      int best_i = argmin_finish(st, hi);
+      const float ov = __shfl_xor(best_v, 32);
+      const int oi = __shfl_xor(best_i, 32);
+      if (ov < best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if ((i >> 3) == w) cw[w] |= (uint64_t)(uint32_t)best_i << (8 * (i & 7));
+    }
+    if (hi == 0 && row0 + j < p.n) {
+      uint8_t *o = p.codes + (size_t)(row0 + j) * m;
+      if ((m & 7) == 0 && mg == m) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          if (w * 8 < m) reinterpret_cast<uint64_t *>(o)[w] = cw[w];
+      } else {
+        for (int i = i0; i < p.i1; ++i) o[i] = (uint8_t)(cw[i >> 3] >> (8 * (i & 7)));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Rotation  RX[j][i] = sum_k Rc[i][k] X[j][k]   (src/OPQ.jl:26, src/Linscan.jl:102)
 // R sits in LDS in A-fragment order; each wave stages a 32-vector tile of X transposed in LDS
@@ -447,19 +559,24 @@ __global__ void widen_codes_kernel(int16_t *out1, const uint8_t *codes, size_t n
 }
 
 // ------------------------------------------------------------------------------------------
-template <int KS, int NT, int NWAVES>
+template <int KS, int NT, int NWAVES, bool DIRECT>
 static int launch_encode(EncParams p, int num_cu, hipStream_t stream) {
   p.NT = NT;  // centroids are padded to NT*32 (+inf norms, zero rows)
   // All m sub-codebooks in LDS when they fit (SIFT: 128 KiB, Deep: 96 KiB); otherwise the
   // sub-quantizers are encoded in groups, one launch per group (X is re-read per group).
   const size_t per_sub = ((size_t)p.NT * KS * 64 + (size_t)p.NT * 32) * sizeof(float);
-  const size_t fixed = (size_t)NWAVES * 2 * KS * XS_STRIDE * sizeof(float);
+  const size_t fixed_staged = (size_t)NWAVES * 2 * KS * XS_STRIDE * sizeof(float);
   const size_t budget = 160 * 1024;
-  if (per_sub + fixed > budget)
+  if (per_sub + fixed_staged > budget)
     return fail(RQ_EUNSUPPORTED, "one sub-codebook needs %zu B of LDS (> 160 KiB): h=%d ksteps=%d",
-                per_sub + fixed, p.h, KS);
+                per_sub + fixed_staged, p.h, KS);
+  // every sub-quantizer exactly 2*KS wide (and 8-byte aligned rows): the LDS-free-X fast path
+  constexpr bool direct = DIRECT;
+  const size_t fixed = direct ? 0 : fixed_staged;
   const int gmax = (int)std::min<size_t>((budget - fixed) / per_sub, (size_t)p.m);
-  auto kern = encode_pq_kernel<KS, NT, NWAVES>;
+  void (*kern)(EncParams);
+  if constexpr (DIRECT) kern = encode_pq_direct_kernel<KS, NT, NWAVES>;
+  else kern = encode_pq_kernel<KS, NT, NWAVES>;
   const int64_t ntiles = (p.n + 31) / 32;
   const int grid = (int)std::min<int64_t>(num_cu, (ntiles + NWAVES - 1) / NWAVES);
   for (int i0 = 0; i0 < p.m; i0 += gmax) {
@@ -493,19 +610,24 @@ int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int
   }
   p.off[m] = pos;
   const int ks = (maxsub + 1) / 2;
-  const int nw = tuning("ENC_WAVES", 8);
+  const int nw = tuning("ENC_WAVES", 16);
   const int nt = (h + 31) / 32;
-#define RQ_ENC_NT(KSV, NW)                                                  \
+#define RQ_ENC_NT(KSV, NW, DIR)                                             \
   do {                                                                     \
-    if (nt <= 1) return launch_encode<KSV, 1, NW>(p, num_cu, stream);       \
-    if (nt <= 2) return launch_encode<KSV, 2, NW>(p, num_cu, stream);       \
-    if (nt <= 4) return launch_encode<KSV, 4, NW>(p, num_cu, stream);       \
-    return launch_encode<KSV, 8, NW>(p, num_cu, stream);                    \
+    if (nt <= 1) return launch_encode<KSV, 1, NW, DIR>(p, num_cu, stream);  \
+    if (nt <= 2) return launch_encode<KSV, 2, NW, DIR>(p, num_cu, stream);  \
+    if (nt <= 4) return launch_encode<KSV, 4, NW, DIR>(p, num_cu, stream);  \
+    return launch_encode<KSV, 8, NW, DIR>(p, num_cu, stream);               \
   } while (0)
+  // fast path: every sub-quantizer exactly 2*KS wide and rows 8-byte aligned -> X straight to registers,
+  // 8 or 16 wavefronts per workgroup; otherwise the LDS-staged kernel (8 wavefronts)
 #define RQ_ENC_CASE(KSV)                                                   \
   if (ks <= KSV) {                                                         \
-    if (nw == 4) RQ_ENC_NT(KSV, 4);                                         \
-    RQ_ENC_NT(KSV, 8);                                                      \
+    const bool direct = tuning("ENC_DIRECT", 1) && (d % m == 0) && (d / m == 2 * KSV) && \
+                        (((uintptr_t)X & 7) == 0);                         \
+    if (direct && nw == 16) RQ_ENC_NT(KSV, 16, true);                       \
+    if (direct) RQ_ENC_NT(KSV, 8, true);                                    \
+    RQ_ENC_NT(KSV, 8, false);                                               \
   }
   RQ_ENC_CASE(1)
   RQ_ENC_CASE(2)

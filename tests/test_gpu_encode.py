@@ -21,7 +21,7 @@ def _split(Ccat, d, m, h):
     return out
 
 
-@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("waves", [8, 16])
 @pytest.mark.parametrize("name", ENC)
 def test_quantize_pq_matches_golden(rq, name, waves):
     g = golden(name)
@@ -31,7 +31,7 @@ def test_quantize_pq_matches_golden(rq, name, waves):
     try:
         B = rq.quantize_pq(g["X"], C)
     finally:
-        rq.set_tuning("ENC_WAVES", 4)
+        rq.set_tuning("ENC_WAVES", 8)
     assert B.dtype == np.int16 and B.shape == g["codes"].shape
     assert np.array_equal(B, g["codes"].astype(np.int16) + 1)       # one-based (src/PQ.jl:45-47)
     assert np.array_equal(rq.quantize_pq_u8(g["X"], C), g["codes"])

@@ -56,11 +56,11 @@ if "encode" in a.what:
     X = torch.randint(0, 200, (n, d), generator=g, device=dev).float()
     C = torch.randint(0, 200, (256 * d,), generator=g, device=dev).float()
     out = torch.empty((n, m), dtype=torch.uint8, device=dev)
-    for w in (4, 8):
+    for w in (8, 16):
         rq.set_tuning("ENC_WAVES", w)
         ms = bench(lambda: rqd.encode_pq(X, C, m, 256, out=out), a.iters)
         print("encode n=%d d=%d m=%d waves=%d %8.3f ms  %12.0f vec/s  %6.1f TF" % (n, d, m, w, ms, n / ms * 1e3, 2.0 * d * 256 * n / ms / 1e9))
-    rq.set_tuning("ENC_WAVES", 4)
+    rq.set_tuning("ENC_WAVES", 8)
 if "rotate" in a.what:
     X = torch.randn((n, d), generator=g, device=dev)
     R = torch.randn((d, d), generator=g, device=dev)
