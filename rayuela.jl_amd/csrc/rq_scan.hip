@@ -647,7 +647,7 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   if (slack_i <= 0) slack_i = std::min(std::max(4 * K, 1024), 16384);
   const uint32_t slack = (uint32_t)slack_i;
   pl.trigger = (uint32_t)K + slack;
-  pl.sample = (uint32_t)tuning("SCAN_SAMPLE", 8192);
+  pl.sample = (uint32_t)tuning("SCAN_SAMPLE", 16384);
   pl.cap = pl.trigger + Cfg::BLK;
   pl.p2 = next_pow2((uint32_t)K);
   // LDS scratch for the final sort: at least one query, at most QG, within 160 KiB total

@@ -98,7 +98,7 @@ def test_threshold_strategies_are_all_exact(rq, oracle, knob, value):
     queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
     codes = synth.random_codes(n, m, seed=123)
     d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
-    default = {"SCAN_SAMPLE": 8192, "SCAN_SRANK_MUL": 2, "SCAN_SLACK": 0}[knob]
+    default = {"SCAN_SAMPLE": 16384, "SCAN_SRANK_MUL": 2, "SCAN_SLACK": 0}[knob]
     rq.set_tuning(knob, value)
     try:
         d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
