@@ -5,24 +5,30 @@
 //   dist  d_j     = ((T[0][b_j0] + T[1][b_j1]) + ...)           sequential f32               (:85-87)
 //   top-k         = k smallest (dist, id) pairs, lexicographic, ascending                    (:91-97)
 //
-// MI355X design (DESIGN.md section "ADC scan"):
-//   * One 1024-thread workgroup per CU (16 wavefronts), persistent over work items
-//     (query-group x row-slice) handed out by an atomic counter.
+// MI355X design:
+//   * Two 512-thread workgroups per CU, persistent over work items (query-group x row-slice)
+//     handed out by an atomic counter; the second workgroup streams while the first one sits in
+//     a barrier, a cut or its final sort.
 //   * A query group is QG queries.  Their LUTs live in LDS interleaved 4 queries per entry:
 //     lut[k][quad][r] is a float4 = T_q[k][r] for the 4 queries of the quad, so ONE
 //     ds_read_b128 gather serves 4 queries; slot = r mod 16 spreads a 16-lane group over
 //     all 64 banks (the [k][r][QG] layout would only reach every other 16-byte slot).
-//   * Codes stream from HBM/L2 coalesced, 16 or 32 bytes per lane per block; every code byte
-//     is read once per query GROUP, not per query.
-//   * Top-k: per-query threshold tau (the k-th smallest key seen so far).  A row survives the
-//     hot loop only if dist < tau; survivors are appended (wave-aggregated LDS atomic) to a
-//     per-query candidate buffer in global memory (L2 resident).  When a buffer could overflow
-//     during the next block it is cut back to exactly k keys by an 8-pass radix select, all
-//     queries of the group in lockstep.  Strict '<' is exact because row ids only grow from
-//     block to block: a later row that ties tau's distance has a larger id, i.e. a larger key.
+//     The last KG sub-quantizers are gathered through L1 from a per-workgroup global table
+//     instead (the LDS pipe is the bound; the vector-memory pipe runs beside it).
+//   * Codes stream from HBM/L2 coalesced, 16 or 32 bytes per lane per sub-step, U sub-steps per
+//     block; every code byte is read once per query GROUP, not per query.
+//   * Top-k: per-query threshold tau.  A row survives the hot loop only if dist < tau; survivors
+//     are appended (one LDS atomic per row for all QG queries) to a per-query candidate buffer in
+//     global memory.  tau starts from a sampled estimate (per-thread minima of a stratified
+//     sample, rank selected in LDS); if fewer than k rows beat it the slice is redone from
+//     tau = +inf, which cuts the buffer back to exactly k keys by an 8-pass radix select whenever
+//     it could overflow.  Strict '<' is exact because row ids only grow from block to block: a
+//     later row that ties tau's distance has a larger id, i.e. a larger key.
 //   * At the end of a slice the k survivors are bitonic-sorted in LDS (the LUT is dead by then
 //     and its space is reused) and written either as final (dist,id) or as packed keys for
 //     the slice/GPU merge kernel.
+//   * LUT modes 1/2 and the per-row bias serve linscan_lsq / linscan_cq
+//     (deps/src/linscan_aqd_pairwise_byte.cpp) with the same kernel.
 #include "rq_internal.h"
 #include "rq_topk.h"
 
@@ -68,7 +74,6 @@ struct ScanCfg {
   static constexpr int KL = M - KG;                 // sub-quantizers [0, KL) gather from LDS
   static constexpr int GTAB_F4 = KG * NQUAD * 256;  // float4 entries of the global (L1) table
   static constexpr int LUT_LDS_BYTES = KL * QG * 1024;
-  static constexpr int ROW_WORDS = (M + 3) / 4;
   static_assert(RPT >= 1, "M too large for this tiling");
 };
 

@@ -11,7 +11,8 @@
 //   radix_select  : k-th smallest key of an unsorted global buffer, 8 MSB-first 8-bit passes,
 //                   for G independent query-lanes in lockstep (TPG threads each)
 //   compact_leq   : copy the keys <= tau to the front of another buffer
-//   bitonic_sort  : ascending sort of a power-of-two LDS array
+//   radix_select_lds : the same on keys already in LDS (threshold sample, uint32 keys)
+//   bitonic_sort_tiled : ascending sort of a power-of-two LDS array, wave-local stages without barriers
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
