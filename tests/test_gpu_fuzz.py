@@ -1,0 +1,55 @@
+"""GPU: randomized shapes (seeded, no hypothesis shrinking needed) of the scan and the encode against the
+oracle -- ragged sizes, every supported m, tiny and huge k relative to n, duplicate rows, integer LUTs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_scan_fuzz(rq, oracle, seed):
+    import rayuela_jl_amd.synth as synth
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.choice([2, 4, 8, 16, 32]))
+    sub = int(rng.choice([1, 2, 3, 4, 8, 16]))
+    n = int(rng.choice([1, 2, 63, 64, 65, 1000, 4097, 20000, 140000, 270000]))
+    nq = int(rng.choice([1, 3, 8, 9, 33]))
+    K = int(min(n, rng.choice([1, 2, 7, 64, 100, 1000, 3000])))
+    if rng.random() < 0.5:   # integer-valued tables and few distinct rows -> massive exact ties
+        centers = rng.integers(0, 4, (m, 256, sub)).astype(np.float32)
+        queries = rng.integers(0, 4, (nq, m * sub)).astype(np.float32)
+        codes = (synth.random_codes(n, m, seed=seed) % 3).astype(np.uint8)
+    else:
+        centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+        queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+        codes = synth.random_codes(n, m, seed=seed)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+    assert np.array_equal(i0, i1), (m, sub, n, nq, K)
+    assert _eq_bits(d0, d1), (m, sub, n, nq, K)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_encode_fuzz(rq, oracle, seed):
+    import rayuela_jl_amd.synth as synth
+    rng = np.random.default_rng(2000 + seed)
+    m = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 32]))
+    sub = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 16]))
+    extra = int(rng.choice([0, 0, 1, m - 1])) if m > 1 else 0      # uneven splitarray splits
+    d = m * sub + extra
+    h = int(rng.choice([1, 2, 17, 32, 64, 100, 255, 256]))
+    n = int(rng.choice([1, 31, 32, 33, 1000, 5003]))
+    X = (rng.standard_normal((n, d)) * 5).astype(np.float32)
+    if rng.random() < 0.3:
+        X = np.round(X)                                            # exact ties between centroids happen
+    off = synth.splitarray(d, m)
+    C = [np.round(rng.standard_normal((h, int(off[i + 1] - off[i]))) * 5).astype(np.float32) for i in range(m)]
+    if h > 2:
+        C[0][h // 2] = C[0][0]                                     # duplicate centroid -> first index must win
+    codes0 = oracle.encode_pq(X, synth.cat_codebooks(C), m, h)
+    codes1 = rq.quantize_pq_u8(X, C)
+    assert np.array_equal(codes0, codes1), (m, d, h, n, int((codes0 != codes1).sum()))
