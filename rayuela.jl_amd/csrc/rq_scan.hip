@@ -100,7 +100,7 @@ struct ScanParams {
   int id_base;
   uint32_t nslices, rows_per_slice, ngroups;
   uint32_t cap;             // candidate buffer capacity per query (keys)
-  uint32_t trigger;         // compact when cnt > trigger  (cap - BLK >= trigger >= K)
+  uint32_t trigger;         // compact when cnt > trigger  (cap - 2*BLK >= trigger >= K)
   uint32_t p2;              // next_pow2(K)
   uint32_t scratch_keys;    // LDS sort scratch capacity in keys
   uint32_t sample;          // rows sampled per slice to initialise tau (0 = off)
@@ -350,10 +350,13 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     // ---- stream the slice -----------------------------------------------------------------------
 #pragma unroll 1
     for (uint32_t base = r_begin; base < r_end; base += BLK) {
-      // capacity invariant: cnt[q] + BLK <= cap for every q when a block starts
-      bool need = ctrl->cnt[g] > p.trigger;
-      if (__syncthreads_or(need)) {
+      // ONE barrier per block.  Capacity invariant: cnt[q] + BLK <= cap for every q when a block starts.
+      // The pre-barrier read of cnt may miss what slower wavefronts are still appending for the
+      // previous block (at most BLK keys), hence cap = trigger + 2*BLK; behind the barrier cnt is exact.
+      const bool maybe = ctrl->cnt[g] > p.trigger;
+      if (__syncthreads_or(maybe)) {
         const unsigned long long t_c = RQ_STAT_T();
+        const bool need = ctrl->cnt[g] > p.trigger;
         compact_group<M>(ctrl, cand_wg, p, need, g, gi);
         RQ_STAT_ADD(3, t_c);
         RQ_STAT_INC(6);
@@ -444,8 +447,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
         }
       }
       }  // sub-steps
-      __syncthreads();
     }
+    __syncthreads();   // every append of the slice has landed
 
     RQ_STAT_ADD(2, t_ph);
     t_ph = RQ_STAT_T();
@@ -653,7 +656,7 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   const uint32_t slack = (uint32_t)slack_i;
   pl.trigger = (uint32_t)K + slack;
   pl.sample = (uint32_t)tuning("SCAN_SAMPLE", 16384);
-  pl.cap = pl.trigger + Cfg::BLK;
+  pl.cap = pl.trigger + 2 * Cfg::BLK;
   pl.p2 = next_pow2((uint32_t)K);
   // LDS scratch for the final sort: at least one query, at most QG, within 160 KiB total
   const size_t lds_max = 160 * 1024 - CTRL_BYTES;
