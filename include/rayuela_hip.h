@@ -146,6 +146,16 @@ int rq_dev_reconstruct(float *CB, const uint8_t *codes, const float *C, int64_t 
 int rq_dev_qerror(double *acc, const float *X, const float *CB, int64_t n, int d, void *stream);
 int rq_dev_gram(float *G, const float *X, const float *CB, int64_t n, int d, void *stream);
 
+/* train_pq (src/PQ.jl:68-99) and train_opq (src/OPQ.jl:49-139) on host pointers: X [n][d]; outputs
+ * C (concat of the m [h][sub_i] codebooks), B1 [n][m] Int16 ONE-based, R [d][d] (memory image of Julia's R),
+ * obj [niter+1], *error = qerror_pq of the result.  init: 0 "natural", 1 "random".  R0 / C0 may be NULL;
+ * when given they replace the random initialisation (reproducible runs).  `seed` feeds the library's own
+ * splitmix64 stream -- the reference uses Julia's global RNG, so equal seeds do not mean equal draws. */
+int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n, int d, int m, int h,
+                int niter, uint64_t seed);
+int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, int64_t n, int d, int m,
+                 int h, int niter, int init, uint64_t seed, const float *R0, const float *C0);
+
 /* ---- device-resident index handle (codes uploaded once; used by the Julia shim's
  * optional fast path and by multi-GPU deployments, one handle per process/GPU) ------------- */
 typedef struct rq_index rq_index;

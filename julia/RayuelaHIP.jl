@@ -12,7 +12,7 @@
 # C ABI is exercised through ctypes by tests/ (rayuela.jl_amd/*.py mirrors this file line by line).
 module RayuelaHIP
 
-export quantize_pq, quantize_opq, linscan_pq, linscan_opq, linscan_lsq, linscan_cq
+export quantize_pq, quantize_opq, linscan_pq, linscan_opq, linscan_lsq, linscan_cq, train_pq, train_opq
 
 # deps/build.jl:64-67 writes the library paths into deps/deps.jl; here one constant / env var.
 const librayuela_hip = get(ENV, "RAYUELA_HIP_LIB",
@@ -143,6 +143,52 @@ end
 
 function linscan_cq(B::Matrix{T}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat}}, k::Int=10000) where T <: Integer
   return linscan_cq(convert(Matrix{UInt8}, B .- 1), X, C, k)
+end
+
+# splitarray(1:d, m) sizes (src/utils.jl:179-203), to cut the flat codebook buffer back into matrices
+function _split_codebooks(Ccat::Vector{Float32}, d::Int, m::Int, h::Int)
+  per, extra = divrem(d, m)
+  C = Vector{Matrix{Float32}}(undef, m)
+  pos = 0
+  for i = 1:m
+    sub  = per + (i <= extra ? 1 : 0)
+    C[i] = reshape(Ccat[pos+1 : pos+sub*h], sub, h)
+    pos += sub * h
+  end
+  return C
+end
+
+"""
+    train_pq(X, m, h, niter=25, V=false) -> C, B, error     (src/PQ.jl:68-99)
+k-means per subspace on the device.  Initial centres come from the library's seeded stream.
+"""
+function train_pq(X::Matrix{Float32}, m::Integer, h::Integer, niter::Integer=25, V::Bool=false; seed::Integer=0)
+  d, n = size(X)
+  Ccat = Vector{Float32}(undef, h * d)
+  B    = Matrix{Int16}(undef, m, n)
+  err  = Ref{Cdouble}(0.0)
+  _check(ccall((:rq_train_pq, librayuela_hip), Cint,
+    (Ptr{Cfloat}, Ptr{Int16}, Ref{Cdouble}, Ptr{Cfloat}, Int64, Cint, Cint, Cint, Cint, UInt64),
+    Ccat, B, err, X, Int64(n), Cint(d), Cint(m), Cint(h), Cint(niter), UInt64(seed)))
+  return _split_codebooks(Ccat, d, Int(m), Int(h)), B, Float32(err[])
+end
+
+"""
+    train_opq(X, m, h, niter, init, V=false) -> C, B, R, obj     (src/OPQ.jl:49-139)
+"""
+function train_opq(X::Matrix{Float32}, m::Integer, h::Integer, niter::Integer, init::String, V::Bool=false; seed::Integer=0)
+  d, n = size(X)
+  init in ("natural", "random") || error("Intialization \$init unknown")
+  Ccat = Vector{Float32}(undef, h * d)
+  B    = Matrix{Int16}(undef, m, n)
+  R    = Matrix{Float32}(undef, d, d)
+  obj  = zeros(Float32, niter + 1)
+  _check(ccall((:rq_train_opq, librayuela_hip), Cint,
+    (Ptr{Cfloat}, Ptr{Int16}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cint, Cint, Cint, Cint, Cint, UInt64,
+     Ptr{Cfloat}, Ptr{Cfloat}),
+    Ccat, B, R, obj, X, Int64(n), Cint(d), Cint(m), Cint(h), Cint(niter), Cint(init == "natural" ? 0 : 1),
+    UInt64(seed), C_NULL, C_NULL))
+  return _split_codebooks(Ccat, d, Int(m), Int(h)), B, R, obj
 end
 
 end # module

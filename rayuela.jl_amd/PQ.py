@@ -39,3 +39,32 @@ def quantize_pq_u8(X, C):
     B = np.empty((n, m), dtype=np.uint8)
     _lib.check(_lib.lib().rq_encode_pq(B.ctypes.data, X.ctypes.data, Cc.ctypes.data, n, d, m, h))
     return B
+
+
+def train_pq(X, m, h, niter=25, V=False, seed=0):
+    """train_pq(X, m, h, niter=25, V=false) -> C, B, error        (src/PQ.jl:68-99)
+
+    Lloyd's k-means in every subspace (all m subspaces per device pass), through rq_train_pq.
+    C: list of m (h, sub_i) codebooks; B: (n, m) int16 one-based; error: qerror_pq of the result.
+    Initial centres come from the library's seeded stream, not Julia's RNG (see include/rayuela_hip.h)."""
+    X = _as_f32(X, "X")
+    n, d = X.shape
+    Ccat = np.empty(h * d, dtype=np.float32)
+    B = np.empty((n, m), dtype=np.int16)
+    import ctypes
+    err = ctypes.c_double(0.0)
+    _lib.check(_lib.lib().rq_train_pq(Ccat.ctypes.data, B.ctypes.data, ctypes.cast(ctypes.byref(err), ctypes.c_void_p),
+                                      X.ctypes.data, n, d, m, h, niter, seed))
+    if V:
+        print("  Error in training is %e" % err.value)
+    return _split_codebooks(Ccat, d, m, h), B, float(err.value)
+
+
+def _split_codebooks(Ccat, d, m, h):
+    per, extra = divmod(d, m)
+    out, pos = [], 0
+    for i in range(m):
+        sub = per + (1 if i < extra else 0)
+        out.append(Ccat[pos:pos + h * sub].reshape(h, sub).copy())
+        pos += h * sub
+    return out

@@ -12,17 +12,8 @@ from .PQ import quantize_pq, quantize_pq_u8  # noqa: F401
 from .OPQ import quantize_opq, rotate  # noqa: F401
 
 
-def train_pq(*a, **k):
-    """train_pq (src/PQ.jl:68-99); needs torch for device memory, imported lazily."""
-    from .train import train_pq as f
-    return f(*a, **k)
-
-
-def train_opq(*a, **k):
-    """train_opq (src/OPQ.jl:49-139); needs torch for device memory, imported lazily."""
-    from .train import train_opq as f
-    return f(*a, **k)
-
+from .PQ import train_pq  # noqa: F401,E402
+from .OPQ import train_opq  # noqa: F401,E402
 from .Linscan import (linscan_pq, linscan_opq, linscan_lsq, linscan_cq, linscan_aqd_query,  # noqa: F401
                       linscan_aqd_query_extra_byte, eval_recall)
 

