@@ -133,6 +133,16 @@ static int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_
   if (((uintptr_t)codes & 15) != 0) return fail(RQ_EINVAL, "codes pointer must be 16-byte aligned");
   DeviceInfo di;
   RQ_TRY(device_info(&di));
+  const int mp = scan_padded_m(m);
+  if (mp < 0) return fail(RQ_EUNSUPPORTED, "the ADC scan kernels cover 1 <= m <= 32 sub-quantizers; got m=%d", m);
+  if (mp != m) {
+    // row width not one of the tiled ones: zero-pad the rows (padding tables are all zero, so the
+    // sequential sum is unchanged bit for bit)
+    void *padded = nullptr;
+    RQ_TRY(workspace(WS_PAD, (size_t)n * mp, &padded));
+    RQ_TRY(pad_codes_launch((uint8_t *)padded, codes, n, m, mp, stream));
+    codes = (const uint8_t *)padded;
+  }
   ScanPlan pl;
   RQ_TRY(scan_plan(pl, n, nq, m, d, k, di.num_cu, tuning("SCAN_SLICES", 0)));
   void *cand = nullptr, *counter = nullptr;

@@ -38,7 +38,7 @@ int device_info(DeviceInfo *out);
 // Grow-only per-device scratch, owned by the library.  Calls on one device are expected to be
 // issued from one stream at a time (the host-pointer API serialises them itself).
 int workspace(int slot, size_t bytes, void **ptr);
-enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_SLOTS = 4 };
+enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_PAD = 4, WS_SLOTS = 5 };
 
 // ---- ADC scan -------------------------------------------------------------------------------
 struct ScanPlan {
@@ -54,6 +54,8 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
                 hipStream_t stream, int lut_mode = 0, const float *row_bias = nullptr);
 enum { LUT_PQ = 0, LUT_LSQ = 1, LUT_CQ = 2 };
+int scan_padded_m(int m);   // smallest tiled row width >= m (2,4,8,16,32) or -1
+int pad_codes_launch(uint8_t *dst, const uint8_t *src, int64_t n, int m, int mp, hipStream_t stream);
 int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t *keys_in, int64_t nq,
                  int P, int K, int id_base, hipStream_t stream);
 int lut_launch(float *lut, const float *centers, const float *queries, int64_t nq, int m, int sub,

@@ -94,6 +94,7 @@ struct ScanParams {
   const float *queries;     // [nq][d]
   uint32_t n, nq;
   int sub, d, K;
+  int m_real;               // sub-quantizers that exist; tables k >= m_real are all-zero padding
   int lut_mode;             // 0 PQ sub-space (c-q)^2 | 1 LSQ -2<q,c> full-dim | 2 CQ (q-c)^2 full-dim
   const float *row_bias;    // LSQ: dbnorms[n], added after the table sum; else nullptr
   uint32_t id_offset;
@@ -125,7 +126,7 @@ struct ScanParams {
 // ------------------------------------------------------------------------------------------
 template <int M>
 __device__ __forceinline__ void build_lut(float *lut, float4 *gtab, const float *qstage,
-                                          const float *centers, int sub, int d, int mode, int tid) {
+                                          const float *centers, int sub, int d, int mode, int m_real, int tid) {
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD;
   const int cdim = mode == 0 ? sub : d;
@@ -136,7 +137,9 @@ __device__ __forceinline__ void build_lut(float *lut, float4 *gtab, const float 
     float acc[QG];
 #pragma unroll
     for (int q = 0; q < QG; ++q) acc[q] = 0.0f;
-    if (mode == 1) {
+    if (k >= m_real) {
+      // padding sub-quantizer (m rounded up to a supported tile width): T = 0, and x + 0.0f == x
+    } else if (mode == 1) {
       for (int s = 0; s < cdim; ++s) {
         const float cs = c[s];
 #pragma unroll
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     }
     __syncthreads();
     unsigned long long t_ph = RQ_STAT_T();
-    build_lut<M>(lut, gtab, qstage, p.centers, p.sub, p.d, p.lut_mode, tid);
+    build_lut<M>(lut, gtab, qstage, p.centers, p.sub, p.d, p.lut_mode, p.m_real, tid);
     __syncthreads();
     // the L1 part of the table was written by other wavefronts (and the previous item's lines may
     // still sit in this CU's L1): drop them before the first gather
@@ -596,6 +599,15 @@ __global__ void adc_lut_kernel(float *lut, const float *centers, const float *qu
   lut[e] = acc;
 }
 
+// codes [n][m] -> [n][mp] with zero padding bytes (m not one of the tiled widths)
+__global__ void pad_codes_kernel(uint8_t *dst, const uint8_t *src, size_t n, int m, int mp) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * (size_t)mp) return;
+  const size_t r = e / mp;
+  const int k = (int)(e - r * mp);
+  dst[e] = k < m ? src[r * m + k] : (uint8_t)0;
+}
+
 __global__ void synth_codes_kernel(uint8_t *codes, size_t nbytes, uint64_t seed, uint64_t e0) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (i >= nbytes) return;
@@ -678,7 +690,14 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
               ((size_t)Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * (d + SCAN_THREADS) * 4 <= lds_max);
 }
 
+int scan_padded_m(int m) {
+  for (int mp : {2, 4, 8, 16, 32})
+    if (m <= mp) return mp;
+  return -1;
+}
+
 int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_cu, int force_slices) {
+  m = scan_padded_m(m);
   switch (m) {
     case 2: plan_for<2>(pl, n, nq, d, K, num_cu, force_slices); break;
     case 4: plan_for<4>(pl, n, nq, d, K, num_cu, force_slices); break;
@@ -686,7 +705,7 @@ int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_
     case 16: plan_for<16>(pl, n, nq, d, K, num_cu, force_slices); break;
     case 32: plan_for<32>(pl, n, nq, d, K, num_cu, force_slices); break;
     default:
-      return fail(RQ_EUNSUPPORTED, "ADC scan kernels cover m in {2,4,8,16,32}; got m=%d", m);
+      return fail(RQ_EUNSUPPORTED, "the ADC scan kernels cover 1 <= m <= 32 sub-quantizers");
   }
   if (!pl.lds_ok) return fail(RQ_EUNSUPPORTED, "k=%d / d=%d does not fit the 160 KiB LDS plan", K, d);
   return RQ_OK;
@@ -699,6 +718,8 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   ScanParams p;
   p.codes = codes; p.centers = centers; p.queries = queries;
   p.n = (uint32_t)n; p.nq = (uint32_t)nq; p.sub = d / m; p.d = d; p.K = K;
+  p.m_real = m;
+  m = scan_padded_m(m);   // `codes` already has this row width (dev_linscan pads when needed)
   p.lut_mode = lut_mode; p.row_bias = row_bias;
   p.id_offset = id_offset; p.id_base = id_base;
   p.nslices = pl.nslices; p.rows_per_slice = pl.rows_per_slice; p.ngroups = pl.ngroups;
@@ -731,6 +752,14 @@ int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(merge_topk_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(merge_topk_kernel, dim3((uint32_t)nq), dim3(MERGE_THREADS), lds, stream, p);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+int pad_codes_launch(uint8_t *dst, const uint8_t *src, int64_t n, int m, int mp, hipStream_t stream) {
+  const size_t total = (size_t)n * mp;
+  hipLaunchKernelGGL(pad_codes_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, dst, src,
+                     (size_t)n, m, mp);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
 }
