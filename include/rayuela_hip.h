@@ -114,7 +114,7 @@ int rq_dev_encode_opq(uint8_t *codes, const float *X, const float *R, const floa
 /* Per-query ADC look-up tables lut [nq][m][256] (deps/src/linscan_aqd.cpp:66-74); test aid. */
 int rq_dev_adc_lut(float *lut, const float *centers, const float *queries, int64_t nq, int m,
                    int subdim, void *stream);
-/* The ADC scan + exact top-k over one resident shard of n rows.
+/* The ADC scan + exact top-k over one resident shard of n rows (1 <= m <= 64, h = 256, k <= RQ_MAX_K).
  *   dists/ids [nq][k] (may both be NULL when keys != NULL)
  *   keys      [nq][k] uint64 or NULL: sorted packed (ordered-dist << 32 | id) per query, the
  *             form exchanged between shards/GPUs and consumed by rq_dev_merge_topk

@@ -134,7 +134,7 @@ static int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_
   DeviceInfo di;
   RQ_TRY(device_info(&di));
   const int mp = scan_padded_m(m);
-  if (mp < 0) return fail(RQ_EUNSUPPORTED, "the ADC scan kernels cover 1 <= m <= 32 sub-quantizers; got m=%d", m);
+  if (mp < 0) return fail(RQ_EUNSUPPORTED, "the ADC scan kernels cover 1 <= m <= 64 sub-quantizers; got m=%d", m);
   if (mp != m) {
     // row width not one of the tiled ones: zero-pad the rows (padding tables are all zero, so the
     // sequential sum is unchanged bit for bit)

@@ -54,7 +54,7 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
                 hipStream_t stream, int lut_mode = 0, const float *row_bias = nullptr);
 enum { LUT_PQ = 0, LUT_LSQ = 1, LUT_CQ = 2 };
-int scan_padded_m(int m);   // smallest tiled row width >= m (2,4,8,16,32) or -1
+int scan_padded_m(int m);   // smallest tiled row width >= m (2,4,8,16,32,64) or -1
 int pad_codes_launch(uint8_t *dst, const uint8_t *src, int64_t n, int m, int mp, hipStream_t stream);
 int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t *keys_in, int64_t nq,
                  int P, int K, int id_base, hipStream_t stream);

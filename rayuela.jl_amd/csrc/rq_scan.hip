@@ -47,16 +47,32 @@ __device__ __forceinline__ uint32_t writelane_u32(uint32_t old, T val, int L) {
   return old;
 }
 
+// LUT entry of QPG queries
+template <int QPG> struct LutVec;
+template <> struct LutVec<4> {
+  using type = float4;
+  static __device__ __forceinline__ type make(const float *a) { return make_float4(a[0], a[1], a[2], a[3]); }
+  static __device__ __forceinline__ float get(const type &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+};
+template <> struct LutVec<2> {
+  using type = float2;
+  static __device__ __forceinline__ type make(const float *a) { return make_float2(a[0], a[1]); }
+  static __device__ __forceinline__ float get(const type &v, int i) { return i == 0 ? v.x : v.y; }
+};
+
 template <int M>
 struct ScanCfg {
-  static constexpr int QG = (M <= 8) ? 8 : 4;      // queries per group
-  static constexpr int NQUAD = QG / 4;
-  static constexpr int RPT = 32 / (M * NQUAD);      // rows per thread per block
+  // queries per LDS gather: a float4 entry (ds_read_b128) up to m = 32; m = 64 only fits the 160 KiB of
+  // LDS with float2 entries (ds_read_b64, 2 queries per gather)
+  static constexpr int QPG = (M <= 32) ? 4 : 2;
+  static constexpr int QG = (M <= 8) ? 8 : (M <= 32) ? 4 : 2;   // queries per group
+  static constexpr int NQUAD = QG / QPG;                         // gathers per code byte
+  static constexpr int RPT = (32 / (M * NQUAD)) > 0 ? 32 / (M * NQUAD) : 1;   // rows per thread per sub-step
   static constexpr int SUB = SCAN_THREADS * RPT;    // rows per sub-step (one 16/32-byte load per lane)
 #ifndef RQ_SCAN_U8
 #define RQ_SCAN_U8 4
 #endif
-  static constexpr int U = (M <= 8) ? RQ_SCAN_U8 : 2;  // sub-steps per block: loads of a block fly together
+  static constexpr int U = (M <= 8) ? RQ_SCAN_U8 : (M <= 32) ? 2 : 1;  // sub-steps per block: loads of a block fly together
   static constexpr int BLK = SUB * U;               // rows per workgroup block (barrier / tau refresh period)
   static constexpr int LUT_BYTES = M * QG * 1024;   // full table; the LDS part is LUT_LDS_BYTES below
   // The LDS gather pipe is the kernel's bound (~11-12 cycles per 64-lane ds_read_b128 with random
@@ -67,12 +83,12 @@ struct ScanCfg {
 #ifndef RQ_SCAN_KG8
 #define RQ_SCAN_KG8 2
 #endif
-  static constexpr int KG = (M == 8) ? RQ_SCAN_KG8 : (M == 16) ? 4 : (M == 32) ? 4 : (M == 4) ? 1 : 0;
+  static constexpr int KG = (M == 8) ? RQ_SCAN_KG8 : (M == 16) ? 4 : (M == 32) ? 4 : (M == 4) ? 1 : 0;   // M = 64: all in LDS
 #else
   static constexpr int KG = 0;
 #endif
   static constexpr int KL = M - KG;                 // sub-quantizers [0, KL) gather from LDS
-  static constexpr int GTAB_F4 = KG * NQUAD * 256;  // float4 entries of the global (L1) table
+  static constexpr int GTAB_F4 = KG * NQUAD * 256;  // entries (float4 for QPG = 4) of the global (L1) table
   static constexpr int LUT_LDS_BYTES = KL * QG * 1024;
   static_assert(RPT >= 1, "M too large for this tiling");
 };
@@ -160,11 +176,13 @@ __device__ __forceinline__ void build_lut(float *lut, float4 *gtab, const float 
         }
       }
     }
+    using LV = LutVec<Cfg::QPG>;
+    using Vec = typename LV::type;
 #pragma unroll
     for (int quad = 0; quad < NQUAD; ++quad) {
-      float4 v = make_float4(acc[quad * 4 + 0], acc[quad * 4 + 1], acc[quad * 4 + 2], acc[quad * 4 + 3]);
-      if (k < Cfg::KL) reinterpret_cast<float4 *>(lut)[(k * NQUAD + quad) * 256 + r] = v;
-      else gtab[((k - Cfg::KL) * NQUAD + quad) * 256 + r] = v;
+      const Vec v = LV::make(&acc[quad * Cfg::QPG]);
+      if (k < Cfg::KL) reinterpret_cast<Vec *>(lut)[(k * NQUAD + quad) * 256 + r] = v;
+      else reinterpret_cast<Vec *>(gtab)[((k - Cfg::KL) * NQUAD + quad) * 256 + r] = v;
     }
   }
 }
@@ -173,10 +191,15 @@ __device__ __forceinline__ void build_lut(float *lut, float4 *gtab, const float 
 // acc_q = ((T_q[0][b0] + T_q[1][b1]) + ...)  -- deps/src/linscan_aqd.cpp:85-87, sequential f32.
 template <int M>
 __device__ __forceinline__ void row_dists(const uint32_t *w, int r, const float4 *lut4,
-                                          const float4 *__restrict__ gtab, float (&acc)[ScanCfg<M>::QG]) {
-  constexpr int NQUAD = ScanCfg<M>::NQUAD, KL = ScanCfg<M>::KL;
+                                          const float4 *__restrict__ gtab4, float (&acc)[ScanCfg<M>::QG]) {
+  using Cfg = ScanCfg<M>;
+  using LV = LutVec<Cfg::QPG>;
+  using Vec = typename LV::type;
+  constexpr int NQUAD = Cfg::NQUAD, KL = Cfg::KL, QPG = Cfg::QPG;
+  const Vec *lutv = reinterpret_cast<const Vec *>(lut4);
+  const Vec *__restrict__ gtab = reinterpret_cast<const Vec *>(gtab4);
   // issue the L1 gathers of the last sub-quantizers first: their latency hides under the LDS ones
-  float4 tg[(ScanCfg<M>::KG > 0 ? ScanCfg<M>::KG : 1) * NQUAD];
+  Vec tg[(Cfg::KG > 0 ? Cfg::KG : 1) * NQUAD];
 #pragma unroll
   for (int k = KL; k < M; ++k) {
     const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
@@ -188,15 +211,11 @@ __device__ __forceinline__ void row_dists(const uint32_t *w, int r, const float4
     const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
 #pragma unroll
     for (int quad = 0; quad < NQUAD; ++quad) {
-      const float4 t = k < KL ? lut4[(k * NQUAD + quad) * 256 + byte] : tg[(k - KL) * NQUAD + quad];
-      if (k == 0) {
-        acc[quad * 4 + 0] = t.x; acc[quad * 4 + 1] = t.y;
-        acc[quad * 4 + 2] = t.z; acc[quad * 4 + 3] = t.w;
-      } else {
-        acc[quad * 4 + 0] = acc[quad * 4 + 0] + t.x;
-        acc[quad * 4 + 1] = acc[quad * 4 + 1] + t.y;
-        acc[quad * 4 + 2] = acc[quad * 4 + 2] + t.z;
-        acc[quad * 4 + 3] = acc[quad * 4 + 3] + t.w;
+      const Vec t = k < KL ? lutv[(k * NQUAD + quad) * 256 + byte] : tg[(k - KL) * NQUAD + quad];
+#pragma unroll
+      for (int c = 0; c < QPG; ++c) {
+        if (k == 0) acc[quad * QPG + c] = LV::get(t, c);
+        else acc[quad * QPG + c] = acc[quad * QPG + c] + LV::get(t, c);
       }
     }
   }
@@ -691,7 +710,7 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
 }
 
 int scan_padded_m(int m) {
-  for (int mp : {2, 4, 8, 16, 32})
+  for (int mp : {2, 4, 8, 16, 32, 64})
     if (m <= mp) return mp;
   return -1;
 }
@@ -704,8 +723,9 @@ int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_
     case 8: plan_for<8>(pl, n, nq, d, K, num_cu, force_slices); break;
     case 16: plan_for<16>(pl, n, nq, d, K, num_cu, force_slices); break;
     case 32: plan_for<32>(pl, n, nq, d, K, num_cu, force_slices); break;
+    case 64: plan_for<64>(pl, n, nq, d, K, num_cu, force_slices); break;
     default:
-      return fail(RQ_EUNSUPPORTED, "the ADC scan kernels cover 1 <= m <= 32 sub-quantizers");
+      return fail(RQ_EUNSUPPORTED, "the ADC scan kernels cover 1 <= m <= 64 sub-quantizers");
   }
   if (!pl.lds_ok) return fail(RQ_EUNSUPPORTED, "k=%d / d=%d does not fit the 160 KiB LDS plan", K, d);
   return RQ_OK;
@@ -737,6 +757,7 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
     case 8: return launch_scan<8>(p, pl, stream);
     case 16: return launch_scan<16>(p, pl, stream);
     case 32: return launch_scan<32>(p, pl, stream);
+    case 64: return launch_scan<64>(p, pl, stream);
   }
   return fail(RQ_EUNSUPPORTED, "m=%d", m);
 }

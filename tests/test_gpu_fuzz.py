@@ -14,7 +14,7 @@ def _eq_bits(a, b):
 def test_scan_fuzz(rq, oracle, seed):
     import rayuela_jl_amd.synth as synth
     rng = np.random.default_rng(1000 + seed)
-    m = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 24, 32]))
+    m = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 24, 32, 40, 64]))
     sub = int(rng.choice([1, 2, 3, 4, 8, 16]))
     n = int(rng.choice([1, 2, 63, 64, 65, 1000, 4097, 20000, 140000, 270000]))
     nq = int(rng.choice([1, 3, 8, 9, 33]))

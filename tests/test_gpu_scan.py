@@ -73,6 +73,8 @@ def test_lut_kernel_bit_exact(rq, oracle):
     (5_000, 32, 2, 3, 10),
     (1, 8, 4, 2, 1),               # single row
     (70_000, 8, 4, 17, 16384),     # RQ_MAX_K
+    (60_000, 64, 2, 11, 1000),     # PQ64: float2 LUT entries, 2 queries per group
+    (10_000, 48, 2, 3, 100),       # padded to 64
 ])
 def test_scan_vs_oracle_random(rq, oracle, n, m, sub, nq, K):
     import rayuela_jl_amd.synth as synth
