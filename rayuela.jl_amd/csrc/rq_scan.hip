@@ -669,7 +669,7 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   pl.ngroups = (uint32_t)((nq + Cfg::QG - 1) / Cfg::QG);
   // row slices: enough work items to fill the chip, but slices long enough that the
   // per-slice top-k overhead (~K(1+ln(rows/K)) survivors, one sort) stays small
-  int64_t min_rows = std::max<int64_t>(65536, 32LL * K);
+  int64_t min_rows = std::max<int64_t>(16384, 32LL * K);
   min_rows = (min_rows + Cfg::BLK - 1) / Cfg::BLK * Cfg::BLK;
   int64_t max_slices = std::max<int64_t>(1, n / min_rows);
   int64_t want = (4LL * num_cu + pl.ngroups - 1) / pl.ngroups;
