@@ -31,7 +31,7 @@ def test_quantize_pq_matches_golden(rq, name, waves):
     try:
         B = rq.quantize_pq(g["X"], C)
     finally:
-        rq.set_tuning("ENC_WAVES", 8)
+        rq.set_tuning("ENC_WAVES", 16)
     assert B.dtype == np.int16 and B.shape == g["codes"].shape
     assert np.array_equal(B, g["codes"].astype(np.int16) + 1)       # one-based (src/PQ.jl:45-47)
     assert np.array_equal(rq.quantize_pq_u8(g["X"], C), g["codes"])
