@@ -45,8 +45,8 @@ struct ScanPlan {
   int qg, blk;
   uint32_t ngroups, nslices, rows_per_slice;
   uint32_t cap, trigger, p2, scratch_keys, grid, sample;
-  size_t cand_bytes, gtab_off;
-  bool lds_ok;
+  size_t cand_bytes, gtab_off, bkt_off;
+  bool lds_ok, bigk;
 };
 int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_cu, int force_slices);
 int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes,

@@ -126,6 +126,8 @@ struct ScanParams {
   float4 *gtab;               // [gridDim][GTAB_F4] L1-gathered part of the LUT
   unsigned long long *stats;  // optional [8]: cycles in lut, sample, stream, cuts, final cut, sort; #cuts; #fallbacks
   uint64_t *cand;           // [gridDim][QG][2][cap]
+  uint16_t *bkt;            // [gridDim][cap] bucket ids of the large-K sample sort
+  int bigk;                 // K > SCAN_SS_MIN_K: finish with samplesort_topk instead of cut + LDS bitonic
   // outputs: direct (nslices == 1 && keys == nullptr) or packed keys [nq][nslices][K]
   float *dists;
   uint32_t *ids;
@@ -262,6 +264,36 @@ __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, ui
 #define RQ_STAT_ADD(slot, t0) do { if (p.stats && threadIdx.x == 0) atomicAdd(&p.stats[slot], (unsigned long long)clock64() - (t0)); } while (0)
 #define RQ_STAT_INC(slot) do { if (p.stats && threadIdx.x == 0) atomicAdd(&p.stats[slot], 1ull); } while (0)
 
+// Large-K finish of one work item (out of line: keeps the streaming loop's register allocation
+// independent of it).  cnt/sel: the item's per-query candidate counts and current buffer halves.
+__device__ __noinline__ void finish_bigk(const uint32_t *cnt_q, const uint32_t *sel_q, uint32_t QG, uint64_t *cand_wg,
+                                         uint16_t *bkt, uint32_t cap, uint32_t K, uint32_t q0, uint32_t nq,
+                                         uint64_t *keys_slice, uint32_t nslices, float *dists, uint32_t *ids,
+                                         uint32_t id_base, unsigned char *lds, unsigned long long *stats) {
+  const uint32_t tid = threadIdx.x;
+#pragma unroll 1
+  for (uint32_t q = 0; q < QG; ++q) {
+    const uint32_t qq = q0 + q;
+    if (qq >= nq) break;
+    const uint32_t cnt = cnt_q[q], sel = sel_q[q];
+    const uint64_t *src = cand_wg + ((size_t)q * 2 + sel) * cap;
+    uint64_t *dst = cand_wg + ((size_t)q * 2 + (sel ^ 1u)) * cap;
+    const uint32_t n_out = min(K, cnt);
+    if (keys_slice) {
+      uint64_t *o = keys_slice + (size_t)qq * nslices * K;
+      for (uint32_t i = n_out + tid; i < K; i += SCAN_THREADS) o[i] = KEY_MAX;   // short slice
+      samplesort_topk<SCAN_THREADS>(src, dst, bkt, cnt, n_out, lds, [o](uint32_t r, uint64_t key) { o[r] = key; }, stats);
+    } else {
+      float *od = dists + (size_t)qq * K;
+      uint32_t *oi = ids + (size_t)qq * K;
+      samplesort_topk<SCAN_THREADS>(src, dst, bkt, cnt, n_out, lds, [od, oi, id_base](uint32_t r, uint64_t key) {
+        od[r] = key_dist(key);
+        oi[r] = key_id(key) + id_base;
+      }, stats);
+    }
+  }
+}
+
 template <int M, bool BIAS>
 __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p) {
   using Cfg = ScanCfg<M>;
@@ -315,12 +347,20 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     // than K rows beat it (needs a sample ~3x off) attempt 1 redoes the slice with tau = +inf,
     // which is exact by construction.  Either way the answer is exact: whenever >= K rows beat
     // tau, the K best rows are among them.
-    const uint32_t S = p.sample;
+    // The sample statistic is the per-thread MINIMUM of gsz rows, so the fraction of threads whose
+    // minimum beats the q-quantile is 1-(1-q)^gsz (~ q*gsz only while that is small); gsz shrinks
+    // for large K so that the selected rank stays in the well-conditioned middle of the 512 minima.
+    uint32_t S = p.sample;
     uint32_t srank = 0;
     bool sampled = false;
-    if (S > 0 && p.K >= 8 && rows >= 8u * S && (uint64_t)rows >= 16ull * (uint64_t)p.K) {
-      srank = (uint32_t)(((uint64_t)p.srank_mul * (uint64_t)p.K * S + rows - 1) / rows) + 8u;
-      sampled = srank * 2u <= (uint32_t)SCAN_THREADS;
+    if (S >= (uint32_t)SCAN_THREADS && p.K >= 8 && rows >= 8u * S && (uint64_t)rows >= 16ull * (uint64_t)p.K) {
+      const float q = (float)p.srank_mul * (float)p.K / (float)rows;      // target quantile (<= 1/8 * mul)
+      uint32_t gsz = S / (uint32_t)SCAN_THREADS;
+      if (q * (float)gsz > 0.7f) gsz = max(1u, (uint32_t)(0.7f / q));
+      S = gsz * (uint32_t)SCAN_THREADS;
+      const float frac = 1.0f - __expf((float)gsz * __logf(fmaxf(1.0f - q, 1e-6f)));
+      srank = (uint32_t)ceilf(frac * (float)SCAN_THREADS) + 8u;
+      sampled = q < 0.5f && srank * 4u <= 3u * (uint32_t)SCAN_THREADS;
     }
 #pragma unroll 1
     for (int attempt = sampled ? 0 : 1; attempt < 2; ++attempt) {
@@ -480,7 +520,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
       const bool shortfall = ctrl->cnt[g] < min((uint32_t)p.K, rows);
       if (__syncthreads_or(shortfall)) continue;  // exact fallback: redo the slice from tau = +inf
     }
-    {
+    if (!p.bigk) {
       bool need = ctrl->cnt[g] > (uint32_t)p.K;
       if (__syncthreads_or(need)) compact_group<M>(ctrl, cand_wg, p, need, g, gi);
     }
@@ -488,6 +528,14 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     }  // attempts
     RQ_STAT_ADD(4, t_ph);
     t_ph = RQ_STAT_T();
+    if (p.bigk) {
+      // large K: select + sort in one sample-sort pass per query, keys stay in global memory
+      finish_bigk(ctrl->cnt, ctrl->sel, QG, cand_wg, p.bkt + (size_t)blockIdx.x * p.cap, p.cap, (uint32_t)p.K,
+                  q0, p.nq, p.keys ? p.keys + (size_t)slice * p.K : nullptr, p.nslices, p.dists, p.ids,
+                  (uint32_t)p.id_base, smem + CTRL_BYTES, p.stats);
+      RQ_STAT_ADD(5, t_ph);
+      continue;
+    }
     // sort `nconc` queries at a time in LDS (scratch aliases the LUT, which is dead now)
     uint32_t nconc = p.scratch_keys / p.p2;
     if (nconc > (uint32_t)QG) nconc = QG;
@@ -652,6 +700,7 @@ static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) 
   constexpr int CTRL_BYTES = (sizeof(ScanCtrl<Cfg::QG>) + 15) & ~15;
   size_t lds = CTRL_BYTES + (size_t)std::max<size_t>(Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * (p.d + SCAN_THREADS) * 4,
                                                      (size_t)p.scratch_keys * 8);
+  if (p.bigk) lds = std::max<size_t>(lds, CTRL_BYTES + SS_LDS_BYTES);
   auto kern = p.row_bias ? adc_scan_kernel<M, true> : adc_scan_kernel<M, false>;
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -683,18 +732,21 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   // slack between cuts: with the sampled tau about 2-3K rows survive a slice, so a slack of 4K means
   // "no cut before the end"; the exact fallback (tau from +inf) cuts every `slack` survivors.
   int slack_i = tuning("SCAN_SLACK", 0);
-  if (slack_i <= 0) slack_i = std::min(std::max(4 * K, 1024), 16384);
+  if (slack_i <= 0) slack_i = std::max(std::min(std::max(4 * K, 1024), 16384), K + K / 2);
   const uint32_t slack = (uint32_t)slack_i;
   pl.trigger = (uint32_t)K + slack;
   pl.sample = (uint32_t)tuning("SCAN_SAMPLE", 16384);
   pl.cap = pl.trigger + 2 * Cfg::BLK;
   pl.p2 = next_pow2((uint32_t)K);
+  // large K finishes with the global-memory sample sort: its LDS need does not grow with K
+  pl.bigk = K > tuning("SCAN_SS_MIN_K", 1024);
   // LDS scratch for the final sort: at least one query, at most QG, within 160 KiB total
   const size_t lds_max = 160 * 1024 - CTRL_BYTES;
   size_t want_keys = (size_t)pl.p2 * Cfg::QG;
   size_t base_keys = ((size_t)Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * (d + SCAN_THREADS) * 4) / 8;
   size_t keys = std::max(base_keys, std::min(want_keys, (size_t)64 * 1024 / 8 * 2));
   keys = std::max(keys, (size_t)pl.p2);
+  if (pl.bigk) keys = std::max(base_keys, (size_t)(SS_LDS_BYTES + 7) / 8);
   keys = std::min(keys, lds_max / 8);
   pl.scratch_keys = (uint32_t)keys;
   const uint64_t items = (uint64_t)pl.ngroups * pl.nslices;
@@ -705,7 +757,9 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   pl.cand_bytes = (size_t)pl.grid * Cfg::QG * 2 * pl.cap * sizeof(uint64_t);
   pl.gtab_off = pl.cand_bytes;   // the L1-gathered LUT parts live behind the candidate buffers
   pl.cand_bytes += (size_t)pl.grid * (Cfg::GTAB_F4 > 0 ? Cfg::GTAB_F4 : 1) * sizeof(float4);
-  pl.lds_ok = ((size_t)pl.p2 * 8 <= lds_max) &&
+  pl.bkt_off = pl.cand_bytes;
+  if (pl.bigk) pl.cand_bytes += ((size_t)pl.grid * pl.cap * sizeof(uint16_t) + 15) & ~(size_t)15;
+  pl.lds_ok = (pl.bigk || (size_t)pl.p2 * 8 <= lds_max) &&
               ((size_t)Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * (d + SCAN_THREADS) * 4 <= lds_max);
 }
 
@@ -748,6 +802,8 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.srank_mul = (uint32_t)tuning("SCAN_SRANK_MUL", 2);
   p.work_counter = work_counter; p.cand = cand;
   p.gtab = reinterpret_cast<float4 *>(reinterpret_cast<char *>(cand) + pl.gtab_off);
+  p.bkt = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(cand) + pl.bkt_off);
+  p.bigk = pl.bigk ? 1 : 0;
   p.stats = tuning("SCAN_STATS", 0) ? reinterpret_cast<unsigned long long *>(work_counter + 16) : nullptr;
   p.dists = dists; p.ids = ids; p.keys = keys;
   RQ_HIP(hipMemsetAsync(work_counter, 0, p.stats ? 256 : sizeof(uint32_t), stream));

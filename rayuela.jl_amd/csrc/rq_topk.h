@@ -258,4 +258,203 @@ __host__ __device__ inline uint32_t next_pow2(uint32_t v) {
   return p;
 }
 
+// ------------------------------------------------------------------------------------------
+// Exact "n_out smallest of cnt keys, ascending" for large n_out, by all NT threads of a block.
+//
+// The LDS bitonic sort needs next_pow2(K) keys of LDS and 105 read-modify-write stages at
+// 16384 keys; for K in the thousands that dominated the scan.  This is a sample sort instead,
+// with the keys staying in global memory (L2-resident: they were just written):
+//   1. 2048 keys at stride cnt/2048 are sorted in LDS (16 KiB); 2047 of them split the key
+//      space into 2048 buckets of ~cnt/2048 keys;
+//   2. every key finds its bucket (11-step branch-free search in LDS) and counts itself;
+//   3. an exclusive scan gives the bucket starts and the bucket b* that holds rank n_out-1 --
+//      buckets behind b* are dropped, which replaces the radix-select cut;
+//   4. the kept keys are scattered to their bucket's range of `dst`;
+//   5. every kept key ranks itself inside its bucket by counting (keys are unique, so ranks
+//      are a permutation) and is emitted at  start[b] + rank  if that is < n_out.
+// The result is exact for any input; a skewed sample only makes step 5 slower (O(bucket^2)).
+// src/dst: global, cnt keys each (dst is scratch); bkt: global scratch, cnt u16; lds:
+// SS_LDS_BYTES.  All arguments are uniform over the block; contains __syncthreads().
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t SS_NS = 2048;
+constexpr uint32_t SS_LDS_BYTES = SS_NS * 8 + SS_NS * 4 + 128 + SS_NS * 8;
+
+template <int NT, class Emit>
+__device__ __forceinline__ void samplesort_topk(const uint64_t *src, uint64_t *dst, uint16_t *bkt, uint32_t cnt,
+                                                uint32_t n_out, unsigned char *lds, Emit emit,
+                                                unsigned long long *stats = nullptr) {
+  // stats (optional): cycles of [9] sample sort, [10] bucket search, [11] scan + scatter (rank = rest)
+#define SS_T() ((stats && threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull)
+#define SS_ADD(slot, t0) do { if (stats && threadIdx.x == 0) atomicAdd(&stats[slot], (unsigned long long)clock64() - (t0)); } while (0)
+  constexpr uint32_t NS = SS_NS;
+  constexpr int PER = NS / NT;
+  static_assert(NS % NT == 0 && NT % 64 == 0 && NT / 64 <= 16, "thread split");
+  uint64_t *smp = reinterpret_cast<uint64_t *>(lds);
+  uint32_t *nxt = reinterpret_cast<uint32_t *>(lds + NS * 8);
+  uint32_t *aux = nxt + NS;   // [0..15] wave sums, [16] b*, [17] end of b*
+  uint64_t *tree = reinterpret_cast<uint64_t *>(lds + NS * 8 + NS * 4 + 128);   // splitters, BFS order
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __syncthreads();   // the previous user of `lds` is done
+  if (cnt <= NS) {
+    // small input: the whole array is its own sample
+    const uint32_t p2 = next_pow2(cnt);
+    for (uint32_t i = tid; i < p2; i += NT) smp[i] = i < cnt ? src[i] : KEY_MAX;
+    bitonic_sort_tiled(smp, p2, NT / 64, wave, lane, true);
+    for (uint32_t i = tid; i < n_out; i += NT) emit(i, smp[i]);
+    return;
+  }
+  unsigned long long t_s = SS_T();
+  for (uint32_t i = tid; i < NS; i += NT) {
+    smp[i] = src[(uint32_t)(((uint64_t)i * cnt) >> 11)];
+    nxt[i] = 0;
+  }
+  bitonic_sort_tiled(smp, NS, NT / 64, wave, lane, true);
+  // The 2047 splitters smp[0..2046] go into breadth-first (Eytzinger) order: a binary search over
+  // the SORTED array reads, at depth t, addresses that are all congruent modulo 2^(11-t) keys --
+  // up to 64 distinct addresses in one LDS bank; in BFS order a level is contiguous.
+  for (uint32_t t = tid; t < NS; t += NT) {
+    if (t) {
+      const uint32_t lvl = 31u - (uint32_t)__builtin_clz(t), j = t - (1u << lvl);
+      tree[t] = smp[(((2u * j + 1u) << (10u - lvl))) - 1u];
+    }
+  }
+  __syncthreads();
+  SS_ADD(9, t_s);
+  t_s = SS_T();
+
+  // ---- 2. bucket of every key (number of splitters that are <= key) ----------------------------
+#pragma unroll 1
+  for (uint32_t i0 = 0; i0 < cnt; i0 += NT * 4) {
+    uint64_t k[4];
+    uint32_t b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t idx = i0 + u * NT + tid;
+      k[u] = idx < cnt ? src[idx] : KEY_MAX;
+      b[u] = 1;
+    }
+#pragma unroll
+    for (int lvl = 0; lvl < 11; ++lvl) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = 2u * b[u] + (uint32_t)(tree[b[u]] <= k[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[u] -= NS;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t idx = i0 + u * NT + tid;
+      if (idx < cnt) {
+        atomicAdd(&nxt[b[u]], 1u);
+        bkt[idx] = (uint16_t)b[u];
+      }
+    }
+  }
+  __syncthreads();
+  SS_ADD(10, t_s);
+  t_s = SS_T();
+
+  // ---- 3. exclusive scan of the bucket counts; b* = bucket holding rank n_out-1 -----------------
+  {
+    uint32_t c[PER], s = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { c[j] = nxt[tid * PER + j]; s += c[j]; }
+    const uint32_t incl = wave_incl_scan(s, (int)lane);
+    if (lane == 63) aux[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - s;
+    for (uint32_t w = 0; w < wave; ++w) run += aux[w];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const uint32_t end = run + c[j];
+      nxt[tid * PER + j] = run;
+      if (run < n_out && n_out <= end) { aux[16] = tid * PER + j; aux[17] = end; }
+      run = end;
+    }
+    __syncthreads();
+  }
+  const uint32_t bstar = aux[16], kept = aux[17];
+
+  // ---- 4. scatter the kept keys; nxt[b] walks from the bucket's start to its end ----------------
+#pragma unroll 1
+  for (uint32_t i0 = 0; i0 < cnt; i0 += NT * 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t idx = i0 + u * NT + tid;
+      if (idx < cnt) {
+        const uint32_t b = bkt[idx];
+        if (b <= bstar) {
+          const uint32_t pos = atomicAdd(&nxt[b], 1u);
+          dst[pos] = src[idx];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  SS_ADD(11, t_s);
+
+  // ---- 5. rank inside the bucket, emit ---------------------------------------------------------
+  // One 16-lane DPP row per bucket (buckets average cnt/2048 ~ 8-13 keys): the row loads the
+  // bucket 16 keys at a time, one key per lane, and every lane counts the keys below its own by
+  // rotating the other chunk around the row -- one global load per 16 keys instead of one per
+  // comparison.  nxt[b] is the bucket's end now, nxt[b-1] its start.
+  {
+    constexpr uint32_t NR = NT / 16, UB = 4;   // rows per block; buckets a row has in flight
+    const uint32_t row = tid >> 4, l16 = tid & 15;
+    // r += #{rotations 1..15 of `other` around the 16-lane row that are < mine}: a 64-bit compare is
+    // the borrow of (other - mine), so each rotation is sub / subb with the rotation folded into the
+    // DPP operand, plus one add-with-carry.  (s_nop: DPP after a VALU write of EXEC needs 5 states.)
+#define SS_ROTS(N)                                                                     \
+    "v_sub_co_u32_dpp %1, vcc, %2, %4 row_ror:" #N " row_mask:0xf bank_mask:0xf\n"      \
+    "v_subb_co_u32_dpp %1, vcc, %3, %5, vcc row_ror:" #N " row_mask:0xf bank_mask:0xf\n" \
+    "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n"
+#ifdef SS_SKIP_RANK
+    if (0)
+#endif
+#pragma unroll 1
+    for (uint32_t b0 = row; b0 <= bstar; b0 += NR * UB) {
+      uint32_t lo[UB], hi[UB];
+      uint64_t first[UB];
+#pragma unroll
+      for (uint32_t u = 0; u < UB; ++u) {
+        const uint32_t b = b0 + u * NR;
+        const bool on = b <= bstar;
+        lo[u] = (on && b) ? nxt[b - 1] : 0u;
+        hi[u] = on ? nxt[b] : 0u;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < UB; ++u) first[u] = (lo[u] + l16 < hi[u]) ? dst[lo[u] + l16] : KEY_MAX;
+#pragma unroll
+      for (uint32_t u = 0; u < UB; ++u) {
+#pragma unroll 1
+        for (uint32_t a = lo[u]; a < hi[u]; a += 16) {
+          const bool have = a + l16 < hi[u];
+          const uint64_t mine = (a == lo[u]) ? first[u] : (have ? dst[a + l16] : KEY_MAX);
+          uint32_t r = lo[u];
+#pragma unroll 1
+          for (uint32_t c = lo[u]; c < hi[u]; c += 16) {
+            const uint64_t other = (c == a) ? mine : (c == lo[u]) ? first[u] : ((c + l16 < hi[u]) ? dst[c + l16] : KEY_MAX);
+            r += (uint32_t)(other < mine);
+            const uint32_t olo = (uint32_t)other, ohi = (uint32_t)(other >> 32);
+            const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
+            uint32_t t;
+            asm volatile("s_nop 4\n" SS_ROTS(1) SS_ROTS(2) SS_ROTS(3) SS_ROTS(4) SS_ROTS(5) SS_ROTS(6) SS_ROTS(7)
+                         SS_ROTS(8) SS_ROTS(9) SS_ROTS(10) SS_ROTS(11) SS_ROTS(12) SS_ROTS(13) SS_ROTS(14) SS_ROTS(15)
+                         : "+v"(r), "=&v"(t)
+                         : "v"(olo), "v"(ohi), "v"(mlo), "v"(mhi)
+                         : "vcc");
+          }
+#ifndef SS_SKIP_EMIT
+          if (have && r < n_out) emit(r, mine);
+#else
+          if (have && r == 0xffffffffu) emit(0, mine);
+#endif
+        }
+      }
+    }
+#undef SS_ROTS
+  }
+#undef SS_T
+#undef SS_ADD
+}
+
 }  // namespace rq
