@@ -567,12 +567,12 @@ static int launch_encode(EncParams p, int num_cu, hipStream_t stream) {
   const size_t per_sub = ((size_t)p.NT * KS * 64 + (size_t)p.NT * 32) * sizeof(float);
   const size_t fixed_staged = (size_t)NWAVES * 2 * KS * XS_STRIDE * sizeof(float);
   const size_t budget = 160 * 1024;
-  if (per_sub + fixed_staged > budget)
-    return fail(RQ_EUNSUPPORTED, "one sub-codebook needs %zu B of LDS (> 160 KiB): h=%d ksteps=%d",
-                per_sub + fixed_staged, p.h, KS);
   // every sub-quantizer exactly 2*KS wide (and 8-byte aligned rows): the LDS-free-X fast path
   constexpr bool direct = DIRECT;
   const size_t fixed = direct ? 0 : fixed_staged;
+  if (per_sub + fixed > budget)
+    return fail(RQ_EUNSUPPORTED, "one sub-codebook needs %zu B of LDS (> 160 KiB): h=%d ksteps=%d",
+                per_sub + fixed, p.h, KS);
   const int gmax = (int)std::min<size_t>((budget - fixed) / per_sub, (size_t)p.m);
   void (*kern)(EncParams);
   if constexpr (DIRECT) kern = encode_pq_direct_kernel<KS, NT, NWAVES>;

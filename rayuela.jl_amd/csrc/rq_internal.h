@@ -38,7 +38,7 @@ int device_info(DeviceInfo *out);
 // Grow-only per-device scratch, owned by the library.  Calls on one device are expected to be
 // issued from one stream at a time (the host-pointer API serialises them itself).
 int workspace(int slot, size_t bytes, void **ptr);
-enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_PAD = 4, WS_SLOTS = 5 };
+enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_PAD = 4, WS_MERGE = 5, WS_SLOTS = 6 };
 
 // ---- ADC scan -------------------------------------------------------------------------------
 struct ScanPlan {

@@ -353,9 +353,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     uint32_t S = p.sample;
     uint32_t srank = 0;
     bool sampled = false;
-    if (S >= (uint32_t)SCAN_THREADS && p.K >= 8 && rows >= 8u * S && (uint64_t)rows >= 16ull * (uint64_t)p.K) {
+    if (S >= (uint32_t)SCAN_THREADS && p.K >= 8 && rows >= 32u * (uint32_t)SCAN_THREADS &&
+        (uint64_t)rows >= 16ull * (uint64_t)p.K) {
       const float q = (float)p.srank_mul * (float)p.K / (float)rows;      // target quantile (<= 1/8 * mul)
       uint32_t gsz = S / (uint32_t)SCAN_THREADS;
+      gsz = min(gsz, rows / (8u * (uint32_t)SCAN_THREADS));               // short slice: sample at most 1/8 of it
       if (q * (float)gsz > 0.7f) gsz = max(1u, (uint32_t)(0.7f / q));
       S = gsz * (uint32_t)SCAN_THREADS;
       const float frac = 1.0f - __expf((float)gsz * __logf(fmaxf(1.0f - q, 1e-6f)));
@@ -646,6 +648,39 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_topk_kernel(MergeParams p
   }
 }
 
+// Large K: the same merge as a sample sort over the P*K keys (no K-sized LDS array).  Persistent
+// 512-thread workgroups, each with P*K keys + P*K u16 of global scratch.
+__global__ __launch_bounds__(SCAN_THREADS) void merge_topk_big_kernel(MergeParams p, uint64_t *scratch, uint16_t *bkt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t cnt = p.P * (uint32_t)p.K, K = (uint32_t)p.K, tid = threadIdx.x;
+  uint64_t *dst = scratch + (size_t)blockIdx.x * cnt;
+  uint16_t *b = bkt + (size_t)blockIdx.x * cnt;
+  for (uint32_t q = blockIdx.x; q < p.nq; q += gridDim.x) {
+    const uint64_t *src = p.keys_in + (size_t)q * cnt;
+    uint64_t *ok = p.keys_out ? p.keys_out + (size_t)q * K : nullptr;
+    float *od = p.dists ? p.dists + (size_t)q * K : nullptr;
+    uint32_t *oi = p.ids ? p.ids + (size_t)q * K : nullptr;
+    const uint32_t id_base = (uint32_t)p.id_base;
+    auto emit = [ok, od, oi, id_base](uint32_t r, uint64_t key) {
+      if (ok) ok[r] = key;
+      if (od) od[r] = key_dist(key);
+      if (oi) oi[r] = key_id(key) + id_base;
+    };
+    const uint32_t got = samplesort_topk<SCAN_THREADS>(src, dst, b, cnt, K, smem, emit);
+    for (uint32_t i = got + tid; i < K; i += SCAN_THREADS) emit(i, KEY_MAX);   // fewer than K real keys
+  }
+}
+
+// P == 1: the list is already the answer, only unpack it
+__global__ void unpack_keys_kernel(MergeParams p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)p.nq * p.K) return;
+  const uint64_t key = p.keys_in[i];
+  if (p.keys_out) p.keys_out[i] = key;
+  if (p.dists) p.dists[i] = key_dist(key);
+  if (p.ids) p.ids[i] = key_id(key) + (uint32_t)p.id_base;
+}
+
 // Stand-alone LUT kernel (test aid, rq_dev_adc_lut): lut[q][k][r], one thread per (q,k,r).
 __global__ void adc_lut_kernel(float *lut, const float *centers, const float *queries, uint32_t nq,
                                int m, int sub) {
@@ -716,19 +751,6 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   pl.qg = Cfg::QG;
   pl.blk = Cfg::BLK;
   pl.ngroups = (uint32_t)((nq + Cfg::QG - 1) / Cfg::QG);
-  // row slices: enough work items to fill the chip, but slices long enough that the
-  // per-slice top-k overhead (~K(1+ln(rows/K)) survivors, one sort) stays small
-  int64_t min_rows = std::max<int64_t>(16384, 32LL * K);
-  min_rows = (min_rows + Cfg::BLK - 1) / Cfg::BLK * Cfg::BLK;
-  int64_t max_slices = std::max<int64_t>(1, n / min_rows);
-  int64_t want = (4LL * num_cu + pl.ngroups - 1) / pl.ngroups;
-  int64_t ns = std::min<int64_t>(std::max<int64_t>(1, want), max_slices);
-  if (force_slices > 0) ns = force_slices;
-  int64_t rps = (n + ns - 1) / ns;
-  rps = (rps + Cfg::BLK - 1) / Cfg::BLK * Cfg::BLK;
-  ns = (n + rps - 1) / rps;
-  pl.nslices = (uint32_t)ns;
-  pl.rows_per_slice = (uint32_t)rps;
   // slack between cuts: with the sampled tau about 2-3K rows survive a slice, so a slack of 4K means
   // "no cut before the end"; the exact fallback (tau from +inf) cuts every `slack` survivors.
   int slack_i = tuning("SCAN_SLACK", 0);
@@ -749,10 +771,25 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   if (pl.bigk) keys = std::max(base_keys, (size_t)(SS_LDS_BYTES + 7) / 8);
   keys = std::min(keys, lds_max / 8);
   pl.scratch_keys = (uint32_t)keys;
-  const uint64_t items = (uint64_t)pl.ngroups * pl.nslices;
   // workgroups per CU: as many as the LDS request admits (2 x 512 threads when it is <= 80 KiB)
   const size_t lds_req = CTRL_BYTES + std::max<size_t>(base_keys * 8, (size_t)pl.scratch_keys * 8);
   const int wgs = std::max(1, std::min<int>(SCAN_WGS_PER_CU, (int)(160 * 1024 / lds_req)));
+  // row slices: enough work items to fill the chip, but slices long enough that the
+  // per-slice top-k overhead (~K(1+ln(rows/K)) survivors, one sort) stays small
+  int64_t min_rows = std::max<int64_t>(16384, 32LL * K);
+  min_rows = (min_rows + Cfg::BLK - 1) / Cfg::BLK * Cfg::BLK;
+  int64_t max_slices = std::max<int64_t>(1, n / min_rows);
+  // one work item per resident workgroup when the batch has fewer query groups than that (measured:
+  // 125 groups -> 4 slices beat 2, 6 and 9); more groups than workgroups -> whole-base items
+  int64_t want = ((int64_t)num_cu * wgs) / pl.ngroups;
+  int64_t ns = std::min<int64_t>(std::max<int64_t>(1, want), max_slices);
+  if (force_slices > 0) ns = force_slices;
+  int64_t rps = (n + ns - 1) / ns;
+  rps = (rps + Cfg::BLK - 1) / Cfg::BLK * Cfg::BLK;
+  ns = (n + rps - 1) / rps;
+  pl.nslices = (uint32_t)ns;
+  pl.rows_per_slice = (uint32_t)rps;
+  const uint64_t items = (uint64_t)pl.ngroups * pl.nslices;
   pl.grid = (uint32_t)std::min<uint64_t>(items, (uint64_t)num_cu * wgs);
   pl.cand_bytes = (size_t)pl.grid * Cfg::QG * 2 * pl.cap * sizeof(uint64_t);
   pl.gtab_off = pl.cand_bytes;   // the L1-gathered LUT parts live behind the candidate buffers
@@ -824,6 +861,28 @@ int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t
   p.keys_in = keys_in; p.nq = (uint32_t)nq; p.P = (uint32_t)P; p.K = K; p.id_base = id_base;
   p.p2 = next_pow2((uint32_t)K);
   p.dists = dists; p.ids = ids; p.keys_out = keys_out;
+  if (P == 1) {
+    const size_t total = (size_t)nq * K;
+    hipLaunchKernelGGL(unpack_keys_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, p);
+    RQ_HIP(hipGetLastError());
+    return RQ_OK;
+  }
+  if (K > tuning("SCAN_SS_MIN_K", 1024)) {
+    int dev = 0, num_cu = 256;
+    RQ_HIP(hipGetDevice(&dev));
+    RQ_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    const uint32_t grid = (uint32_t)std::min<int64_t>(nq, 2LL * num_cu);
+    const size_t per_wg = (size_t)P * K;
+    void *ws = nullptr;
+    RQ_TRY(workspace(WS_MERGE, (size_t)grid * per_wg * (sizeof(uint64_t) + sizeof(uint16_t)) + 16, &ws));
+    uint64_t *scratch = (uint64_t *)ws;
+    uint16_t *bkt = (uint16_t *)(scratch + (size_t)grid * per_wg);
+    RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(merge_topk_big_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SS_LDS_BYTES));
+    hipLaunchKernelGGL(merge_topk_big_kernel, dim3(grid), dim3(SCAN_THREADS), SS_LDS_BYTES, stream, p, scratch, bkt);
+    RQ_HIP(hipGetLastError());
+    return RQ_OK;
+  }
   constexpr int CTRL_BYTES = (sizeof(MergeCtrl) + 15) & ~15;
   size_t lds = CTRL_BYTES + (size_t)p.p2 * 8;
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(merge_topk_kernel),

@@ -275,12 +275,14 @@ __host__ __device__ inline uint32_t next_pow2(uint32_t v) {
 // The result is exact for any input; a skewed sample only makes step 5 slower (O(bucket^2)).
 // src/dst: global, cnt keys each (dst is scratch); bkt: global scratch, cnt u16; lds:
 // SS_LDS_BYTES.  All arguments are uniform over the block; contains __syncthreads().
+// Keys equal to KEY_MAX are padding (short slices / shards): they are ignored, and the return
+// value is the number of keys emitted, min(n_out, #real keys) -- the caller pads the rest.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t SS_NS = 2048;
 constexpr uint32_t SS_LDS_BYTES = SS_NS * 8 + SS_NS * 4 + 128 + SS_NS * 8;
 
 template <int NT, class Emit>
-__device__ __forceinline__ void samplesort_topk(const uint64_t *src, uint64_t *dst, uint16_t *bkt, uint32_t cnt,
+__device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_t *dst, uint16_t *bkt, uint32_t cnt,
                                                 uint32_t n_out, unsigned char *lds, Emit emit,
                                                 unsigned long long *stats = nullptr) {
   // stats (optional): cycles of [9] sample sort, [10] bucket search, [11] scan + scatter (rank = rest)
@@ -299,15 +301,21 @@ __device__ __forceinline__ void samplesort_topk(const uint64_t *src, uint64_t *d
     // small input: the whole array is its own sample
     const uint32_t p2 = next_pow2(cnt);
     for (uint32_t i = tid; i < p2; i += NT) smp[i] = i < cnt ? src[i] : KEY_MAX;
+    if (tid == 0) aux[18] = 0;
     bitonic_sort_tiled(smp, p2, NT / 64, wave, lane, true);
+    for (uint32_t i = tid; i < cnt; i += NT)
+      if (smp[i] != KEY_MAX && (i + 1 == p2 || smp[i + 1] == KEY_MAX)) aux[18] = i + 1;   // #real keys
+    __syncthreads();
+    n_out = min(n_out, aux[18]);
     for (uint32_t i = tid; i < n_out; i += NT) emit(i, smp[i]);
-    return;
+    return n_out;
   }
   unsigned long long t_s = SS_T();
   for (uint32_t i = tid; i < NS; i += NT) {
     smp[i] = src[(uint32_t)(((uint64_t)i * cnt) >> 11)];
     nxt[i] = 0;
   }
+  if (tid == 0) { aux[16] = 0; aux[17] = 0; }
   bitonic_sort_tiled(smp, NS, NT / 64, wave, lane, true);
   // The 2047 splitters smp[0..2046] go into breadth-first (Eytzinger) order: a binary search over
   // the SORTED array reads, at depth t, addresses that are all congruent modulo 2^(11-t) keys --
@@ -344,8 +352,9 @@ __device__ __forceinline__ void samplesort_topk(const uint64_t *src, uint64_t *d
     for (int u = 0; u < 4; ++u) {
       const uint32_t idx = i0 + u * NT + tid;
       if (idx < cnt) {
-        atomicAdd(&nxt[b[u]], 1u);
-        bkt[idx] = (uint16_t)b[u];
+        const bool real = k[u] != KEY_MAX;
+        if (real) atomicAdd(&nxt[b[u]], 1u);
+        bkt[idx] = real ? (uint16_t)b[u] : (uint16_t)0xFFFFu;
       }
     }
   }
@@ -361,8 +370,12 @@ __device__ __forceinline__ void samplesort_topk(const uint64_t *src, uint64_t *d
     const uint32_t incl = wave_incl_scan(s, (int)lane);
     if (lane == 63) aux[wave] = incl;
     __syncthreads();
-    uint32_t run = incl - s;
-    for (uint32_t w = 0; w < wave; ++w) run += aux[w];
+    uint32_t run = incl - s, total = 0;
+    for (uint32_t w = 0; w < (uint32_t)(NT / 64); ++w) {
+      if (w < wave) run += aux[w];
+      total += aux[w];
+    }
+    n_out = min(n_out, total);   // #real keys
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const uint32_t end = run + c[j];
@@ -455,6 +468,7 @@ __device__ __forceinline__ void samplesort_topk(const uint64_t *src, uint64_t *d
   }
 #undef SS_T
 #undef SS_ADD
+  return n_out;
 }
 
 }  // namespace rq

@@ -139,6 +139,43 @@ def test_shard_merge_equals_single_scan(rq, oracle):
     assert _eq_bits(dists.cpu().numpy(), d0)
 
 
+@pytest.mark.parametrize("K", [1025, 3000, 10000])
+def test_large_k_sample_sort_paths(rq, oracle, K):
+    """K > 1024 finishes with the sample sort (select + sort in global memory): the single-slice
+    scan, the sliced scan + merge (slices shorter than K pad their lists with KEY_MAX) and the
+    shard merge all give the reference answer bit for bit."""
+    import torch
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import device as rqd
+    n, m, sub, nq = 45_000, 8, 16, 19
+    rng = np.random.default_rng(K)
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=K + 1)
+    codes[1000:1400] = codes[7]          # a run of identical rows: equal distances, ordered by id
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    for slices in (0, 1, 3, 8):          # 8 slices of 5625 rows: shorter than K = 10000
+        rq.set_tuning("SCAN_SLICES", slices)
+        try:
+            d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+        finally:
+            rq.set_tuning("SCAN_SLICES", 0)
+        assert np.array_equal(i0, i1), (K, slices)
+        assert _eq_bits(d0, d1), (K, slices)
+    cen, qs = torch.from_numpy(centers).cuda(), torch.from_numpy(queries).cuda()
+    bounds = [0, 20_000, 20_900, n]
+    keys = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        kk = min(K, b - a)
+        k_sh = rqd.linscan(torch.from_numpy(codes[a:b]).cuda(), cen, qs, kk, id_offset=a, want_keys=True)
+        if kk < K:
+            k_sh = torch.cat([k_sh, torch.full((nq, K - kk), -1, dtype=torch.int64, device="cuda")], dim=1)
+        keys.append(k_sh)
+    dists, ids = rqd.merge_topk(torch.stack(keys, dim=1).contiguous(), K)
+    assert np.array_equal(ids.cpu().numpy().view(np.uint32), i0)
+    assert _eq_bits(dists.cpu().numpy(), d0)
+
+
 def test_sharded_index_single_rank_uses_hip_kernels(rq, oracle):
     """ShardedIndex with its default (HIP) scan/merge functions, world size 1: keys out of the scan,
     through rq_dev_merge_topk, equal the direct answer."""
