@@ -82,6 +82,21 @@ int rq_dev_linscan_aq(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t
                       int64_t nq, int m, int d, int k, int lut_mode, uint32_t id_offset, int id_base,
                       void *stream);
 
+/* ---- quantize_rvq (src/RVQ.jl:18-66) -----------------------------------------
+ * m full-dimensional stages on the running residual: stage i = pairwise SqEuclidean + first-index
+ * argmin against C[i] (d x h in Julia = [h][d] here; codebooks = the m matrices back to back), then
+ * Xr .-= C[i][:, B[i]] (:56).  d <= 128 (d even).  codes [n][m] uint8 zero-based / Int16 one-based m x n
+ * (:60-62).  counts [m][h] (may be NULL) = update_assignments!'s per-centre counts (:43-47): a zero marks
+ * an `unused` centre, for which the reference re-picks a singleton with Julia's RNG (:50-53) -- that
+ * random re-pick stays on the caller's side.  Xr_out [n][d] (may be NULL) receives the final residual. */
+int rq_encode_rvq(uint8_t *codes, const float *X, const float *codebooks, int64_t n, int d, int m, int h,
+                  uint32_t *counts, float *Xr_out);
+int rq_encode_rvq_i16(int16_t *codes1, const float *X, const float *codebooks, int64_t n, int d, int m, int h,
+                      uint32_t *counts, float *Xr_out);
+/* device-pointer form: Xr [n][d] holds X on entry and the final residual on return */
+int rq_dev_encode_rvq(uint8_t *codes, float *Xr, const float *codebooks, int64_t n, int d, int m, int h,
+                      uint32_t *counts, void *stream);
+
 /* ---- host-pointer entry points (what the julia/ shims ccall) ---------------------------------- */
 /* linscan_pq (src/Linscan.jl:5-26).  id_base = 1 folds Julia's `res .+= 1` into the kernel. */
 int rq_linscan_pq(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers,

@@ -5,6 +5,7 @@
 #   quantize_pq   src/PQ.jl:18-48        quantize_opq  src/OPQ.jl:19-27
 #   linscan_pq    src/Linscan.jl:5-37    linscan_opq   src/Linscan.jl:93-115
 #   linscan_lsq   src/Linscan.jl:118-157 linscan_cq    src/Linscan.jl:160-193   (SURVEY 8f rank 2)
+#   quantize_rvq  src/RVQ.jl:18-66                                              (SURVEY 8f rank 3)
 # Julia's column-major arrays are passed as they are: a d-by-n Matrix{Float32} is the C array
 # [n][d] the library expects, an m-by-n Matrix{UInt8} is [n][m], k-by-nq outputs are [nq][k].
 #
@@ -12,7 +13,7 @@
 # C ABI is exercised through ctypes by tests/ (rayuela.jl_amd/*.py mirrors this file line by line).
 module RayuelaHIP
 
-export quantize_pq, quantize_opq, linscan_pq, linscan_opq, linscan_lsq, linscan_cq, train_pq, train_opq
+export quantize_pq, quantize_opq, quantize_rvq, linscan_pq, linscan_opq, linscan_lsq, linscan_cq, train_pq, train_opq
 
 # deps/build.jl:64-67 writes the library paths into deps/deps.jl; here one constant / env var.
 const librayuela_hip = get(ENV, "RAYUELA_HIP_LIB",
@@ -58,6 +59,41 @@ function quantize_opq(X::Matrix{Float32}, R::Matrix{Float32}, C::Vector{Matrix{F
     (Ptr{Int16}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cint, Cint, Cint),
     B, X, R, _cat_codebooks(C), Int64(n), Cint(d), Cint(m), Cint(h)))
   return B
+end
+
+"""
+    quantize_rvq(X, C, V=false) -> B, singletons     (src/RVQ.jl:18-66)
+`B::Matrix{Int16}` m-by-n one-based; `singletons[i]` holds re-picked entries for the unused centres of
+codebook i.  The m encode stages and residual updates run on the device; the library returns the
+per-centre counts, and only when some are zero is the reference's own randomised re-pick
+(`Clustering.repick_unused_centers`, :50-53; needs `using Clustering, Distances` like src/Rayuela.jl)
+replayed here on the residual of that stage.
+"""
+function quantize_rvq(X::Matrix{Float32}, C::Vector{Matrix{Float32}}, V::Bool=false)
+  d, n = size(X)
+  m    = length(C)
+  h    = size(C[1], 2)
+  B      = Matrix{Int16}(undef, m, n)
+  counts = Matrix{UInt32}(undef, h, m)          # C view [m][h]
+  _check(ccall((:rq_encode_rvq_i16, librayuela_hip), Cint,
+    (Ptr{Int16}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cint, Cint, Cint, Ptr{UInt32}, Ptr{Cfloat}),
+    B, X, hcat(C...), Int64(n), Cint(d), Cint(m), Cint(h), counts, C_NULL))
+  singletons = Vector{Matrix{Float32}}(undef, m)
+  if any(counts .== 0)
+    Xr = copy(X)
+    for i = 1:m
+      unused = findall(counts[:, i] .== 0)
+      picked = C[i][:, B[i, :]]
+      if !isempty(unused)
+        costs = vec(sum((Xr .- picked) .^ 2, dims=1))
+        temp_codebook = similar(C[i])
+        Clustering.repick_unused_centers(Xr, costs, temp_codebook, unused, Distances.SqEuclidean())
+        singletons[i] = temp_codebook[:, unused]
+      end
+      Xr .-= picked
+    end
+  end
+  return B, singletons
 end
 
 """

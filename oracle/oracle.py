@@ -58,6 +58,8 @@ def lib():
         _LIB.oracle_encode_opq.restype = None
         _LIB.oracle_encode_opq.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int64, C.c_int, C.c_int, C.c_int]
+        _LIB.oracle_encode_rvq.restype = None
+        _LIB.oracle_encode_rvq.argtypes = [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_int]
         _LIB.oracle_splitarray.restype = None
         _LIB.oracle_splitarray.argtypes = [C.c_int, C.c_int, C.c_void_p]
         _LIB.oracle_num_threads.restype = C.c_int
@@ -241,6 +243,21 @@ def encode_opq(X, R, C_cat, m, h):
     codes = np.zeros((n, m), dtype=np.uint8)
     lib().oracle_encode_opq(_ptr(codes), _ptr(X), _ptr(R), _ptr(Cc), n, d, m, h)
     return codes
+
+
+def encode_rvq(X, C, with_extras=False):
+    """src/RVQ.jl:18-66.  C [m][h][d] full-dimensional codebooks; codes [n][m] u8 zero-based.
+    with_extras -> (codes, counts [m][h], final residual [n][d])."""
+    X = _c(X, np.float32)
+    C = _c(C, np.float32)
+    n, d = X.shape
+    m, h, d2 = C.shape
+    assert d2 == d
+    codes = np.zeros((n, m), dtype=np.uint8)
+    counts = np.zeros((m, h), dtype=np.uint32)
+    Xr = np.zeros((n, d), dtype=np.float32)
+    lib().oracle_encode_rvq(_ptr(codes), _ptr(counts), _ptr(Xr), _ptr(X), _ptr(C), n, d, m, h)
+    return (codes, counts, Xr) if with_extras else codes
 
 
 def eval_recall(ids_gnd, ids_predicted, k):

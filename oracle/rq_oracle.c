@@ -336,6 +336,37 @@ void oracle_encode_opq(uint8_t *codes, const float *X, const float *R, const flo
   free(RX);
 }
 
+/* ------------------------------------------------------------------------- */
+/* src/RVQ.jl:18-66  quantize_rvq(X, C): for i = 1..m                           */
+/*   dmat = pairwise(SqEuclidean(), C[i], Xr)  (:37)  -- full-dimensional, so   */
+/*   the same GEMM-trick distance + strict-'<' argmin as quantize_pq with ONE   */
+/*   sub-quantizer of width d (same canonical fmaf chains, PARITY UNPINNED like */
+/*   oracle_encode_pq);  Xr .-= C[i][:, B[i]]  (:56), a plain f32 subtraction.  */
+/* C [m][h][d]; codes [n][m] zero-based; counts [m][h] (optional) = :43-47      */
+/* `counts`; Xr_out [n][d] (optional) = the final residual.                     */
+/* ------------------------------------------------------------------------- */
+void oracle_encode_rvq(uint8_t *codes, uint32_t *counts, float *Xr_out, const float *X, const float *C,
+                       int64_t n, int d, int m, int h) {
+  float *Xr = (float *)malloc(sizeof(float) * (size_t)n * d);
+  uint8_t *stage = (uint8_t *)malloc((size_t)n);
+  memcpy(Xr, X, sizeof(float) * (size_t)n * d);
+  if (counts) memset(counts, 0, sizeof(uint32_t) * (size_t)m * h);
+  for (int i = 0; i < m; i++) {
+    const float *Ci = C + (size_t)i * h * d;
+    oracle_encode_pq(stage, NULL, Xr, Ci, n, d, 1, h);
+    for (int64_t j = 0; j < n; j++) {
+      const float *c = Ci + (size_t)stage[j] * d;
+      float *x = Xr + (size_t)j * d;
+      for (int s = 0; s < d; s++) x[s] = x[s] - c[s];
+      codes[(size_t)j * m + i] = stage[j];
+      if (counts) counts[(size_t)i * h + stage[j]]++;
+    }
+  }
+  if (Xr_out) memcpy(Xr_out, Xr, sizeof(float) * (size_t)n * d);
+  free(stage);
+  free(Xr);
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -10,6 +10,7 @@ from .utils import splitarray, cat_codebooks  # noqa: F401
 from .xvecs import fvecs_read, ivecs_read, bvecs_read, fvecs_write, ivecs_write  # noqa: F401
 from .PQ import quantize_pq, quantize_pq_u8  # noqa: F401
 from .OPQ import quantize_opq, rotate  # noqa: F401
+from .RVQ import quantize_rvq, quantize_rvq_u8  # noqa: F401
 
 
 from .PQ import train_pq  # noqa: F401,E402

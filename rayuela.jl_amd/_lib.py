@@ -38,6 +38,9 @@ SIGNATURES = {
     "rq_encode_opq": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32]),
     "rq_encode_pq_i16": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32]),
     "rq_encode_opq_i16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32]),
+    "rq_encode_rvq": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "rq_encode_rvq_i16": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "rq_dev_encode_rvq": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "rq_rotate_T": (_i32, [_vp, _vp, _vp, _i32, _i64]),
     "rq_dev_encode_pq": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rq_dev_rotate_T": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp]),

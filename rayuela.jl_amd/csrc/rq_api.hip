@@ -8,6 +8,7 @@
 #include <mutex>
 #include <string>
 
+#include <vector>
 #include "rq_internal.h"
 
 namespace rq {
@@ -467,6 +468,73 @@ int rq_dev_encode_opq(uint8_t *codes, const float *X, const float *R, const floa
   RQ_TRY(workspace(WS_TMP, (size_t)n * d * 4, &tmp));
   RQ_TRY(rotate_launch((float *)tmp, R, X, d, n, di.num_cu, (hipStream_t)stream));
   return encode_launch(codes, (const float *)tmp, C, n, d, m, h, di.num_cu, (hipStream_t)stream);
+}
+
+int rq_dev_encode_rvq(uint8_t *codes, float *Xr, const float *codebooks, int64_t n, int d, int m, int h,
+                      uint32_t *counts, void *stream) {
+  if (n <= 0) return RQ_OK;
+  if (d < 1 || m < 1 || h < 1 || h > 256) return fail(RQ_EINVAL, "rvq: bad shape d=%d m=%d h=%d", d, m, h);
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  void *tmp = nullptr;
+  RQ_TRY(workspace(WS_TMP, (size_t)n, &tmp));
+  return rvq_encode_launch(codes, Xr, (uint8_t *)tmp, counts, codebooks, n, d, m, h, di.num_cu, (hipStream_t)stream);
+}
+
+static int host_encode_rvq(uint8_t *codes, int16_t *codes1, const float *X, const float *C, int64_t n, int d, int m,
+                           int h, uint32_t *counts, float *Xr_out) {
+  Timer tt;
+  g_t_h2d = g_t_kernel = g_t_d2h = 0;
+  if (counts) memset(counts, 0, (size_t)m * h * sizeof(uint32_t));
+  if (n <= 0) return RQ_OK;
+  if (d < 1 || m < 1 || h < 1 || h > 256) return fail(RQ_EINVAL, "rvq: bad shape d=%d m=%d h=%d", d, m, h);
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (1LL << 30) / ((int64_t)d * 4)));
+  DevBuf dX, dC, dcodes, dstage, d16, dcnt;
+  RQ_TRY(dX.alloc((size_t)chunk * d * 4));
+  RQ_TRY(dC.alloc((size_t)m * h * d * 4));
+  RQ_TRY(dcodes.alloc((size_t)chunk * m));
+  RQ_TRY(dstage.alloc((size_t)chunk));
+  RQ_TRY(dcnt.alloc((size_t)m * h * 4));
+  if (codes1) RQ_TRY(d16.alloc((size_t)chunk * m * 2));
+  RQ_HIP(hipMemcpy(dC.p, C, (size_t)m * h * d * 4, hipMemcpyHostToDevice));
+  std::vector<uint32_t> part(counts ? (size_t)m * h : 0);
+  for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+    const int64_t nr = std::min(chunk, n - r0);
+    Timer t1;
+    RQ_HIP(hipMemcpy(dX.p, X + (size_t)r0 * d, (size_t)nr * d * 4, hipMemcpyHostToDevice));
+    g_t_h2d += t1.ms();
+    Timer t2;
+    RQ_TRY(rvq_encode_launch(dcodes.as<uint8_t>(), dX.as<float>(), dstage.as<uint8_t>(),
+                             counts ? dcnt.as<unsigned int>() : nullptr, dC.as<float>(), nr, d, m, h, di.num_cu,
+                             nullptr));
+    if (codes1) RQ_TRY(widen_codes_launch(d16.as<int16_t>(), dcodes.as<uint8_t>(), nr * m, nullptr));
+    RQ_HIP(hipDeviceSynchronize());
+    g_t_kernel += t2.ms();
+    Timer t3;
+    if (codes1)
+      RQ_HIP(hipMemcpy(codes1 + (size_t)r0 * m, d16.p, (size_t)nr * m * 2, hipMemcpyDeviceToHost));
+    else
+      RQ_HIP(hipMemcpy(codes + (size_t)r0 * m, dcodes.p, (size_t)nr * m, hipMemcpyDeviceToHost));
+    if (Xr_out) RQ_HIP(hipMemcpy(Xr_out + (size_t)r0 * d, dX.p, (size_t)nr * d * 4, hipMemcpyDeviceToHost));
+    if (counts) {
+      RQ_HIP(hipMemcpy(part.data(), dcnt.p, part.size() * 4, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < part.size(); ++i) counts[i] += part[i];
+    }
+    g_t_d2h += t3.ms();
+  }
+  g_t_total = tt.ms();
+  return RQ_OK;
+}
+
+int rq_encode_rvq(uint8_t *codes, const float *X, const float *codebooks, int64_t n, int d, int m, int h,
+                  uint32_t *counts, float *Xr_out) {
+  return host_encode_rvq(codes, nullptr, X, codebooks, n, d, m, h, counts, Xr_out);
+}
+int rq_encode_rvq_i16(int16_t *codes1, const float *X, const float *codebooks, int64_t n, int d, int m, int h,
+                      uint32_t *counts, float *Xr_out) {
+  return host_encode_rvq(nullptr, codes1, X, codebooks, n, d, m, h, counts, Xr_out);
 }
 
 int rq_dev_adc_lut(float *lut, const float *centers, const float *queries, int64_t nq, int m, int subdim,

@@ -331,7 +331,10 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_direct_kernel(EncParams
 #pragma unroll
     for (int u = 0; u < KS; ++u) xn[u] = src[u];
   };
-  if (tile0 < ntiles) gload(tile0, 0);
+  // the next sub-vector is prefetched during the MFMAs, except for full-dimensional sub-spaces
+  // (KS = 64: the prefetch alone would be 128 registers; two wavefronts per SIMD cover the load)
+  constexpr bool PF = KS < 64;
+  if (PF && tile0 < ntiles) gload(tile0, 0);
 
   for (int64_t tile = tile0; tile < ntiles; tile += total_waves) {
     const int64_t row0 = tile * 32;
@@ -339,6 +342,7 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_direct_kernel(EncParams
 #pragma unroll 1
     for (int il = 0; il < mg; ++il) {
       const int i = i0 + il;
+      if constexpr (!PF) gload(tile, il);
       float b[KS];
       float sb = 0.0f;
 #pragma unroll
@@ -348,8 +352,10 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_direct_kernel(EncParams
         sb = __builtin_fmaf(v.x, v.x, sb);     // chain s = 0..sub-1 in order
         sb = __builtin_fmaf(v.y, v.y, sb);
       }
-      if (il + 1 < mg) gload(tile, il + 1);
-      else if (tile + total_waves < ntiles) gload(tile + total_waves, 0);
+      if constexpr (PF) {
+        if (il + 1 < mg) gload(tile, il + 1);
+        else if (tile + total_waves < ntiles) gload(tile + total_waves, 0);
+      }
       ArgminState st;
       st.best_v = __uint_as_float(0x7f800000u);
       st.best_t = 0;
@@ -637,9 +643,21 @@ int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int
   RQ_ENC_CASE(8)
   RQ_ENC_CASE(16)
   RQ_ENC_CASE(32)
+  // wide sub-spaces (RVQ stages are full-dimensional: sub = d = 96 / 128): 8 wavefronts, X in registers;
+  // the LDS-staged fallback runs 4 wavefronts and only fits while codebook + staging <= 160 KiB
+#define RQ_ENC_CASE_WIDE(KSV)                                              \
+  if (ks <= KSV) {                                                         \
+    const bool direct = tuning("ENC_DIRECT", 1) && (d % m == 0) && (d / m == 2 * KSV) && \
+                        (((uintptr_t)X & 7) == 0);                         \
+    if (direct) RQ_ENC_NT(KSV, 8, true);                                    \
+    RQ_ENC_NT(KSV, 4, false);                                               \
+  }
+  RQ_ENC_CASE_WIDE(48)
+  RQ_ENC_CASE_WIDE(64)
+#undef RQ_ENC_CASE_WIDE
 #undef RQ_ENC_NT
 #undef RQ_ENC_CASE
-  return fail(RQ_EUNSUPPORTED, "sub-space dimension %d > 64 not covered by the encode kernels", maxsub);
+  return fail(RQ_EUNSUPPORTED, "sub-space dimension %d > 128 not covered by the encode kernels", maxsub);
 }
 
 int rotate_launch(float *RX, const float *R, const float *X, int d, int64_t n, int num_cu,
@@ -668,6 +686,68 @@ int rotate_launch(float *RX, const float *R, const float *X, int d, int64_t n, i
   const int grid = (int)std::min<int64_t>(num_cu, (ntiles + NW - 1) / NW);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, p);
   RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+// RVQ stage epilogue (src/RVQ.jl:56  Xr .-= C[i][:, B[i]]): Xr[j][:] -= C_i[code_j][:], the stage's
+// codes go to column `stage` of the [n][m] code matrix, and the per-centre counts of the stage
+// (update_assignments!'s `counts`, src/RVQ.jl:43-47) are accumulated.  One thread per float4 of Xr.
+__global__ __launch_bounds__(256) void rvq_residual_kernel(float *Xr, const float *Ci, const uint8_t *stage_codes,
+                                                           uint8_t *codes, unsigned int *counts, int64_t n, int d,
+                                                           int m, int stage) {
+  const int d4 = d >> 2;   // d % 4 == 0 on this path
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * d4) return;
+  const int64_t j = e / d4;
+  const int c4 = (int)(e - j * d4);
+  const int code = stage_codes[j];
+  float4 x = reinterpret_cast<float4 *>(Xr)[e];
+  const float4 c = reinterpret_cast<const float4 *>(Ci)[(size_t)code * d4 + c4];
+  x.x = x.x - c.x; x.y = x.y - c.y; x.z = x.z - c.z; x.w = x.w - c.w;
+  reinterpret_cast<float4 *>(Xr)[e] = x;
+  if (c4 == 0) {
+    codes[j * m + stage] = (uint8_t)code;
+    if (counts) atomicAdd(&counts[code], 1u);
+  }
+}
+
+__global__ __launch_bounds__(256) void rvq_residual_scalar_kernel(float *Xr, const float *Ci, const uint8_t *stage_codes,
+                                                                  uint8_t *codes, unsigned int *counts, int64_t n,
+                                                                  int d, int m, int stage) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * d) return;
+  const int64_t j = e / d;
+  const int c = (int)(e - j * d);
+  const int code = stage_codes[j];
+  Xr[e] = Xr[e] - Ci[(size_t)code * d + c];
+  if (c == 0) {
+    codes[j * m + stage] = (uint8_t)code;
+    if (counts) atomicAdd(&counts[code], 1u);
+  }
+}
+
+// quantize_rvq (src/RVQ.jl:18-66) on resident data: m full-dimensional stages, each the encode kernel
+// with one sub-quantizer of width d on the running residual.  Xr [n][d] is overwritten (in: X or a copy
+// of it, out: the final residual); stage_codes is n bytes of scratch; counts is [m][h] or NULL.
+int rvq_encode_launch(uint8_t *codes, float *Xr, uint8_t *stage_codes, unsigned int *counts, const float *C,
+                      int64_t n, int d, int m, int h, int num_cu, hipStream_t stream) {
+  if (n <= 0) return RQ_OK;
+  if (counts) RQ_HIP(hipMemsetAsync(counts, 0, (size_t)m * h * sizeof(unsigned int), stream));
+  for (int i = 0; i < m; ++i) {
+    const float *Ci = C + (size_t)i * h * d;
+    RQ_TRY(encode_launch(stage_codes, Xr, Ci, n, d, 1, h, num_cu, stream));
+    unsigned int *cnt = counts ? counts + (size_t)i * h : nullptr;
+    if ((d & 3) == 0 && (((uintptr_t)Xr | (uintptr_t)Ci) & 15) == 0) {
+      const int64_t total = n * (d >> 2);
+      hipLaunchKernelGGL(rvq_residual_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, Xr, Ci,
+                         stage_codes, codes, cnt, n, d, m, i);
+    } else {
+      const int64_t total = n * d;
+      hipLaunchKernelGGL(rvq_residual_scalar_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, Xr,
+                         Ci, stage_codes, codes, cnt, n, d, m, i);
+    }
+    RQ_HIP(hipGetLastError());
+  }
   return RQ_OK;
 }
 

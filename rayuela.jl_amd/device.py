@@ -42,6 +42,19 @@ def encode_opq(X, R, Ccat, m, h, out=None):
     return out
 
 
+def encode_rvq(Xr, C, out=None, want_counts=False):
+    """quantize_rvq on resident tensors.  Xr (n, d) holds X and is OVERWRITTEN with the final residual;
+    C (m, h, d).  Returns codes (n, m) uint8 [, counts (m, h) int32]."""
+    n, d = Xr.shape
+    m, h, _ = C.shape
+    out = torch.empty((n, m), dtype=torch.uint8, device=Xr.device) if out is None else out
+    counts = torch.zeros((m, h), dtype=torch.int32, device=Xr.device) if want_counts else None
+    _lib.check(_lib.lib().rq_dev_encode_rvq(_chk(out, torch.uint8, "codes"), _chk(Xr, torch.float32, "Xr"),
+                                            _chk(C, torch.float32, "C"), n, d, m, h,
+                                            None if counts is None else counts.data_ptr(), _stream()))
+    return (out, counts) if want_counts else out
+
+
 def adc_lut(centers, queries):
     m, h, sub = centers.shape
     nq = queries.shape[0]

@@ -102,6 +102,23 @@ def codebooks(X, m, h=256, seed=SEED_CODEBOOK, iters=5, sample=20000):
     return out
 
 
+def rvq_codebooks(X, m, h=256, seed=SEED_CODEBOOK, iters=3, sample=4096):
+    """m residual codebooks [m][h][d] f32: stage i = a few Lloyd iterations on the residual of a sample
+    (float64 brute force; a stand-in for train_rvq, src/RVQ.jl:86-127, good enough to give every stage
+    a sensible scale)."""
+    n, d = X.shape
+    idx = (splitmix64(_counter(min(sample, n)) ^ np.uint64(seed * 7919)) % np.uint64(n)).astype(np.int64)
+    Xr = X[idx].astype(np.float32).copy()
+    out = np.empty((m, h, d), dtype=np.float32)
+    for i in range(m):
+        Ci = codebooks(Xr, 1, h, seed=seed + 1000 * (i + 1), iters=iters, sample=Xr.shape[0])[0]
+        out[i] = Ci
+        S = Xr.astype(np.float64)
+        d2 = (S * S).sum(1)[:, None] - 2.0 * S @ Ci.T.astype(np.float64) + (Ci.astype(np.float64) ** 2).sum(1)[None, :]
+        Xr = Xr - Ci[d2.argmin(1)]
+    return out
+
+
 def rotation(d, seed=SEED_ROTATION):
     A = (splitmix64(_counter(d * d) ^ np.uint64(seed * 31337)) >> np.uint64(11)).astype(np.float64)
     A = A / float(1 << 53) - 0.5

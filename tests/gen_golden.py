@@ -124,6 +124,29 @@ def encode_case(name, n, d, m, h, kind, with_R):
     print(name, X.shape, "f32-vs-f64 code flips:", int((codes != c64).sum()))
 
 
+def rvq_case(name, n, d, m, h, kind):
+    """quantize_rvq (src/RVQ.jl:18-66): canonical f32 codes/counts/residual of the oracle (PARITY UNPINNED
+    like the PQ encode) + a float64 replay (codes64 follow the f32 path's residual; gap64 = f64 top-2 gap)."""
+    X = synth.sift_like(n + 2048, d, seed=51) if kind == "sift" else synth.deep_like(n + 2048, d, seed=52)
+    C = synth.rvq_codebooks(X, m, h, seed=53)
+    X = X[:n].copy()
+    X[3] = C[0][5]                       # exact hit in stage 1: distance clamps to 0
+    codes, counts, Xr = oracle.encode_rvq(X, C, with_extras=True)
+    R = X.copy()
+    c64 = np.zeros_like(codes)
+    gap = np.zeros(codes.shape, dtype=np.float32)
+    for i in range(m):
+        d2 = ((R[:, None, :].astype(np.float64) - C[i][None].astype(np.float64)) ** 2).sum(-1)
+        c64[:, i] = d2.argmin(1)
+        part = np.partition(d2, 1, axis=1)
+        gap[:, i] = (part[:, 1] - part[:, 0]).astype(np.float32)
+        R = R - C[i][codes[:, i]]
+    assert np.array_equal(R.view(np.uint32), Xr.view(np.uint32))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), X=X, C=C, codes=codes, counts=counts, Xr=Xr,
+                        codes64=c64, gap64=gap)
+    print(name, X.shape, "f32-vs-f64 code flips:", int((codes != c64).sum()), "unused:", int((counts == 0).sum()))
+
+
 def recall_case():
     """src/Linscan.jl:196-234 evaluated with explicit loops (1-based ids like the Julia caller)."""
     k, nq = 10, 6
@@ -149,8 +172,13 @@ def recall_case():
 
 
 if __name__ == "__main__":
-    assert oracle.ref_available(), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) < 2 or sys.argv[1] == "rvq":
+        rvq_case("rvq_sift_mini", 600, 128, 4, 256, "sift")
+        rvq_case("rvq_deep_mini", 500, 96, 3, 100, "deep")
+        if len(sys.argv) >= 2:
+            sys.exit(0)
+    assert oracle.ref_available(), "build oracle/_ref first: make -C oracle ref"
     scan_case("scan_sift_mini", 4096, 8, 16, 16, [1, 10, 100, 1000], "sift")
     scan_case("scan_deep_mini", 4096, 16, 6, 8, [1, 10, 100], "deep")
     scan_case("scan_all_ties", 3000, 8, 4, 4, [1, 17, 1000], "ties")
