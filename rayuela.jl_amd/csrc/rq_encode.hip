@@ -394,6 +394,145 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_direct_kernel(EncParams
 }
 
 // ------------------------------------------------------------------------------------------
+// Wide sub-spaces (sub > 64 that are not exactly 96 / 128 wide, or whose codebook does not fit LDS:
+// PQ on GIST-960, RVQ / k-means assignment at any d).  The sub-space is cut into chunks of KC
+// k-steps (32, or 16 at NT = 8 to stay inside 256 registers); a codebook chunk (32 KiB at h = 256) is staged
+// into one half of a double-buffered LDS area while the MFMAs of the previous chunk run, and every
+// wavefront keeps the NT accumulator tiles of its 32 vectors across the chunks -- the MFMA chain of a
+// (centroid, vector) pair is still s = 0..sub-1 in order, i.e. the oracle's fmaf chain.
+// ------------------------------------------------------------------------------------------
+template <int NT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void encode_wide_kernel(EncParams p) {
+  constexpr int KC = NT >= 8 ? 16 : 32;
+  constexpr int CHUNK = NT * KC * 64;                  // floats per staged codebook chunk
+  constexpr int PER = CHUNK / (NWAVES * 64);           // ... per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *cb0 = reinterpret_cast<float *>(smem);       // [2][CHUNK]
+  float *saL = cb0 + 2 * CHUNK;                         // [m][NT*32], C/D-fragment order
+  const int m = p.m, h = p.h, d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+
+  for (int idx = tid; idx < m * NT * 32; idx += NWAVES * 64) {
+    const int c32 = idx & 31;
+    const int t = (idx >> 5) % NT;
+    const int i = (idx >> 5) / NT;
+    const int sub = p.off[i + 1] - p.off[i];
+    const int cen = t * 32 + c32;
+    float sa = __uint_as_float(0x7f800000u);
+    if (cen < h) {
+      const float *c = p.C + (size_t)h * p.off[i] + (size_t)cen * sub;
+      sa = 0.0f;
+      for (int s = 0; s < sub; ++s) sa = __builtin_fmaf(c[s], c[s], sa);
+    }
+    const int hh = (c32 >> 2) & 1;
+    const int r = (c32 & 3) + 4 * (c32 >> 3);
+    saL[((size_t)(i * NT + t) * 2 + hh) * 16 + r] = sa;
+  }
+
+  // element `e` of a staged chunk -> (tile t, k-step kk, lane l): centroid t*32 + (l & 31), dimension 2kk + (l >> 5)
+  auto cb_load = [&](int i, int c, int e) -> float {
+    const int l = e & 63;
+    const int kk = (e >> 6) % KC;
+    const int t = (e >> 6) / KC;
+    const int sub = p.off[i + 1] - p.off[i];
+    const int cen = t * 32 + (l & 31);
+    const int s = c * 2 * KC + 2 * kk + (l >> 5);
+    return (cen < h && s < sub) ? p.C[(size_t)h * p.off[i] + (size_t)cen * sub + s] : 0.0f;
+  };
+
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t ngroups = (ntiles + NWAVES - 1) / NWAVES;
+  for (int64_t tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+    const int64_t tile = tg * NWAVES + wave;
+    const int64_t row0 = tile * 32;
+    int64_t gr = row0 + j;
+    if (gr >= p.n) gr = p.n - 1;                        // idle lanes / waves repeat the last row
+    const float *xrow = p.X + gr * d;
+#pragma unroll 1
+    for (int i = 0; i < m; ++i) {
+      const int sub = p.off[i + 1] - p.off[i];
+      const int nchunks = (sub + 2 * KC - 1) / (2 * KC);
+      const float *xs = xrow + p.off[i];
+      f32x16 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+      float sb = 0.0f;
+      __syncthreads();                                  // the previous user of buffer 0 is done
+#pragma unroll
+      for (int u = 0; u < PER; ++u) cb0[tid + u * NWAVES * 64] = cb_load(i, 0, tid + u * NWAVES * 64);
+      __syncthreads();
+#pragma unroll 1
+      for (int c = 0; c < nchunks; ++c) {
+        const float *cb = cb0 + (size_t)(c & 1) * CHUNK + lane;
+        float nxt[PER];
+        const bool more = c + 1 < nchunks;
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < PER; ++u) nxt[u] = cb_load(i, c + 1, tid + u * NWAVES * 64);
+        }
+        float b[KC];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+          const int s0 = c * 2 * KC + 2 * kk;
+          const float x0 = s0 < sub ? xs[s0] : 0.0f;
+          const float x1 = s0 + 1 < sub ? xs[s0 + 1] : 0.0f;
+          b[kk] = hi ? x1 : x0;
+          sb = __builtin_fmaf(x0, x0, sb);               // zero padding leaves the chain untouched
+          sb = __builtin_fmaf(x1, x1, sb);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+          for (int kk = 0; kk < KC; ++kk)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[(t * KC + kk) * 64], b[kk], acc[t], 0, 0, 0);
+        }
+        if (more) {
+          float *dstb = cb0 + (size_t)((c + 1) & 1) * CHUNK;
+#pragma unroll
+          for (int u = 0; u < PER; ++u) dstb[tid + u * NWAVES * 64] = nxt[u];
+        }
+        __syncthreads();
+      }
+      ArgminState st;
+      st.best_v = __uint_as_float(0x7f800000u);
+      st.best_t = 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) st.ub[r] = f32x2{0.0f, 0.0f};
+      const float4 *sa_i = reinterpret_cast<const float4 *>(saL + ((size_t)i * NT * 2 + hi) * 16);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) tile_argmin(acc[t], sa_i + (size_t)t * 8, sb, t, st);
+      float best_v = st.best_v;
+      int best_i = argmin_finish(st, hi);
+      const float ov = __shfl_xor(best_v, 32);
+      const int oi = __shfl_xor(best_i, 32);
+      if (ov < best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+      if (hi == 0 && row0 + j < p.n) p.codes[(size_t)(row0 + j) * m + i] = (uint8_t)best_i;
+    }
+  }
+}
+
+template <int NT>
+static int launch_encode_wide(EncParams p, int num_cu, hipStream_t stream) {
+  constexpr int NW = 8;
+  p.NT = NT;
+  constexpr int KC = NT >= 8 ? 16 : 32;
+  const size_t lds = (size_t)2 * NT * KC * 64 * sizeof(float) + (size_t)p.m * NT * 32 * sizeof(float);
+  if (lds > 160 * 1024)
+    return fail(RQ_EUNSUPPORTED, "wide encode: m=%d sub-quantizers of h=%d need %zu B of LDS", p.m, p.h, lds);
+  auto kern = encode_wide_kernel<NT, NW>;
+  RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)lds));
+  const int64_t ngroups = ((p.n + 31) / 32 + NW - 1) / NW;
+  const int grid = (int)std::min<int64_t>(num_cu, ngroups);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, p);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Rotation  RX[j][i] = sum_k Rc[i][k] X[j][k]   (src/OPQ.jl:26, src/Linscan.jl:102)
 // R sits in LDS in A-fragment order; each wave stages a 32-vector tile of X transposed in LDS
 // and runs NT x KK 32x32x2 MFMAs; the k loop is the fmaf chain k = 0..d-1 of the oracle.
@@ -646,18 +785,19 @@ int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int
   // wide sub-spaces (RVQ stages are full-dimensional: sub = d = 96 / 128): 8 wavefronts, X in registers;
   // the LDS-staged fallback runs 4 wavefronts and only fits while codebook + staging <= 160 KiB
 #define RQ_ENC_CASE_WIDE(KSV)                                              \
-  if (ks <= KSV) {                                                         \
-    const bool direct = tuning("ENC_DIRECT", 1) && (d % m == 0) && (d / m == 2 * KSV) && \
-                        (((uintptr_t)X & 7) == 0);                         \
-    if (direct) RQ_ENC_NT(KSV, 8, true);                                    \
-    RQ_ENC_NT(KSV, 4, false);                                               \
-  }
+  if (ks == KSV && tuning("ENC_DIRECT", 1) && (d % m == 0) && (d / m == 2 * KSV) && \
+      (((uintptr_t)X & 7) == 0) && (size_t)nt * KSV * 64 * 4 + (size_t)nt * 128 <= 160 * 1024)   \
+    RQ_ENC_NT(KSV, 8, true);
   RQ_ENC_CASE_WIDE(48)
   RQ_ENC_CASE_WIDE(64)
 #undef RQ_ENC_CASE_WIDE
 #undef RQ_ENC_NT
 #undef RQ_ENC_CASE
-  return fail(RQ_EUNSUPPORTED, "sub-space dimension %d > 128 not covered by the encode kernels", maxsub);
+  // any other width: chunked kernel, codebook streamed through LDS
+  if (nt <= 1) return launch_encode_wide<1>(p, num_cu, stream);
+  if (nt <= 2) return launch_encode_wide<2>(p, num_cu, stream);
+  if (nt <= 4) return launch_encode_wide<4>(p, num_cu, stream);
+  return launch_encode_wide<8>(p, num_cu, stream);
 }
 
 int rotate_launch(float *RX, const float *R, const float *X, int d, int64_t n, int num_cu,

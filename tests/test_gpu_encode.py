@@ -58,6 +58,12 @@ def test_rotation_and_quantize_opq(rq, oracle, name):
     (3_000, 50, 7, 33, "sift"),       # uneven split 8,7,7,7,7,7,7 and odd h
     (31, 16, 16, 17, "deep"),         # sub = 1, fewer rows than one tile
     (2_000, 256, 4, 256, "deep"),     # sub = 64
+    (1_500, 960, 8, 256, "sift"),     # GIST shape: sub = 120 -> chunked wide kernel
+    (700, 200, 1, 256, "deep"),       # one full-dimensional codebook (k-means assignment), 4 chunks of 32 k-steps... at NT=8: 7 of 16
+    (900, 150, 2, 100, "sift"),       # sub = 75 (odd), h = 100
+    (400, 131, 1, 33, "deep"),        # odd width, NT = 2
+    (2_000, 128, 1, 256, "sift"),     # exactly 128 wide: registers-only KS = 64 kernel
+    (2_000, 96, 1, 64, "deep"),       # exactly 96 wide: KS = 48
 ])
 def test_encode_vs_oracle_random(rq, oracle, n, d, m, h, kind):
     import rayuela_jl_amd.synth as synth

@@ -31,6 +31,7 @@ def test_quantize_rvq_matches_golden(rq, name):
     (3_001, 64, 5, 77, "deep"),      # h not a multiple of 32, ragged last tile
     (1_000, 30, 3, 64, "sift"),      # d % 4 != 0 -> scalar residual kernel, LDS-staged encode
     (33, 16, 2, 16, "deep"),
+    (2_000, 256, 3, 256, "deep"),    # d > 128: chunked wide encode per stage
 ])
 def test_quantize_rvq_vs_oracle_random(rq, oracle, n, d, m, h, kind):
     import rayuela_jl_amd.synth as synth
