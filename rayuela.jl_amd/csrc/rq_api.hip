@@ -149,22 +149,24 @@ static int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_
   void *cand = nullptr, *counter = nullptr;
   RQ_TRY(workspace(WS_CAND, pl.cand_bytes, &cand));
   RQ_TRY(workspace(WS_COUNTER, 256, &counter));
-  const bool direct = (pl.nslices == 1);
-  if (direct) {
-    // one slice: the scan kernel writes the final answer itself
-    if (keys && (dists || ids)) {
-      RQ_TRY(scan_launch(pl, nullptr, nullptr, keys, codes, centers, queries, n, nq, m, d, k, id_offset, id_base,
-                         (uint32_t *)counter, (uint64_t *)cand, stream, lut_mode, row_bias));
-      return merge_launch(dists, ids, nullptr, keys, nq, 1, k, id_base, stream);
-    }
-    return scan_launch(pl, dists, ids, keys, codes, centers, queries, n, nq, m, d, k, id_offset, id_base,
-                       (uint32_t *)counter, (uint64_t *)cand, stream, lut_mode, row_bias);
-  }
+  // whole items write the answer (or final keys) themselves; the sliced tail leaves per-slice key lists
+  // that merge_topk turns into the same outputs for those queries
+  const int64_t q_tail = std::min<int64_t>(nq, (int64_t)pl.whole * pl.qg);
+  const bool sliced = pl.nslices > 1 && q_tail < nq;
+  const bool both = keys && (dists || ids);      // keys requested together with dists/ids: unpack at the end
   void *part = nullptr;
-  RQ_TRY(workspace(WS_KEYS, (size_t)nq * pl.nslices * k * sizeof(uint64_t), &part));
-  RQ_TRY(scan_launch(pl, nullptr, nullptr, (uint64_t *)part, codes, centers, queries, n, nq, m, d, k, id_offset,
-                     id_base, (uint32_t *)counter, (uint64_t *)cand, stream, lut_mode, row_bias));
-  return merge_launch(dists, ids, keys, (const uint64_t *)part, nq, (int)pl.nslices, k, id_base, stream);
+  if (sliced) RQ_TRY(workspace(WS_KEYS, (size_t)(nq - q_tail) * pl.nslices * k * sizeof(uint64_t), &part));
+  RQ_TRY(scan_launch(pl, both ? nullptr : dists, both ? nullptr : ids, keys, (uint64_t *)part, codes, centers, queries,
+                     n, nq, m, d, k, id_offset, id_base, (uint32_t *)counter, (uint64_t *)cand, stream, lut_mode,
+                     row_bias));
+  if (sliced) {
+    const size_t off = (size_t)q_tail * k;
+    RQ_TRY(merge_launch(both || !dists ? nullptr : dists + off, both || !ids ? nullptr : ids + off,
+                        keys ? keys + off : nullptr, (const uint64_t *)part, nq - q_tail, (int)pl.nslices, k, id_base,
+                        stream));
+  }
+  if (both) return merge_launch(dists, ids, nullptr, keys, nq, 1, k, id_base, stream);
+  return RQ_OK;
 }
 
 static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers,

@@ -43,13 +43,13 @@ enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_PAD = 4, WS_MERG
 // ---- ADC scan -------------------------------------------------------------------------------
 struct ScanPlan {
   int qg, blk;
-  uint32_t ngroups, nslices, rows_per_slice;
+  uint32_t ngroups, nslices, rows_per_slice, whole;
   uint32_t cap, trigger, p2, scratch_keys, grid, sample;
   size_t cand_bytes, gtab_off, bkt_off;
-  bool lds_ok, bigk;
+  bool lds_ok, bigk, spread;
 };
 int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_cu, int force_slices);
-int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes,
+int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, uint64_t *part, const uint8_t *codes,
                 const float *centers, const float *queries, int64_t n, int64_t nq, int m, int d, int K,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
                 hipStream_t stream, int lut_mode = 0, const float *row_bias = nullptr);

@@ -116,6 +116,8 @@ struct ScanParams {
   uint32_t id_offset;
   int id_base;
   uint32_t nslices, rows_per_slice, ngroups;
+  uint32_t whole;           // query groups [0, whole) are ONE item over all rows (answer written directly);
+                            // groups [whole, ngroups) are cut into nslices row slices (key lists -> merge)
   uint32_t cap;             // candidate buffer capacity per query (keys)
   uint32_t trigger;         // compact when cnt > trigger  (cap - 2*BLK >= trigger >= K)
   uint32_t p2;              // next_pow2(K)
@@ -128,10 +130,12 @@ struct ScanParams {
   uint64_t *cand;           // [gridDim][QG][2][cap]
   uint16_t *bkt;            // [gridDim][cap] bucket ids of the large-K sample sort
   int bigk;                 // K > SCAN_SS_MIN_K: finish with samplesort_topk instead of cut + LDS bitonic
-  // outputs: direct (nslices == 1 && keys == nullptr) or packed keys [nq][nslices][K]
+  // outputs of whole items: dists/ids [nq][K], or packed keys [nq][K] when keys != nullptr;
+  // of sliced items: part [(query - whole*QG)][nslices][K] packed keys
   float *dists;
   uint32_t *ids;
   uint64_t *keys;
+  uint64_t *part;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -268,7 +272,7 @@ __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, ui
 // independent of it).  cnt/sel: the item's per-query candidate counts and current buffer halves.
 __device__ __noinline__ void finish_bigk(const uint32_t *cnt_q, const uint32_t *sel_q, uint32_t QG, uint64_t *cand_wg,
                                          uint16_t *bkt, uint32_t cap, uint32_t K, uint32_t q0, uint32_t nq,
-                                         uint64_t *keys_slice, uint32_t nslices, float *dists, uint32_t *ids,
+                                         uint64_t *keys_base, uint32_t key_stride, float *dists, uint32_t *ids,
                                          uint32_t id_base, unsigned char *lds, unsigned long long *stats) {
   const uint32_t tid = threadIdx.x;
 #pragma unroll 1
@@ -279,8 +283,8 @@ __device__ __noinline__ void finish_bigk(const uint32_t *cnt_q, const uint32_t *
     const uint64_t *src = cand_wg + ((size_t)q * 2 + sel) * cap;
     uint64_t *dst = cand_wg + ((size_t)q * 2 + (sel ^ 1u)) * cap;
     const uint32_t n_out = min(K, cnt);
-    if (keys_slice) {
-      uint64_t *o = keys_slice + (size_t)qq * nslices * K;
+    if (keys_base) {
+      uint64_t *o = keys_base + (size_t)qq * key_stride;
       for (uint32_t i = n_out + tid; i < K; i += SCAN_THREADS) o[i] = KEY_MAX;   // short slice
       samplesort_topk<SCAN_THREADS>(src, dst, bkt, cnt, n_out, lds, [o](uint32_t r, uint64_t key) { o[r] = key; }, stats);
     } else {
@@ -312,7 +316,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
   const int g = tid / TPG, gi = tid % TPG;  // query-lane view used by select / sort
   uint64_t *cand_wg = p.cand + (size_t)blockIdx.x * QG * 2 * p.cap;
   float4 *gtab = p.gtab + (size_t)blockIdx.x * (Cfg::GTAB_F4 > 0 ? Cfg::GTAB_F4 : 1);
-  const uint32_t nitems = p.ngroups * p.nslices;
+  const uint32_t tail_groups = p.ngroups - p.whole;
+  const uint32_t nitems = p.whole + tail_groups * p.nslices;
 
   for (;;) {
     __syncthreads();
@@ -320,8 +325,17 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     __syncthreads();
     const uint32_t item = ctrl->item;
     if (item >= nitems) break;
-    const uint32_t slice = item / p.ngroups, group = item % p.ngroups;
+    // whole items first (the long ones), then the sliced tail, slice-major so that the workgroups
+    // running together stream the same rows
+    const bool sliced = item >= p.whole && p.nslices > 1;
+    const uint32_t t_item = item - min(item, p.whole);
+    const uint32_t slice = sliced ? t_item / tail_groups : 0u;
+    const uint32_t group = item < p.whole ? item : p.whole + (sliced ? t_item % tail_groups : t_item);
     const uint32_t q0 = group * QG;
+    // where this item's sorted keys go (nullptr: dists/ids)
+    uint64_t *const keys_base = sliced ? p.part + (size_t)slice * p.K - (size_t)p.whole * QG * p.nslices * p.K
+                                       : p.keys;
+    const uint32_t key_stride = sliced ? p.nslices * (uint32_t)p.K : (uint32_t)p.K;
 
     // ---- stage the group's queries, reset the per-query state -------------------------------
     for (int e = tid; e < QG * p.d; e += SCAN_THREADS) {
@@ -337,8 +351,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     // still sit in this CU's L1): drop them before the first gather
     if (Cfg::KG > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     RQ_STAT_ADD(0, t_ph);
-    const uint32_t r_begin = slice * p.rows_per_slice;
-    const uint32_t r_end = min(p.n, r_begin + p.rows_per_slice);
+    const uint32_t r_begin = sliced ? slice * p.rows_per_slice : 0u;
+    const uint32_t r_end = sliced ? min(p.n, r_begin + p.rows_per_slice) : p.n;
     const uint32_t rows = r_end - r_begin;
     const float4 *lut4 = reinterpret_cast<const float4 *>(lut);
     // Threshold initialisation.  attempt 0: tau = the `srank`-th smallest distance of a stratified
@@ -533,7 +547,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     if (p.bigk) {
       // large K: select + sort in one sample-sort pass per query, keys stay in global memory
       finish_bigk(ctrl->cnt, ctrl->sel, QG, cand_wg, p.bkt + (size_t)blockIdx.x * p.cap, p.cap, (uint32_t)p.K,
-                  q0, p.nq, p.keys ? p.keys + (size_t)slice * p.K : nullptr, p.nslices, p.dists, p.ids,
+                  q0, p.nq, keys_base, key_stride, p.dists, p.ids,
                   (uint32_t)p.id_base, smem + CTRL_BYTES, p.stats);
       RQ_STAT_ADD(5, t_ph);
       continue;
@@ -563,8 +577,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
       t_s = RQ_STAT_T();
       const uint32_t qq = q0 + q;
       if (act && qq < p.nq) {
-        if (p.keys) {
-          uint64_t *o = p.keys + ((size_t)qq * p.nslices + slice) * p.K;
+        if (keys_base) {
+          uint64_t *o = keys_base + (size_t)qq * key_stride;
           for (uint32_t i = sgi; i < (uint32_t)p.K; i += tps) o[i] = a[i];
         } else {
           float *od = p.dists + (size_t)qq * p.K;
@@ -736,6 +750,8 @@ static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) 
   size_t lds = CTRL_BYTES + (size_t)std::max<size_t>(Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * (p.d + SCAN_THREADS) * 4,
                                                      (size_t)p.scratch_keys * 8);
   if (p.bigk) lds = std::max<size_t>(lds, CTRL_BYTES + SS_LDS_BYTES);
+  // SCAN_SPREAD: asking for more than half of the LDS forces one workgroup per CU
+  if (plan.spread) lds = std::max<size_t>(lds, 84 * 1024);
   auto kern = p.row_bias ? adc_scan_kernel<M, true> : adc_scan_kernel<M, false>;
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -774,23 +790,43 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   // workgroups per CU: as many as the LDS request admits (2 x 512 threads when it is <= 80 KiB)
   const size_t lds_req = CTRL_BYTES + std::max<size_t>(base_keys * 8, (size_t)pl.scratch_keys * 8);
   const int wgs = std::max(1, std::min<int>(SCAN_WGS_PER_CU, (int)(160 * 1024 / lds_req)));
-  // row slices: enough work items to fill the chip, but slices long enough that the
-  // per-slice top-k overhead (~K(1+ln(rows/K)) survivors, one sort) stays small
+  // Work items = (8-query group, row range), handed out by an atomic counter to the resident workgroups
+  // (2 per CU).  Per item there is a fixed cost (LUT, threshold sample, select + sort, and a merge pass for
+  // sliced groups), so whole-base items are best whenever they fill the chip:
+  //  * fewer groups than resident workgroups: every group is cut into slots/groups row slices
+  //    (1000 queries, K = 1000: 4 slices 1.11 ms; 1, 2, 6, 9 slices 1.85, 1.18, 1.37, 1.64 ms);
+  //  * otherwise whole items, except a small last partial round: when the groups beyond a multiple of
+  //    num_cu are at most num_cu/2 they are cut in two, so that they occupy twice as many CUs for half
+  //    as long (5000 queries: 3.71 -> 3.05 ms, 7000: 4.76 -> 4.10 ms; with a larger remainder, or finer
+  //    cuts, the per-item cost wins: 10000 queries 5.80 -> 5.91 ms, so those stay whole).
   int64_t min_rows = std::max<int64_t>(16384, 32LL * K);
   min_rows = (min_rows + Cfg::BLK - 1) / Cfg::BLK * Cfg::BLK;
-  int64_t max_slices = std::max<int64_t>(1, n / min_rows);
-  // one work item per resident workgroup when the batch has fewer query groups than that (measured:
-  // 125 groups -> 4 slices beat 2, 6 and 9); more groups than workgroups -> whole-base items
-  int64_t want = ((int64_t)num_cu * wgs) / pl.ngroups;
-  int64_t ns = std::min<int64_t>(std::max<int64_t>(1, want), max_slices);
-  if (force_slices > 0) ns = force_slices;
+  const int64_t max_slices = std::max<int64_t>(1, n / min_rows);
+  const int64_t U = num_cu, slots = (int64_t)num_cu * wgs;
+  int64_t whole = 0, tail = pl.ngroups, ns = 1;
+  if ((int64_t)pl.ngroups < slots) {
+    ns = std::min<int64_t>(std::max<int64_t>(1, slots / pl.ngroups), max_slices);
+  } else {
+    whole = (pl.ngroups / U) * U;
+    tail = pl.ngroups - whole;
+    if (tail > 0 && 2 * tail <= U && max_slices >= 2) ns = 2;
+  }
+  const int tail_ns = tuning("SCAN_TAIL_SLICES", 0);           // experiments: slices of the tail groups only
+  if (tail_ns > 0 && tail > 0) ns = std::min<int64_t>(tail_ns, max_slices);
+  if (force_slices > 0) { ns = force_slices; whole = 0; }   // tests: every group sliced
+  if (ns == 1) whole = pl.ngroups;
   int64_t rps = (n + ns - 1) / ns;
   rps = (rps + Cfg::BLK - 1) / Cfg::BLK * Cfg::BLK;
   ns = (n + rps - 1) / rps;
+  if (ns == 1) whole = pl.ngroups;
   pl.nslices = (uint32_t)ns;
   pl.rows_per_slice = (uint32_t)rps;
-  const uint64_t items = (uint64_t)pl.ngroups * pl.nslices;
-  pl.grid = (uint32_t)std::min<uint64_t>(items, (uint64_t)num_cu * wgs);
+  pl.whole = (uint32_t)whole;
+  const uint64_t items = (uint64_t)pl.whole + (uint64_t)(pl.ngroups - pl.whole) * pl.nslices;
+  // experiment knob: one workgroup per CU (made no difference for small grids -- the dispatcher already
+  // spreads them -- and costs 24 % at 4096 queries, so it is off)
+  pl.spread = tuning("SCAN_SPREAD", 0) > 0;
+  pl.grid = (uint32_t)std::min<uint64_t>(items, (uint64_t)num_cu * (pl.spread ? 1 : wgs));
   pl.cand_bytes = (size_t)pl.grid * Cfg::QG * 2 * pl.cap * sizeof(uint64_t);
   pl.gtab_off = pl.cand_bytes;   // the L1-gathered LUT parts live behind the candidate buffers
   pl.cand_bytes += (size_t)pl.grid * (Cfg::GTAB_F4 > 0 ? Cfg::GTAB_F4 : 1) * sizeof(float4);
@@ -822,7 +858,7 @@ int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_
   return RQ_OK;
 }
 
-int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes,
+int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, uint64_t *part, const uint8_t *codes,
                 const float *centers, const float *queries, int64_t n, int64_t nq, int m, int d, int K,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
                 hipStream_t stream, int lut_mode, const float *row_bias) {
@@ -833,7 +869,7 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   m = scan_padded_m(m);   // `codes` already has this row width (dev_linscan pads when needed)
   p.lut_mode = lut_mode; p.row_bias = row_bias;
   p.id_offset = id_offset; p.id_base = id_base;
-  p.nslices = pl.nslices; p.rows_per_slice = pl.rows_per_slice; p.ngroups = pl.ngroups;
+  p.nslices = pl.nslices; p.rows_per_slice = pl.rows_per_slice; p.ngroups = pl.ngroups; p.whole = pl.whole;
   p.cap = pl.cap; p.trigger = pl.trigger; p.p2 = pl.p2; p.scratch_keys = pl.scratch_keys;
   p.sample = pl.sample;
   p.srank_mul = (uint32_t)tuning("SCAN_SRANK_MUL", 2);
@@ -842,7 +878,7 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.bkt = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(cand) + pl.bkt_off);
   p.bigk = pl.bigk ? 1 : 0;
   p.stats = tuning("SCAN_STATS", 0) ? reinterpret_cast<unsigned long long *>(work_counter + 16) : nullptr;
-  p.dists = dists; p.ids = ids; p.keys = keys;
+  p.dists = dists; p.ids = ids; p.keys = keys; p.part = part;
   RQ_HIP(hipMemsetAsync(work_counter, 0, p.stats ? 256 : sizeof(uint32_t), stream));
   switch (m) {
     case 2: return launch_scan<2>(p, pl, stream);
