@@ -45,7 +45,7 @@ extern "C" {
 #define RQ_EUNSUPPORTED (-2) /* shape outside what the kernels cover (h>256, LUT > LDS, ...) */
 #define RQ_ENODEVICE (-3)   /* no gfx950 device visible */
 
-#define RQ_MAX_K 16384      /* largest k the scan returns */
+#define RQ_MAX_K 65536      /* largest k the scan returns */
 
 const char *rq_version(void);
 const char *rq_last_error(void);

@@ -72,7 +72,8 @@ def test_lut_kernel_bit_exact(rq, oracle):
     (9_000, 2, 3, 5, 1),
     (5_000, 32, 2, 3, 10),
     (1, 8, 4, 2, 1),               # single row
-    (70_000, 8, 4, 17, 16384),     # RQ_MAX_K
+    (70_000, 8, 4, 17, 16384),
+    (70_000, 8, 4, 5, 65536),      # RQ_MAX_K: nearly the whole base, exact fallback path (k > rows/16)
     (60_000, 64, 2, 11, 1000),     # PQ64: float2 LUT entries, 2 queries per group
     (10_000, 48, 2, 3, 100),       # padded to 64
 ])
