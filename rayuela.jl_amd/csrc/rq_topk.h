@@ -420,9 +420,6 @@ __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_
     "v_sub_co_u32_dpp %1, vcc, %2, %4 row_ror:" #N " row_mask:0xf bank_mask:0xf\n"      \
     "v_subb_co_u32_dpp %1, vcc, %3, %5, vcc row_ror:" #N " row_mask:0xf bank_mask:0xf\n" \
     "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n"
-#ifdef SS_SKIP_RANK
-    if (0)
-#endif
 #pragma unroll 1
     for (uint32_t b0 = row; b0 <= bstar; b0 += NR * UB) {
       uint32_t lo[UB], hi[UB];
@@ -456,11 +453,7 @@ __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_
                          : "v"(olo), "v"(ohi), "v"(mlo), "v"(mhi)
                          : "vcc");
           }
-#ifndef SS_SKIP_EMIT
           if (have && r < n_out) emit(r, mine);
-#else
-          if (have && r == 0xffffffffu) emit(0, mine);
-#endif
         }
       }
     }
