@@ -395,23 +395,39 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_direct_kernel(EncParams
 
 // ------------------------------------------------------------------------------------------
 // Wide sub-spaces (sub > 64 that are not exactly 96 / 128 wide, or whose codebook does not fit LDS:
-// PQ on GIST-960, RVQ / k-means assignment at any d).  The sub-space is cut into chunks of KC
-// k-steps (32, or 16 at NT = 8 to stay inside 256 registers); a codebook chunk (32 KiB at h = 256) is staged
-// into one half of a double-buffered LDS area while the MFMAs of the previous chunk run, and every
-// wavefront keeps the NT accumulator tiles of its 32 vectors across the chunks -- the MFMA chain of a
-// (centroid, vector) pair is still s = 0..sub-1 in order, i.e. the oracle's fmaf chain.
+// PQ on GIST-960 / MNIST-784, RVQ / k-means assignment at any d).  The work is one flat sequence of
+// chunks (tile group, sub-quantizer, KC k-steps of the sub-space).  While the MFMAs of a chunk run,
+// the NEXT chunk of the sequence -- the next slice of the same sub-space, the first slice of the next
+// sub-quantizer, or of the next tile group -- is in flight: its codebook slice (NT x KC x 64 floats,
+// A-fragment order) goes to the other half of a double-buffered LDS area, its X slice (coalesced
+// loads) to the wavefront's own staging tile.  Every wavefront keeps the NT accumulator tiles of its
+// 32 vectors across the chunks of a sub-space, so the MFMA chain of a (centroid, vector) pair is still
+// s = 0..sub-1 in order, i.e. the oracle's fmaf chain (padded dimensions multiply 0 by 0).
 // ------------------------------------------------------------------------------------------
+template <int NT>
+struct WideCfg {
+  static constexpr int KC = NT >= 8 ? 8 : NT >= 4 ? 16 : 32;   // k-steps per chunk: 128 accumulator registers
+  static constexpr int NW = 8;                                  // at NT = 8 leave room for 8-step staging only
+};
+
 template <int NT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void encode_wide_kernel(EncParams p) {
-  constexpr int KC = NT >= 8 ? 16 : 32;
+  constexpr int KC = WideCfg<NT>::KC;
   constexpr int CHUNK = NT * KC * 64;                  // floats per staged codebook chunk
   constexpr int PER = CHUNK / (NWAVES * 64);           // ... per thread
+  constexpr int DIMS = 2 * KC;                         // dimensions per chunk
+  constexpr int RPI = 64 / DIMS;                       // rows one wave-wide X load covers
+  constexpr int XL = 32 / RPI;                         // X loads per lane per chunk
+  constexpr int XSTR = DIMS + 1;                       // padded row stride of the staged X tile
+  static_assert(CHUNK % (NWAVES * 64) == 0 && 64 % DIMS == 0, "chunk split");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *cb0 = reinterpret_cast<float *>(smem);       // [2][CHUNK]
-  float *saL = cb0 + 2 * CHUNK;                         // [m][NT*32], C/D-fragment order
+  float *xs_all = cb0 + 2 * CHUNK;                     // [NWAVES][32][XSTR]: each wave's X chunk, row-major
+  float *saL = xs_all + NWAVES * 32 * XSTR;            // [m][NT*32], C/D-fragment order
   const int m = p.m, h = p.h, d = p.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hi = lane >> 5;
+  float *xs = xs_all + wave * 32 * XSTR;
 
   for (int idx = tid; idx < m * NT * 32; idx += NWAVES * 64) {
     const int c32 = idx & 31;
@@ -437,65 +453,73 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_wide_kernel(EncParams p) {
     const int t = (e >> 6) / KC;
     const int sub = p.off[i + 1] - p.off[i];
     const int cen = t * 32 + (l & 31);
-    const int s = c * 2 * KC + 2 * kk + (l >> 5);
+    const int s = c * DIMS + 2 * kk + (l >> 5);
     return (cen < h && s < sub) ? p.C[(size_t)h * p.off[i] + (size_t)cen * sub + s] : 0.0f;
+  };
+  // X slice of (tile group tg, sub-quantizer i, chunk c): lane -> (row u*RPI + lane/DIMS, dimension lane%DIMS);
+  // rows past the end repeat the last one (their codes are never written)
+  const int xdim = lane % DIMS, xrow_in = lane / DIMS;
+  auto x_load = [&](int64_t tg, int i, int c, int u) -> float {
+    const int sub = p.off[i + 1] - p.off[i];
+    int64_t gr = (tg * NWAVES + wave) * 32 + u * RPI + xrow_in;
+    if (gr >= p.n) gr = p.n - 1;
+    const int sdim = c * DIMS + xdim;
+    return sdim < sub ? p.X[gr * d + p.off[i] + sdim] : 0.0f;
   };
 
   const int64_t ntiles = (p.n + 31) / 32;
   const int64_t ngroups = (ntiles + NWAVES - 1) / NWAVES;
-  for (int64_t tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
-    const int64_t tile = tg * NWAVES + wave;
-    const int64_t row0 = tile * 32;
-    int64_t gr = row0 + j;
-    if (gr >= p.n) gr = p.n - 1;                        // idle lanes / waves repeat the last row
-    const float *xrow = p.X + gr * d;
+  int64_t tg = blockIdx.x;
+  int i = 0, c = 0;
+  if (tg >= ngroups) return;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) cb0[tid + u * NWAVES * 64] = cb_load(0, 0, tid + u * NWAVES * 64);
+#pragma unroll
+  for (int u = 0; u < XL; ++u) xs[(u * RPI + xrow_in) * XSTR + xdim] = x_load(tg, 0, 0, u);
+  __syncthreads();
+
+  f32x16 acc[NT];
+  float sb = 0.0f;
+  int buf = 0;
 #pragma unroll 1
-    for (int i = 0; i < m; ++i) {
-      const int sub = p.off[i + 1] - p.off[i];
-      const int nchunks = (sub + 2 * KC - 1) / (2 * KC);
-      const float *xs = xrow + p.off[i];
-      f32x16 acc[NT];
+  for (;;) {
+    const int sub = p.off[i + 1] - p.off[i];
+    const int nchunks = (sub + DIMS - 1) / DIMS;
+    // the position after this one in the flat sequence
+    int64_t ntg = tg;
+    int ni = i, nc = c + 1;
+    if (nc == nchunks) { nc = 0; ++ni; if (ni == m) { ni = 0; ntg += gridDim.x; } }
+    const bool more = ntg < ngroups;
+    if (c == 0) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-      float sb = 0.0f;
-      __syncthreads();                                  // the previous user of buffer 0 is done
+      sb = 0.0f;
+    }
+    float nxt[PER], xn[XL];
+    if (more) {
 #pragma unroll
-      for (int u = 0; u < PER; ++u) cb0[tid + u * NWAVES * 64] = cb_load(i, 0, tid + u * NWAVES * 64);
-      __syncthreads();
-#pragma unroll 1
-      for (int c = 0; c < nchunks; ++c) {
-        const float *cb = cb0 + (size_t)(c & 1) * CHUNK + lane;
-        float nxt[PER];
-        const bool more = c + 1 < nchunks;
-        if (more) {
+      for (int u = 0; u < PER; ++u) nxt[u] = cb_load(ni, nc, tid + u * NWAVES * 64);
 #pragma unroll
-          for (int u = 0; u < PER; ++u) nxt[u] = cb_load(i, c + 1, tid + u * NWAVES * 64);
-        }
-        float b[KC];
+      for (int u = 0; u < XL; ++u) xn[u] = x_load(ntg, ni, nc, u);
+    }
+    const float *cb = cb0 + (size_t)buf * CHUNK + lane;
+    float b[KC];
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk) {
-          const int s0 = c * 2 * KC + 2 * kk;
-          const float x0 = s0 < sub ? xs[s0] : 0.0f;
-          const float x1 = s0 + 1 < sub ? xs[s0 + 1] : 0.0f;
-          b[kk] = hi ? x1 : x0;
-          sb = __builtin_fmaf(x0, x0, sb);               // zero padding leaves the chain untouched
-          sb = __builtin_fmaf(x1, x1, sb);
-        }
+    for (int kk = 0; kk < KC; ++kk) {
+      const float x0 = xs[j * XSTR + 2 * kk], x1 = xs[j * XSTR + 2 * kk + 1];
+      b[kk] = hi ? x1 : x0;
+      sb = __builtin_fmaf(x0, x0, sb);
+      sb = __builtin_fmaf(x1, x1, sb);
+    }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
-          for (int kk = 0; kk < KC; ++kk)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[(t * KC + kk) * 64], b[kk], acc[t], 0, 0, 0);
-        }
-        if (more) {
-          float *dstb = cb0 + (size_t)((c + 1) & 1) * CHUNK;
-#pragma unroll
-          for (int u = 0; u < PER; ++u) dstb[tid + u * NWAVES * 64] = nxt[u];
-        }
-        __syncthreads();
-      }
+      for (int kk = 0; kk < KC; ++kk)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[(t * KC + kk) * 64], b[kk], acc[t], 0, 0, 0);
+    }
+    if (c + 1 == nchunks) {   // the sub-space is complete: argmin over the NT tiles
       ArgminState st;
       st.best_v = __uint_as_float(0x7f800000u);
       st.best_t = 0;
@@ -509,17 +533,30 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_wide_kernel(EncParams p) {
       const float ov = __shfl_xor(best_v, 32);
       const int oi = __shfl_xor(best_i, 32);
       if (ov < best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
-      if (hi == 0 && row0 + j < p.n) p.codes[(size_t)(row0 + j) * m + i] = (uint8_t)best_i;
+      const int64_t row = (tg * NWAVES + wave) * 32 + j;
+      if (hi == 0 && row < p.n) p.codes[(size_t)row * m + i] = (uint8_t)best_i;
     }
+    if (!more) break;
+    {
+      float *dstb = cb0 + (size_t)(buf ^ 1) * CHUNK;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) dstb[tid + u * NWAVES * 64] = nxt[u];
+#pragma unroll
+      for (int u = 0; u < XL; ++u) xs[(u * RPI + xrow_in) * XSTR + xdim] = xn[u];   // this wave's own tile
+    }
+    __syncthreads();
+    buf ^= 1;
+    tg = ntg; i = ni; c = nc;
   }
 }
 
 template <int NT>
 static int launch_encode_wide(EncParams p, int num_cu, hipStream_t stream) {
-  constexpr int NW = 8;
+  constexpr int NW = WideCfg<NT>::NW;
+  constexpr int KC = WideCfg<NT>::KC;
   p.NT = NT;
-  constexpr int KC = NT >= 8 ? 16 : 32;
-  const size_t lds = (size_t)2 * NT * KC * 64 * sizeof(float) + (size_t)p.m * NT * 32 * sizeof(float);
+  const size_t lds = (size_t)2 * NT * KC * 64 * sizeof(float) + (size_t)NW * 32 * (2 * KC + 1) * sizeof(float) +
+                     (size_t)p.m * NT * 32 * sizeof(float);
   if (lds > 160 * 1024)
     return fail(RQ_EUNSUPPORTED, "wide encode: m=%d sub-quantizers of h=%d need %zu B of LDS", p.m, p.h, lds);
   auto kern = encode_wide_kernel<NT, NW>;
