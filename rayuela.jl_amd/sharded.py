@@ -45,6 +45,8 @@ def shard_bounds(n_total, world):
 
 
 class ShardedIndex:
+    _use_gather = True   # gather-to-root for the final collection (see search)
+
     def __init__(self, codes_local, centers, id_offset, group=None, scan_fn=None, merge_fn=None):
         self.codes = codes_local          # [n_local][m] uint8, resident on this rank's device
         self.centers = centers            # [m][256][sub] float32, replicated
@@ -95,19 +97,24 @@ class ShardedIndex:
         q_lo, q_hi, d, i = self.search_owned(queries, k, id_base)
         if W == 1:
             return d, i
-        # rank 0 collects the owned blocks (nq/W * k * 8 bytes per rank).  ProcessGroupNCCL has no
-        # gather-to-root for tensor lists on every torch version; an all_gather of these small
-        # blocks is the portable RCCL form, gloo (CPU tests) uses a true gather.
-        if dist.get_backend(self.group) == "nccl":
+        # rank 0 collects the owned blocks (nq/W * k * 8 bytes per rank) with a gather-to-root: W-1 point-to-
+        # point transfers over W-1 DISTINCT xGMI links.  (An all_gather moves the same blocks to every rank and
+        # RCCL runs it as a ring, i.e. (W-1)/W of the whole result through ONE link per rank -- 70 MB at W = 8,
+        # k = 1000, more than the all_to_all above.)  ProcessGroupNCCL has gather since torch 1.11; should a
+        # build lack it the call raises before any traffic and the all_gather form is used from then on.
+        if ShardedIndex._use_gather:
+            gd = [torch.empty_like(d) for _ in range(W)] if self.rank == 0 else None
+            gi = [torch.empty_like(i) for _ in range(W)] if self.rank == 0 else None
+            try:
+                dist.gather(d, gd, dst=0, group=self.group)
+                dist.gather(i, gi, dst=0, group=self.group)
+            except (RuntimeError, NotImplementedError):
+                ShardedIndex._use_gather = False
+        if not ShardedIndex._use_gather:
             gd = [torch.empty_like(d) for _ in range(W)]
             gi = [torch.empty_like(i) for _ in range(W)]
             dist.all_gather(gd, d, group=self.group)
             dist.all_gather(gi, i, group=self.group)
-        else:
-            gd = [torch.empty_like(d) for _ in range(W)] if self.rank == 0 else None
-            gi = [torch.empty_like(i) for _ in range(W)] if self.rank == 0 else None
-            dist.gather(d, gd, dst=0, group=self.group)
-            dist.gather(i, gi, dst=0, group=self.group)
         if self.rank != 0:
             return None
         return torch.cat(gd, dim=0)[:nq].contiguous(), torch.cat(gi, dim=0)[:nq].contiguous()

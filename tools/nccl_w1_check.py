@@ -15,5 +15,6 @@ d0, i0 = rqd.linscan(codes, cen, q, 100)
 print("RESULT nccl world=1 path ok:", torch.equal(r[0], d0), torch.equal(r[1], i0))
 x = torch.arange(8, dtype=torch.int64, device="cuda"); y = torch.empty_like(x); dist.all_to_all_single(y, x)
 g = [torch.empty_like(x)]; dist.all_gather(g, x)
-print("RESULT a2a", y.tolist(), "allgather", g[0].tolist())
+gg = [torch.empty_like(x)]; dist.gather(x, gg, dst=0)
+print("RESULT a2a", y.tolist(), "allgather", g[0].tolist(), "gather", gg[0].tolist())
 dist.barrier(); dist.destroy_process_group()
