@@ -13,6 +13,8 @@
 //   compact_leq   : copy the keys <= tau to the front of another buffer
 //   radix_select_lds : the same on keys already in LDS (threshold sample, uint32 keys)
 //   bitonic_sort_tiled : ascending sort of a power-of-two LDS array, wave-local stages without barriers
+//   samplesort_topk : select + sort of the k smallest of cnt keys for large k, keys staying in global
+//                   memory (splitters in LDS, bucket count / scatter, DPP row ranking per bucket)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -177,6 +177,28 @@ def test_large_k_sample_sort_paths(rq, oracle, K):
     assert _eq_bits(dists.cpu().numpy(), d0)
 
 
+@pytest.mark.parametrize("nq,K", [(4196, 10), (4196, 1500), (4600, 100)])
+def test_whole_and_sliced_items_in_one_launch(rq, oracle, nq, K):
+    """More query groups than resident workgroups with a small remainder: the planner scans the first
+    512 groups whole and cuts the remaining ones into two row slices (+ merge) inside the same launch;
+    keys-and-dists requests go through the same plan."""
+    import torch
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import device as rqd
+    n, m, sub = 50_000, 8, 4
+    rng = np.random.default_rng(nq + K)
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=nq)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+    assert np.array_equal(i0, i1)
+    assert _eq_bits(d0, d1)
+    ct, cen, qs = torch.from_numpy(codes).cuda(), torch.from_numpy(centers).cuda(), torch.from_numpy(queries).cuda()
+    keys = rqd.linscan(ct, cen, qs, K, id_offset=7, want_keys=True).cpu().numpy().view(np.uint64)
+    assert np.array_equal((keys & np.uint64(0xFFFFFFFF)).astype(np.uint32), i0 + np.uint32(7))
+
+
 def test_sharded_index_single_rank_uses_hip_kernels(rq, oracle):
     """ShardedIndex with its default (HIP) scan/merge functions, world size 1: keys out of the scan,
     through rq_dev_merge_topk, equal the direct answer."""
