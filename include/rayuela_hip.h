@@ -93,6 +93,12 @@ int rq_encode_rvq(uint8_t *codes, const float *X, const float *codebooks, int64_
                   uint32_t *counts, float *Xr_out);
 int rq_encode_rvq_i16(int16_t *codes1, const float *X, const float *codebooks, int64_t n, int d, int m, int h,
                       uint32_t *counts, float *Xr_out);
+/* train_rvq (src/RVQ.jl:86-127): one k-means of niter Lloyd iterations per stage on the running residual.
+ * C [m][h][d] out; B1 [n][m] Int16 one-based out (== quantize_rvq(X, C)); *error = qerror(X, B, C).
+ * Seeding: h residual rows drawn from the library's seeded stream (the reference uses kmeans++ with
+ * Julia's global RNG), so results agree in objective, not bit for bit.  h*d*4 B must fit the LDS. */
+int rq_train_rvq(float *C, int16_t *B1, double *error, const float *X, int64_t n, int d, int m, int h, int niter,
+                 uint64_t seed);
 /* device-pointer form: Xr [n][d] holds X on entry and the final residual on return */
 int rq_dev_encode_rvq(uint8_t *codes, float *Xr, const float *codebooks, int64_t n, int d, int m, int h,
                       uint32_t *counts, void *stream);

@@ -13,7 +13,7 @@
 # C ABI is exercised through ctypes by tests/ (rayuela.jl_amd/*.py mirrors this file line by line).
 module RayuelaHIP
 
-export quantize_pq, quantize_opq, quantize_rvq, linscan_pq, linscan_opq, linscan_lsq, linscan_cq, train_pq, train_opq
+export quantize_pq, quantize_opq, quantize_rvq, linscan_pq, linscan_opq, linscan_lsq, linscan_cq, train_pq, train_opq, train_rvq
 
 # deps/build.jl:64-67 writes the library paths into deps/deps.jl; here one constant / env var.
 const librayuela_hip = get(ENV, "RAYUELA_HIP_LIB",
@@ -94,6 +94,23 @@ function quantize_rvq(X::Matrix{Float32}, C::Vector{Matrix{Float32}}, V::Bool=fa
     end
   end
   return B, singletons
+end
+
+"""
+    train_rvq(X, m, h, niter=25, V=false; seed=0) -> C, B, error     (src/RVQ.jl:86-127)
+One k-means per stage on the running residual, on the device.  Seeding comes from the library's seeded
+stream (the reference: kmeans++ with Julia's RNG), so runs agree in objective, not bit for bit.
+"""
+function train_rvq(X::Matrix{Float32}, m::Integer, h::Integer, niter::Integer=25, V::Bool=false; seed::Integer=0)
+  d, n = size(X)
+  Ccat = Array{Float32}(undef, d, h, m)            # C view [m][h][d]
+  B    = Matrix{Int16}(undef, m, n)
+  err  = Ref{Cdouble}(0.0)
+  _check(ccall((:rq_train_rvq, librayuela_hip), Cint,
+    (Ptr{Cfloat}, Ptr{Int16}, Ref{Cdouble}, Ptr{Cfloat}, Int64, Cint, Cint, Cint, Cint, UInt64),
+    Ccat, B, err, X, Int64(n), Cint(d), Cint(m), Cint(h), Cint(niter), UInt64(seed)))
+  C = [Ccat[:, :, i] for i = 1:m]
+  return C, B, Float32(err[])
 end
 
 """

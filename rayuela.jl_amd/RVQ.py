@@ -63,3 +63,22 @@ def quantize_rvq_u8(X, C, with_extras=False):
     _lib.check(_lib.lib().rq_encode_rvq(B.ctypes.data, X.ctypes.data, Cs.ctypes.data, n, d, m, h,
                                         counts.ctypes.data, None if Xr is None else Xr.ctypes.data))
     return (B, counts, Xr) if with_extras else B
+
+
+def train_rvq(X, m, h, niter=25, V=False, seed=0):
+    """train_rvq(X, m, h, niter=25, V=false) -> C, B, error        (src/RVQ.jl:86-127)
+
+    One k-means per stage on the running residual, all on the device (rq_train_rvq).  C: m-long list of
+    (h, d) codebooks; B: (n, m) int16 one-based, equal to quantize_rvq(X, C)[0]; error = qerror(X, B, C).
+    Seeding comes from the library's seeded stream (the reference: kmeans++ with Julia's RNG)."""
+    import ctypes
+    X = _as_f32(X, "X")
+    n, d = X.shape
+    C = np.empty((m, h, d), dtype=np.float32)
+    B = np.empty((n, m), dtype=np.int16)
+    err = ctypes.c_double(0.0)
+    _lib.check(_lib.lib().rq_train_rvq(C.ctypes.data, B.ctypes.data, ctypes.cast(ctypes.byref(err), ctypes.c_void_p),
+                                       X.ctypes.data, n, d, m, h, niter, seed))
+    if V:
+        print("  Error after codebook %d is %e" % (m, err.value))
+    return [C[i] for i in range(m)], B, float(err.value)

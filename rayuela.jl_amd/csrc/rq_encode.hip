@@ -906,6 +906,23 @@ __global__ __launch_bounds__(256) void rvq_residual_scalar_kernel(float *Xr, con
 // quantize_rvq (src/RVQ.jl:18-66) on resident data: m full-dimensional stages, each the encode kernel
 // with one sub-quantizer of width d on the running residual.  Xr [n][d] is overwritten (in: X or a copy
 // of it, out: the final residual); stage_codes is n bytes of scratch; counts is [m][h] or NULL.
+// one stage's epilogue: Xr -= Ci[stage_codes], codes[:, stage] = stage_codes, cnt[code] += 1 (cnt may be NULL)
+int rvq_residual_launch(float *Xr, const float *Ci, const uint8_t *stage_codes, uint8_t *codes, unsigned int *cnt,
+                        int64_t n, int d, int m, int stage, hipStream_t stream) {
+  if (n <= 0) return RQ_OK;
+  if ((d & 3) == 0 && (((uintptr_t)Xr | (uintptr_t)Ci) & 15) == 0) {
+    const int64_t total = n * (d >> 2);
+    hipLaunchKernelGGL(rvq_residual_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, Xr, Ci,
+                       stage_codes, codes, cnt, n, d, m, stage);
+  } else {
+    const int64_t total = n * d;
+    hipLaunchKernelGGL(rvq_residual_scalar_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, Xr,
+                       Ci, stage_codes, codes, cnt, n, d, m, stage);
+  }
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
 int rvq_encode_launch(uint8_t *codes, float *Xr, uint8_t *stage_codes, unsigned int *counts, const float *C,
                       int64_t n, int d, int m, int h, int num_cu, hipStream_t stream) {
   if (n <= 0) return RQ_OK;
@@ -913,17 +930,7 @@ int rvq_encode_launch(uint8_t *codes, float *Xr, uint8_t *stage_codes, unsigned 
   for (int i = 0; i < m; ++i) {
     const float *Ci = C + (size_t)i * h * d;
     RQ_TRY(encode_launch(stage_codes, Xr, Ci, n, d, 1, h, num_cu, stream));
-    unsigned int *cnt = counts ? counts + (size_t)i * h : nullptr;
-    if ((d & 3) == 0 && (((uintptr_t)Xr | (uintptr_t)Ci) & 15) == 0) {
-      const int64_t total = n * (d >> 2);
-      hipLaunchKernelGGL(rvq_residual_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, Xr, Ci,
-                         stage_codes, codes, cnt, n, d, m, i);
-    } else {
-      const int64_t total = n * d;
-      hipLaunchKernelGGL(rvq_residual_scalar_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, Xr,
-                         Ci, stage_codes, codes, cnt, n, d, m, i);
-    }
-    RQ_HIP(hipGetLastError());
+    RQ_TRY(rvq_residual_launch(Xr, Ci, stage_codes, codes, counts ? counts + (size_t)i * h : nullptr, n, d, m, i, stream));
   }
   return RQ_OK;
 }

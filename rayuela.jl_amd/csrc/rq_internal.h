@@ -65,6 +65,8 @@ int synth_codes_launch(uint8_t *codes, int64_t n, int m, uint64_t seed, int64_t 
 // ---- encode / rotation ----------------------------------------------------------------------
 int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m, int h,
                   int num_cu, hipStream_t stream);
+int rvq_residual_launch(float *Xr, const float *Ci, const uint8_t *stage_codes, uint8_t *codes, unsigned int *cnt,
+                        int64_t n, int d, int m, int stage, hipStream_t stream);
 int rvq_encode_launch(uint8_t *codes, float *Xr, uint8_t *stage_codes, unsigned int *counts, const float *C,
                       int64_t n, int d, int m, int h, int num_cu, hipStream_t stream);
 int rotate_launch(float *RX, const float *R, const float *X, int d, int64_t n, int num_cu,

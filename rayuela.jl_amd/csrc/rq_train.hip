@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void qerror_kernel(TrainParams p) {
   const int64_t total = p.n * p.d;
   double s = 0.0;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const double df = (double)p.X[e] - (double)p.CB[e];
+    const double df = (double)p.X[e] - (p.CB ? (double)p.CB[e] : 0.0);   // CB == NULL: sum of squares of X
     s += df * df;
   }
   red[threadIdx.x] = s;

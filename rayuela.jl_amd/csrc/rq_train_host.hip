@@ -187,6 +187,58 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
   return RQ_OK;
 }
 
+// train_rvq (src/RVQ.jl:86-127): one k-means per stage on the running residual (Clustering.kmeans with
+// kmeans++ seeding and Julia's RNG there; h sampled residual rows from the library's seeded stream here),
+// then Xr .-= C[i][:, B[:, i]] (:112).  C [m][h][d]; B1 [n][m] Int16 one-based; error = qerror(X, B, C) (:124).
+int rq_train_rvq(float *C, int16_t *B1, double *error, const float *X, int64_t n, int d, int m, int h, int niter,
+                 uint64_t seed) {
+  if (n < 1 || d < 1 || m < 1 || m > 64 || h < 1 || h > 256 || niter < 0)
+    return fail(RQ_EINVAL, "train_rvq: n=%lld d=%d m=%d h=%d niter=%d", (long long)n, d, m, h, niter);
+  if (n < h) return fail(RQ_EINVAL, "train_rvq: fewer training vectors (%lld) than codebook entries (%d)", (long long)n, h);
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  int off1[2] = {0, d};
+  Rng rng{seed * 0x9E3779B97F4A7C15ull + 3};
+  DevMem dXr, dCi, dstage, dcnt, dcodes, dacc, d16;
+  RQ_TRY(dXr.alloc((size_t)n * d * 4)); RQ_TRY(dCi.alloc((size_t)h * d * 4)); RQ_TRY(dstage.alloc((size_t)n));
+  RQ_TRY(dcnt.alloc((size_t)h * 4)); RQ_TRY(dcodes.alloc((size_t)n * m)); RQ_TRY(dacc.alloc(8));
+  RQ_TRY(d16.alloc((size_t)n * m * 2));
+  RQ_HIP(hipMemcpy(dXr.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice));
+  std::vector<unsigned int> counts((size_t)h);
+  std::vector<uint8_t> cur((size_t)n), prev;
+  for (int i = 0; i < m; ++i) {
+    RQ_TRY(init_centers(dCi.as<float>(), dXr.as<float>(), n, d, 1, h, off1, rng));
+    prev.clear();
+    for (int it = 0; it < niter; ++it) {
+      RQ_TRY(encode_launch(dstage.as<uint8_t>(), dXr.as<float>(), dCi.as<float>(), n, d, 1, h, di.num_cu, nullptr));
+      RQ_HIP(hipMemcpy(cur.data(), dstage.p, (size_t)n, hipMemcpyDeviceToHost));
+      if (!prev.empty() && prev == cur) break;   // assignments stable: Lloyd has converged
+      prev = cur;
+      RQ_TRY(update_centers_launch(dCi.as<float>(), dcnt.as<unsigned int>(), dXr.as<float>(), dstage.as<uint8_t>(), n,
+                                   d, 1, h, di.num_cu, nullptr));
+      RQ_HIP(hipMemcpy(counts.data(), dcnt.p, (size_t)h * 4, hipMemcpyDeviceToHost));
+      for (int k = 0; k < h; ++k)                // re-seed empty clusters from sampled residual rows
+        if (counts[k] == 0) {
+          const int64_t row = (int64_t)(rng.next() % (uint64_t)n);
+          RQ_HIP(hipMemcpy(dCi.as<float>() + (size_t)k * d, dXr.as<float>() + row * d, sizeof(float) * d,
+                           hipMemcpyDeviceToDevice));
+        }
+    }
+    // the assignments of the final centres (what quantize_rvq would return for this stage), then the residual
+    RQ_TRY(encode_launch(dstage.as<uint8_t>(), dXr.as<float>(), dCi.as<float>(), n, d, 1, h, di.num_cu, nullptr));
+    RQ_TRY(rvq_residual_launch(dXr.as<float>(), dCi.as<float>(), dstage.as<uint8_t>(), dcodes.as<uint8_t>(), nullptr, n,
+                               d, m, i, nullptr));
+    RQ_HIP(hipMemcpy(C + (size_t)i * h * d, dCi.p, (size_t)h * d * 4, hipMemcpyDeviceToHost));
+  }
+  RQ_TRY(qerror_launch(dacc.as<double>(), dXr.as<float>(), nullptr, n, d, di.num_cu, nullptr));
+  RQ_TRY(widen_codes_launch(d16.as<int16_t>(), dcodes.as<uint8_t>(), n * m, nullptr));
+  double acc = 0;
+  RQ_HIP(hipMemcpy(&acc, dacc.p, 8, hipMemcpyDeviceToHost));
+  if (error) *error = acc / (double)n;
+  RQ_HIP(hipMemcpy(B1, d16.p, (size_t)n * m * 2, hipMemcpyDeviceToHost));
+  return RQ_OK;
+}
+
 int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, int64_t n, int d, int m, int h,
                  int niter, int init, uint64_t seed, const float *R0, const float *C0) {
   RQ_TRY(check_train(n, d, m, h, niter));

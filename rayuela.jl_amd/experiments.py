@@ -58,3 +58,48 @@ def experiment_opq_query_base(Xt, Xq, gt, m, h, init, niter=25, knn=1000, V=Fals
     dists, idx = linscan_opq(B, Xq, C, b, R, knn)
     recall = eval_recall(gt, idx, knn, verbose=V)
     return C, B, R, train_error, recall
+
+
+def _norms_codebook(B, C, h=256, seed=0):
+    """get_norms_codebook (src/utils.jl:4-26): norms of the reconstructions, quantised by a 1-D k-means
+    (rq_train_pq with d = m = 1).  Returns (norms_codes one-based, norms_codebook (h,))."""
+    from .PQ import train_pq
+    Cs = np.stack([np.asarray(c, dtype=np.float32) for c in C])
+    codes = B.astype(np.int64) - 1
+    recon = np.zeros((B.shape[0], Cs.shape[2]), dtype=np.float32)
+    for i in range(Cs.shape[0]):
+        recon += Cs[i][codes[:, i]]
+    dbnorms = (recon ** 2).sum(axis=1, dtype=np.float32).reshape(-1, 1)
+    Cn, Bn, _ = train_pq(np.ascontiguousarray(dbnorms), 1, h, niter=25, seed=seed)
+    return Bn[:, 0].astype(np.int64), Cn[0][:, 0].copy()
+
+
+def _quantize_norms(B, C, norms_C):
+    """quantize_norms (src/utils.jl:29-60): nearest entry of the norms codebook for every reconstruction."""
+    Cs = np.stack([np.asarray(c, dtype=np.float32) for c in C])
+    codes = B.astype(np.int64) - 1
+    recon = np.zeros((B.shape[0], Cs.shape[2]), dtype=np.float32)
+    for i in range(Cs.shape[0]):
+        recon += Cs[i][codes[:, i]]
+    dbnorms = (recon ** 2).sum(axis=1, dtype=np.float32)
+    order = np.argsort(norms_C, kind="stable")
+    srt = norms_C[order]
+    pos = np.clip(np.searchsorted(srt, dbnorms), 1, len(srt) - 1)
+    left = np.abs(dbnorms - srt[pos - 1]) <= np.abs(dbnorms - srt[pos])
+    return order[np.where(left, pos - 1, pos)] + 1, dbnorms
+
+
+def experiment_rvq(Xt, Xb, Xq, gt, m, h, niter=25, knn=1000, V=False, seed=0):
+    """experiment_rvq (src/RVQ.jl:130-175): train_rvq -> norms codebook -> quantize_rvq of the base ->
+    quantised database norms -> linscan_lsq -> eval_recall."""
+    from .RVQ import train_rvq, quantize_rvq
+    from .Linscan import linscan_lsq
+    d = Xt.shape[1]
+    C, B, train_error = train_rvq(Xt, m, h, niter, V, seed=seed)
+    _, norms_C = _norms_codebook(B, C, h, seed=seed)
+    B_base, _ = quantize_rvq(Xb, C, V)
+    B_base_norms, _ = _quantize_norms(B_base, C, norms_C)
+    db_norms = norms_C[B_base_norms - 1].astype(np.float32)
+    dists, idx = linscan_lsq(B_base, Xq, C, db_norms, np.eye(d, dtype=np.float32), knn)
+    recall = eval_recall(gt, idx, knn, verbose=V)
+    return C, B, train_error, B_base, recall

@@ -74,3 +74,44 @@ def test_device_resident_rvq_and_lsq_search(rq, oracle):
     best = score.argmin(1) + 1
     assert (idx[:, :5] == best[:, None].astype(idx.dtype)).any(axis=1).all()
     assert (idx[:, 0] == best.astype(idx.dtype)).mean() >= 0.9
+
+
+def test_train_rvq_contract(rq, oracle):
+    """train_rvq (src/RVQ.jl:86-127): every stage lowers the error, more Lloyd iterations lower it further,
+    the returned codes are quantize_rvq of the returned codebooks and the reported error is qerror(X, B, C)."""
+    import rayuela_jl_amd.synth as synth
+    X = synth.sift_like(20_000, 64, seed=21)
+    errs = []
+    for m in (1, 2, 4):
+        C, B, e = rq.train_rvq(X, m, 64, niter=8, seed=3)
+        errs.append(e)
+        assert len(C) == m and C[0].shape == (64, 64) and B.shape == (20_000, m) and B.dtype == np.int16
+    assert errs[0] > errs[1] > errs[2] > 0
+    C1, B1, e1 = rq.train_rvq(X, 4, 64, niter=1, seed=3)
+    assert errs[2] < e1
+    C, B, e = rq.train_rvq(X, 4, 64, niter=8, seed=3)
+    assert abs(e - errs[2]) <= 1e-6 * e                   # same seed, same model (up to atomic summation order)
+    Bq, singles = rq.quantize_rvq(X, C)
+    assert np.array_equal(Bq, B)
+    recon = np.zeros(X.shape, dtype=np.float64)
+    for i in range(4):
+        recon += C[i][B[:, i].astype(np.int64) - 1]
+    e64 = ((X.astype(np.float64) - recon) ** 2).sum() / X.shape[0]
+    assert abs(e - e64) <= 1e-5 * e64
+    # the oracle encode agrees on the trained codebooks too
+    assert np.array_equal(oracle.encode_rvq(X, np.stack(C)).astype(np.int16) + 1, B)
+
+
+def test_experiment_rvq_end_to_end(rq):
+    """experiment_rvq (src/RVQ.jl:130-175) on synthetic data: train -> norms codebook -> encode the base ->
+    linscan_lsq -> recall; 32 bits of RVQ must find most true neighbours of clustered data in the top 50."""
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd.experiments import experiment_rvq
+    d, m, h, knn = 32, 4, 256, 50
+    Xb = synth.sift_like(20_000, d, seed=5)
+    Xq = synth.sift_like(64, d, seed=6)
+    dd = ((Xq.astype(np.float64)[:, None, :] - Xb.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+    gt = (dd.argmin(1) + 1).astype(np.uint32)
+    C, B, train_error, B_base, recall = experiment_rvq(Xb[:8000], Xb, Xq, gt, m, h, niter=6, knn=knn)
+    assert recall.shape == (knn,) and (np.diff(recall) >= 0).all() and recall[-1] > 0.5
+    assert train_error > 0 and B_base.shape == (20_000, m)
