@@ -161,25 +161,38 @@ __device__ __forceinline__ void build_lut(float *lut, float4 *gtab, const float 
     for (int q = 0; q < QG; ++q) acc[q] = 0.0f;
     if (k >= m_real) {
       // padding sub-quantizer (m rounded up to a supported tile width): T = 0, and x + 0.0f == x
-    } else if (mode == 1) {
-      for (int s = 0; s < cdim; ++s) {
-        const float cs = c[s];
-#pragma unroll
-        for (int q = 0; q < QG; ++q) {
-          const float two_q = 2.0f * qstage[q * d + s];
-          const float prod = two_q * cs;
-          acc[q] = acc[q] - prod;
-        }
-      }
     } else {
-      for (int s = 0; s < cdim; ++s) {
-        const float cs = c[s];
+      // one table entry per thread, its codebook row streamed 16 bytes at a time (full-dimensional rows
+      // are 512 B apart between lanes: scalar loads would touch 64 cache lines per instruction, 4x as often)
+      auto step = [&](float cs, int s) {
+        if (mode == 1) {
 #pragma unroll
-        for (int q = 0; q < QG; ++q) {
-          const float diff = cs - qstage[q * d + qoff + s];   // (q-c)^2 has the same bits
-          const float sq = diff * diff;
-          acc[q] = acc[q] + sq;
+          for (int q = 0; q < QG; ++q) {
+            const float two_q = 2.0f * qstage[q * d + s];
+            const float prod = two_q * cs;
+            acc[q] = acc[q] - prod;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < QG; ++q) {
+            const float diff = cs - qstage[q * d + qoff + s];   // (q-c)^2 has the same bits
+            const float sq = diff * diff;
+            acc[q] = acc[q] + sq;
+          }
         }
+      };
+      if ((cdim & 3) == 0 && ((uintptr_t)centers & 15) == 0) {
+        const float4 *c4 = reinterpret_cast<const float4 *>(c);
+#pragma unroll 2
+        for (int s4 = 0; s4 < cdim / 4; ++s4) {
+          const float4 cv = c4[s4];
+          step(cv.x, 4 * s4 + 0);
+          step(cv.y, 4 * s4 + 1);
+          step(cv.z, 4 * s4 + 2);
+          step(cv.w, 4 * s4 + 3);
+        }
+      } else {
+        for (int s = 0; s < cdim; ++s) step(c[s], s);
       }
     }
     using LV = LutVec<Cfg::QPG>;

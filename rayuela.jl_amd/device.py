@@ -89,6 +89,33 @@ def linscan(codes, centers, queries, k, id_offset=0, id_base=0, want_keys=False,
     return dists, ids
 
 
+def linscan_aq(codes, codebooks, queries, k, dbnorms=None, id_offset=0, id_base=0, want_keys=False, out=None):
+    """ADC scan for additive quantizers on resident tensors (rq_dev_linscan_aq): codebooks [m*256][d];
+    dbnorms given -> LSQ tables -2<q,c> + per-row norm (src/Linscan.jl:118-157), else CQ tables |q-c|^2 (:160-193)."""
+    n, m = codes.shape
+    nq, d = queries.shape
+    dev = codes.device
+    mode = 1 if dbnorms is not None else 2
+    nrm = None if dbnorms is None else _chk(dbnorms, torch.float32, "dbnorms")
+    if want_keys:
+        keys = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        _lib.check(_lib.lib().rq_dev_linscan_aq(None, None, keys.data_ptr(), _chk(codes, torch.uint8, "codes"),
+                                                _chk(codebooks, torch.float32, "codebooks"),
+                                                _chk(queries, torch.float32, "queries"), nrm, n, nq, m, d, k, mode,
+                                                id_offset, id_base, _stream()))
+        return keys
+    if out is None:
+        dists = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    else:
+        dists, ids = out
+    _lib.check(_lib.lib().rq_dev_linscan_aq(dists.data_ptr(), ids.data_ptr(), None, _chk(codes, torch.uint8, "codes"),
+                                            _chk(codebooks, torch.float32, "codebooks"),
+                                            _chk(queries, torch.float32, "queries"), nrm, n, nq, m, d, k, mode,
+                                            id_offset, id_base, _stream()))
+    return dists, ids
+
+
 def merge_topk(keys_in, k, id_base=0, out=None):
     """keys_in [nq][P][k] int64 (uint64 bit patterns) -> (dists [nq][k], ids [nq][k])."""
     nq, P, kk = keys_in.shape

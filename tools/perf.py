@@ -52,6 +52,16 @@ if "scan" in a.what:
             tot = sum(st[k] for k in ("lut", "sample", "stream", "final_cut", "sort_write")) or 1
             print("   phases(%%): " + " ".join("%s=%.1f" % (k, 100.0 * st[k] / tot) for k in ("lut", "sample", "stream", "cuts", "final_cut", "sort_write")) + " n_cuts=%d n_fallbacks=%d sample_rows=%.1f%% sort_load=%.1f%% sort_stages=%.1f%% sort_out=%.1f%%" % (st["n_cuts"], st["n_fallbacks"], 100.0 * st["sample_rows"] / tot, 100.0 * st["sort_load"] / tot, 100.0 * st["sort_stages"] / tot, 100.0 * st["sort_out"] / tot))
         print("scan   n=%d nq=%d m=%d K=%-5d %8.3f ms  %10.0f q/s  %7.1f GB/s-alg" % (n, nq, m, K, ms, nq / ms * 1e3, nq * n * m / ms / 1e6))
+if "aq" in a.what:   # linscan_lsq / linscan_cq: full-dimensional codebooks, LSQ adds the row norms
+    codes = rqd.synth_codes(n, m, seed=1234)
+    cb = torch.randn((m * 256, d), generator=g, device=dev)
+    queries = torch.randn((nq, d), generator=g, device=dev)
+    norms = torch.rand((n,), generator=g, device=dev) * 100
+    for K in [int(x) for x in a.ks.split(",")]:
+        out = (torch.empty((nq, K), dtype=torch.float32, device=dev), torch.empty((nq, K), dtype=torch.int32, device=dev))
+        for name, nr in (("lsq", norms), ("cq", None)):
+            ms = bench(lambda: rqd.linscan_aq(codes, cb, queries, K, dbnorms=nr, out=out), a.iters)
+            print("%-6s n=%d nq=%d m=%d d=%d K=%-5d %8.3f ms  %10.0f q/s" % (name, n, nq, m, d, K, ms, nq / ms * 1e3))
 if "encode" in a.what:
     X = torch.randint(0, 200, (n, d), generator=g, device=dev).float()
     C = torch.randint(0, 200, (256 * d,), generator=g, device=dev).float()
