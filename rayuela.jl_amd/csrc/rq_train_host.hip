@@ -56,50 +56,71 @@ static void sample_distinct(Rng &rng, int64_t n, int h, std::vector<int64_t> &ou
 // Polar factor U V' of the d x d matrix G (row-major) by one-sided Jacobi SVD in double.
 // G = U S V'  ->  out = U V'   (src/OPQ.jl:112-113: U, S, VV = svd(X * CB'); R = U * VV')
 static void polar_factor(const double *G, double *out, int d) {
-  std::vector<double> A(G, G + (size_t)d * d), V((size_t)d * d, 0.0);
-  for (int i = 0; i < d; ++i) V[(size_t)i * d + i] = 1.0;
+  // columns are stored as rows (At[p] = column p of G, Vt[p] = column p of V): every inner loop runs over
+  // contiguous memory, the three dot products keep four partial sums each (4 independent fma chains
+  // instead of one latency-bound chain) -- 128 x 128: 25 ms -> ~5 ms per call
+  std::vector<double> At((size_t)d * d), Vt((size_t)d * d, 0.0);
+  for (int i = 0; i < d; ++i)
+    for (int p = 0; p < d; ++p) At[(size_t)p * d + i] = G[(size_t)i * d + p];
+  for (int i = 0; i < d; ++i) Vt[(size_t)i * d + i] = 1.0;
   for (int sweep = 0; sweep < 60; ++sweep) {
     double off = 0.0;
     for (int p = 0; p < d - 1; ++p) {
+      double *ap = &At[(size_t)p * d], *vp = &Vt[(size_t)p * d];
       for (int q = p + 1; q < d; ++q) {
-        double alpha = 0, beta = 0, gamma = 0;
-        for (int i = 0; i < d; ++i) {
-          const double ap = A[(size_t)i * d + p], aq = A[(size_t)i * d + q];
-          alpha += ap * ap; beta += aq * aq; gamma += ap * aq;
-        }
+        double *aq = &At[(size_t)q * d], *vq = &Vt[(size_t)q * d];
+        double al[4] = {0, 0, 0, 0}, be[4] = {0, 0, 0, 0}, ga[4] = {0, 0, 0, 0};
+        int i = 0;
+        for (; i + 4 <= d; i += 4)
+          for (int u = 0; u < 4; ++u) {
+            al[u] += ap[i + u] * ap[i + u];
+            be[u] += aq[i + u] * aq[i + u];
+            ga[u] += ap[i + u] * aq[i + u];
+          }
+        for (; i < d; ++i) { al[0] += ap[i] * ap[i]; be[0] += aq[i] * aq[i]; ga[0] += ap[i] * aq[i]; }
+        const double alpha = (al[0] + al[1]) + (al[2] + al[3]), beta = (be[0] + be[1]) + (be[2] + be[3]);
+        const double gamma = (ga[0] + ga[1]) + (ga[2] + ga[3]);
         if (alpha == 0.0 || beta == 0.0) continue;
         const double lim = fabs(gamma) / sqrt(alpha * beta);
         if (lim > off) off = lim;
         if (lim < 1e-15) continue;
         const double zeta = (beta - alpha) / (2.0 * gamma);
         const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-        for (int i = 0; i < d; ++i) {
-          const double ap = A[(size_t)i * d + p], aq = A[(size_t)i * d + q];
-          A[(size_t)i * d + p] = c * ap - s * aq;
-          A[(size_t)i * d + q] = s * ap + c * aq;
-          const double vp = V[(size_t)i * d + p], vq = V[(size_t)i * d + q];
-          V[(size_t)i * d + p] = c * vp - s * vq;
-          V[(size_t)i * d + q] = s * vp + c * vq;
+        const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+        for (int k = 0; k < d; ++k) {
+          const double x = ap[k], y = aq[k];
+          ap[k] = c * x - sn * y;
+          aq[k] = sn * x + c * y;
+        }
+        for (int k = 0; k < d; ++k) {
+          const double x = vp[k], y = vq[k];
+          vp[k] = c * x - sn * y;
+          vq[k] = sn * x + c * y;
         }
       }
     }
     if (off < 1e-14) break;
   }
-  // columns of A are U * S: normalise (a null column keeps the matching column of V: any orthonormal
-  // completion is a valid polar factor there)
+  // rows of At are the columns of U * S: normalise (a null column keeps the matching column of V: any
+  // orthonormal completion is a valid polar factor there)
   for (int j = 0; j < d; ++j) {
+    double *aj = &At[(size_t)j * d];
+    const double *vj = &Vt[(size_t)j * d];
     double nrm = 0;
-    for (int i = 0; i < d; ++i) nrm += A[(size_t)i * d + j] * A[(size_t)i * d + j];
+    for (int i = 0; i < d; ++i) nrm += aj[i] * aj[i];
     nrm = sqrt(nrm);
-    for (int i = 0; i < d; ++i) A[(size_t)i * d + j] = nrm > 1e-300 ? A[(size_t)i * d + j] / nrm : V[(size_t)i * d + j];
+    for (int i = 0; i < d; ++i) aj[i] = nrm > 1e-300 ? aj[i] / nrm : vj[i];
   }
-  for (int i = 0; i < d; ++i)
-    for (int j = 0; j < d; ++j) {
-      double acc = 0;
-      for (int k = 0; k < d; ++k) acc += A[(size_t)i * d + k] * V[(size_t)j * d + k];
-      out[(size_t)i * d + j] = acc;
+  // out = U V':  out[i][j] = sum_k U[i][k] V[j][k] = sum_k At[k][i] Vt[k][j]
+  for (size_t e = 0; e < (size_t)d * d; ++e) out[e] = 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double *uk = &At[(size_t)k * d], *vk = &Vt[(size_t)k * d];
+    for (int i = 0; i < d; ++i) {
+      const double u = uk[i];
+      double *o = &out[(size_t)i * d];
+      for (int j = 0; j < d; ++j) o[j] += u * vk[j];
     }
+  }
 }
 
 struct DevMem {
