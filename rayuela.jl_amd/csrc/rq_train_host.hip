@@ -55,14 +55,34 @@ static void sample_distinct(Rng &rng, int64_t n, int h, std::vector<int64_t> &ou
 
 // Polar factor U V' of the d x d matrix G (row-major) by one-sided Jacobi SVD in double.
 // G = U S V'  ->  out = U V'   (src/OPQ.jl:112-113: U, S, VV = svd(X * CB'); R = U * VV')
-static void polar_factor(const double *G, double *out, int d) {
+// Vwarm (optional, d x d row-major, in/out): right singular vectors of the previous call.  Successive
+// G = X CB' of an OPQ run differ little, so starting from A = G Vwarm, V = Vwarm the sweeps converge in
+// 2-3 instead of ~10; the polar factor itself does not depend on the starting point.
+static void polar_factor(const double *G, double *out, int d, std::vector<double> *Vwarm = nullptr) {
   // columns are stored as rows (At[p] = column p of G, Vt[p] = column p of V): every inner loop runs over
   // contiguous memory, the three dot products keep four partial sums each (4 independent fma chains
   // instead of one latency-bound chain) -- 128 x 128: 25 ms -> ~5 ms per call
   std::vector<double> At((size_t)d * d), Vt((size_t)d * d, 0.0);
-  for (int i = 0; i < d; ++i)
-    for (int p = 0; p < d; ++p) At[(size_t)p * d + i] = G[(size_t)i * d + p];
-  for (int i = 0; i < d; ++i) Vt[(size_t)i * d + i] = 1.0;
+  if (Vwarm && Vwarm->size() == (size_t)d * d) {
+    // Vt[p] = column p of Vwarm;  At[p] = column p of G Vwarm = sum_k G[:, k] Vwarm[k][p]
+    for (int k = 0; k < d; ++k)
+      for (int p = 0; p < d; ++p) Vt[(size_t)p * d + k] = (*Vwarm)[(size_t)k * d + p];
+    std::fill(At.begin(), At.end(), 0.0);
+    for (int p = 0; p < d; ++p) {
+      double *ap = &At[(size_t)p * d];
+      const double *vp = &Vt[(size_t)p * d];
+      for (int i = 0; i < d; ++i) {
+        const double *gi = &G[(size_t)i * d];
+        double acc = 0;
+        for (int k = 0; k < d; ++k) acc += gi[k] * vp[k];
+        ap[i] = acc;
+      }
+    }
+  } else {
+    for (int i = 0; i < d; ++i)
+      for (int p = 0; p < d; ++p) At[(size_t)p * d + i] = G[(size_t)i * d + p];
+    for (int i = 0; i < d; ++i) Vt[(size_t)i * d + i] = 1.0;
+  }
   for (int sweep = 0; sweep < 60; ++sweep) {
     double off = 0.0;
     for (int p = 0; p < d - 1; ++p) {
@@ -100,6 +120,11 @@ static void polar_factor(const double *G, double *out, int d) {
       }
     }
     if (off < 1e-14) break;
+  }
+  if (Vwarm) {   // keep V for the next call
+    Vwarm->assign((size_t)d * d, 0.0);
+    for (int p = 0; p < d; ++p)
+      for (int k = 0; k < d; ++k) (*Vwarm)[(size_t)k * d + p] = Vt[(size_t)p * d + k];
   }
   // rows of At are the columns of U * S: normalise (a null column keeps the matching column of V: any
   // orthonormal completion is a valid polar factor there)
@@ -294,6 +319,7 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
   RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dRX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
   RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr));
   std::vector<float> Gf((size_t)d * d);
+  std::vector<double> Vwarm;   // empty on the first iteration: cold start
   for (int it = 0; it <= niter; ++it) {
     // objective |R CB - X|^2 / n == |CB - R'X|^2 / n (src/OPQ.jl:108)
     RQ_TRY(qerror_launch(dacc.as<double>(), dRX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr));
@@ -304,7 +330,7 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
     RQ_TRY(gram_launch(dG.as<float>(), dX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr));
     RQ_HIP(hipMemcpy(Gf.data(), dG.p, (size_t)d * d * 4, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < Gf.size(); ++i) G[i] = Gf[i];
-    polar_factor(G.data(), P.data(), d);       // P = U V' = Julia's R
+    polar_factor(G.data(), P.data(), d, &Vwarm);       // P = U V' = Julia's R
     for (int i = 0; i < d; ++i)
       for (int k = 0; k < d; ++k) Rh[(size_t)i * d + k] = (float)P[(size_t)k * d + i];
     RQ_HIP(hipMemcpy(dR.p, Rh.data(), (size_t)d * d * 4, hipMemcpyHostToDevice));
