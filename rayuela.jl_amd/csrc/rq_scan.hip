@@ -380,9 +380,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     uint32_t S = p.sample;
     uint32_t srank = 0;
     bool sampled = false;
-    if (S >= (uint32_t)SCAN_THREADS && p.K >= 8 && rows >= 32u * (uint32_t)SCAN_THREADS &&
-        (uint64_t)rows >= 16ull * (uint64_t)p.K) {
-      const float q = (float)p.srank_mul * (float)p.K / (float)rows;      // target quantile (<= 1/8 * mul)
+    const uint32_t Ks = max((uint32_t)p.K, 8u);   // k < 8 aims at the 8th neighbour: same machinery, still exact
+    if (S >= (uint32_t)SCAN_THREADS && rows >= 32u * (uint32_t)SCAN_THREADS && (uint64_t)rows >= 16ull * (uint64_t)Ks) {
+      const float q = (float)p.srank_mul * (float)Ks / (float)rows;       // target quantile (<= 1/8 * mul)
       uint32_t gsz = S / (uint32_t)SCAN_THREADS;
       gsz = min(gsz, rows / (8u * (uint32_t)SCAN_THREADS));               // short slice: sample at most 1/8 of it
       if (q * (float)gsz > 0.7f) gsz = max(1u, (uint32_t)(0.7f / q));
@@ -812,7 +812,7 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   //    num_cu are at most num_cu/2 they are cut in two, so that they occupy twice as many CUs for half
   //    as long (5000 queries: 3.71 -> 3.05 ms, 7000: 4.76 -> 4.10 ms; with a larger remainder, or finer
   //    cuts, the per-item cost wins: 10000 queries 5.80 -> 5.91 ms, so those stay whole).
-  int64_t min_rows = std::max<int64_t>(16384, 32LL * K);
+  int64_t min_rows = std::max<int64_t>(tuning("SCAN_MIN_ROWS", 16384), 32LL * K);
   min_rows = (min_rows + Cfg::BLK - 1) / Cfg::BLK * Cfg::BLK;
   const int64_t max_slices = std::max<int64_t>(1, n / min_rows);
   const int64_t U = num_cu, slots = (int64_t)num_cu * wgs;
