@@ -188,12 +188,20 @@ void rq_index_destroy(rq_index *ix);
 
 /* Diagnostic knob used by tests and tuning runs (same effect as env RQ_<KEY>):
  *   SCAN_SLICES  force the number of row slices per shard (0 = automatic)
- *   ENC_WAVES    wavefronts per encode workgroup (4 or 8) */
+ *   ENC_WAVES    wavefronts per encode workgroup (8 or 16)
+ *   others (SCAN_SAMPLE, SCAN_SRANK_MUL, SCAN_SLACK, SCAN_SS_MIN_K, SCAN_TAIL_SLICES, SCAN_MIN_ROWS, ENC_DIRECT,
+ *   ROT_V2, HOST_OVERLAP, SCAN_STATS) are experiment switches documented where they are read */
 int rq_set_tuning(const char *key, int value);
 /* Diagnostics: with tuning SCAN_STATS=1, summed shader-clock cycles (thread 0 of every workgroup) of the
  * last scan: [0] LUT build [1] threshold sample [2] streaming [3] in-stream cuts [4] final cut [5] sort+write,
  * [6] number of in-stream cuts, [7] number of exact fallbacks, [8] the row part of [1]; out has 12 slots. */
 int rq_scan_stats(unsigned long long *out12);
+
+/* Diagnostics (pure host code, no device needed): the scan planner's decision for a shard of n rows, nq queries,
+ * m sub-quantizers, dimension d, k neighbours on a device with num_cu compute units.  out[0] queries per group,
+ * [1] groups, [2] groups scanned as whole-base items, [3] row slices of the remaining groups, [4] rows per slice,
+ * [5] workgroups launched, [6] candidate capacity per query, [7] 1 = sample-sort finish (k > 1024). */
+int rq_scan_plan(int64_t n, int64_t nq, int m, int d, int k, int num_cu, int64_t *out8);
 
 /* Milliseconds spent in the last host-pointer call on this thread: total wall, H2D, kernels
  * (hipEvent), D2H -- so the PCIe-inclusive and the resident rates can both be reported. */

@@ -62,6 +62,7 @@ SIGNATURES = {
     "rq_index_destroy": (None, [_vp]),
     "rq_set_tuning": (_i32, [C.c_char_p, _i32]),
     "rq_scan_stats": (_i32, [_vp]),
+    "rq_scan_plan": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "rq_last_timing": (_i32, [_vp, _vp, _vp, _vp]),
 }
 
@@ -100,6 +101,14 @@ def check(status):
 
 def set_tuning(key, value):
     check(lib().rq_set_tuning(key.encode(), int(value)))
+
+
+def scan_plan(n, nq, m, d, k, num_cu=256):
+    """The planner's decision (host code only): dict of qg, groups, whole, slices, rows_per_slice, grid, cap, bigk."""
+    out = (C.c_int64 * 8)()
+    check(lib().rq_scan_plan(n, nq, m, d, k, num_cu, C.cast(out, C.c_void_p)))
+    keys = ("qg", "groups", "whole", "slices", "rows_per_slice", "grid", "cap", "bigk")
+    return dict(zip(keys, [int(x) for x in out]))
 
 
 def scan_stats():

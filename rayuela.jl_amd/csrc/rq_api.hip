@@ -402,6 +402,15 @@ int rq_set_tuning(const char *key, int value) {
   return RQ_OK;
 }
 
+int rq_scan_plan(int64_t n, int64_t nq, int m, int d, int k, int num_cu, int64_t *out8) {
+  if (!out8 || n < 1 || nq < 1 || k < 1 || num_cu < 1) return fail(RQ_EINVAL, "rq_scan_plan: bad arguments");
+  ScanPlan pl;
+  RQ_TRY(scan_plan(pl, n, nq, m, d, k, num_cu, tuning("SCAN_SLICES", 0)));
+  out8[0] = pl.qg; out8[1] = pl.ngroups; out8[2] = pl.whole; out8[3] = pl.nslices; out8[4] = pl.rows_per_slice;
+  out8[5] = pl.grid; out8[6] = pl.cap; out8[7] = pl.bigk ? 1 : 0;
+  return RQ_OK;
+}
+
 int rq_scan_stats(unsigned long long *out8) {
   // diagnostics: phase cycle counters of the last scan launched with tuning SCAN_STATS=1
   void *counter = nullptr;

@@ -69,3 +69,28 @@ def test_host_mirror_argument_checks(rq):
     with pytest.raises(TypeError):  # Float64 data never dispatches in the reference (src/PQ.jl:32)
         rq.quantize_pq(np.zeros((4, 8), np.float64), [np.zeros((4, 4), np.float32)] * 2)
     assert [list(p) for p in rq.splitarray(range(1, 11), 4)] == [[1, 2, 3], [4, 5, 6], [7, 8], [9, 10]]
+
+
+def test_scan_planner_decisions():
+    """The planner is pure host code: its work-item decomposition can be checked without a GPU."""
+    from rayuela_jl_amd import _lib
+    # headline shape: 1250 groups >= 512 resident workgroups, remainder 226 > num_cu/2 -> everything whole
+    p = _lib.scan_plan(1_000_000, 10_000, 8, 128, 1000)
+    assert p["qg"] == 8 and p["groups"] == 1250 and p["whole"] == 1250 and p["slices"] == 1 and p["grid"] == 512
+    assert p["bigk"] == 0 and p["cap"] >= 1000 + 4000
+    # 5000 queries: 625 groups = 512 whole + 113 (<= 128) cut in two
+    p = _lib.scan_plan(1_000_000, 5_000, 8, 128, 100)
+    assert (p["whole"], p["slices"]) == (512, 2) and p["rows_per_slice"] * 2 >= 1_000_000
+    # small batch: slices = resident workgroups / groups, never shorter than max(16384, 32 k) rows
+    p = _lib.scan_plan(1_000_000, 1_000, 8, 128, 1000)
+    assert (p["whole"], p["slices"]) == (0, 4)
+    p = _lib.scan_plan(1_000_000, 8, 8, 128, 10)
+    assert p["whole"] == 0 and p["slices"] == 49 and p["rows_per_slice"] == 20480   # >= 16384, whole 4096-row blocks
+    p = _lib.scan_plan(1_000_000, 8, 8, 128, 10_000)
+    assert p["slices"] == 3 and p["bigk"] == 1           # 32 k rows per slice at least; sample-sort finish
+    # m = 16 groups 4 queries; padded widths plan like the next tiled width
+    assert _lib.scan_plan(1_000_000, 1_000, 16, 96, 100)["qg"] == 4
+    assert _lib.scan_plan(1_000_000, 1_000, 12, 96, 100) == _lib.scan_plan(1_000_000, 1_000, 16, 96, 100)
+    # SIFT1B shard: 1.25e8 rows, 1024 queries -> 128 groups, 4 slices
+    p = _lib.scan_plan(125_000_000, 1024, 8, 128, 100)
+    assert (p["groups"], p["slices"]) == (128, 4)
