@@ -368,8 +368,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     const uint32_t r_end = sliced ? min(p.n, r_begin + p.rows_per_slice) : p.n;
     const uint32_t rows = r_end - r_begin;
     const float4 *lut4 = reinterpret_cast<const float4 *>(lut);
-    // Threshold initialisation.  attempt 0: tau = the `srank`-th smallest distance of a stratified
-    // sample of S rows, srank ~ 2*K*S/rows + 8, so about 2-3K rows survive the whole slice instead of
+    // Threshold initialisation.  attempt 0: tau = the `srank`-th smallest of the per-thread minima of a
+    // stratified sample of S rows, so about 1.5-2.5 K rows survive the whole slice instead of
     // K*(1+ln(rows/K)) and no cut is needed before the end.  That tau is an estimate: if fewer
     // than K rows beat it (needs a sample ~3x off) attempt 1 redoes the slice with tau = +inf,
     // which is exact by construction.  Either way the answer is exact: whenever >= K rows beat
@@ -382,14 +382,20 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     bool sampled = false;
     const uint32_t Ks = max((uint32_t)p.K, 8u);   // k < 8 aims at the 8th neighbour: same machinery, still exact
     if (S >= (uint32_t)SCAN_THREADS && rows >= 32u * (uint32_t)SCAN_THREADS && (uint64_t)rows >= 16ull * (uint64_t)Ks) {
-      const float q = (float)p.srank_mul * (float)Ks / (float)rows;       // target quantile (<= 1/8 * mul)
+      // The number of thread minima below the true K-th distance is Binomial(512, frac), frac = 1-(1-K/rows)^g.
+      // tau = the minimum of rank  mean + z sigma + 2  (z = 3 * srank_mul = 6): fewer than K survivors -- the
+      // only cost of a miss is one redone slice -- is a 6-sigma event, and the surplus over K shrinks with K:
+      // ~2.5 K survivors at K = 1000 (sigma/mean = 25 %), ~1.5 K at K = 10000 (7 %).
+      const float q = (float)Ks / (float)rows;                            // the K-th neighbour's quantile (<= 1/16)
       uint32_t gsz = S / (uint32_t)SCAN_THREADS;
       gsz = min(gsz, rows / (8u * (uint32_t)SCAN_THREADS));               // short slice: sample at most 1/8 of it
-      if (q * (float)gsz > 0.7f) gsz = max(1u, (uint32_t)(0.7f / q));
+      if (q * (float)gsz > 0.45f) gsz = max(1u, (uint32_t)(0.45f / q));   // keep the rank in the middle of the 512
       S = gsz * (uint32_t)SCAN_THREADS;
       const float frac = 1.0f - __expf((float)gsz * __logf(fmaxf(1.0f - q, 1e-6f)));
-      srank = (uint32_t)ceilf(frac * (float)SCAN_THREADS) + 8u;
-      sampled = q < 0.5f && srank * 4u <= 3u * (uint32_t)SCAN_THREADS;
+      const float mean = frac * (float)SCAN_THREADS;
+      const float z = 3.0f * (float)p.srank_mul;
+      srank = (uint32_t)ceilf(mean + z * sqrtf(mean * (1.0f - frac))) + 2u;
+      sampled = srank * 4u <= 3u * (uint32_t)SCAN_THREADS;
     }
 #pragma unroll 1
     for (int attempt = sampled ? 0 : 1; attempt < 2; ++attempt) {
@@ -783,7 +789,7 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   // slack between cuts: with the sampled tau about 2-3K rows survive a slice, so a slack of 4K means
   // "no cut before the end"; the exact fallback (tau from +inf) cuts every `slack` survivors.
   int slack_i = tuning("SCAN_SLACK", 0);
-  if (slack_i <= 0) slack_i = std::max(std::min(std::max(4 * K, 1024), 16384), K + K / 2);
+  if (slack_i <= 0) slack_i = std::max(std::min(std::max(4 * K, 2048), 16384), K + K / 2);
   const uint32_t slack = (uint32_t)slack_i;
   pl.trigger = (uint32_t)K + slack;
   pl.sample = (uint32_t)tuning("SCAN_SAMPLE", 16384);
