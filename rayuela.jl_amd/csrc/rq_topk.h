@@ -222,6 +222,38 @@ __device__ __forceinline__ void bitonic_batch(uint64_t *a, uint32_t c0, uint32_t
   }
 }
 
+// Two consecutive stages (j, j/2) of one merge phase k in ONE LDS round trip: the four elements
+// b, b+j/2, b+j, b+j+j/2 (b with the bits j and j/2 clear) exchange among themselves only, and they lie in
+// the same k-block, so one direction serves all four compare-exchanges.  Groups g0, g0+64 per lane.
+__device__ __forceinline__ void bitonic_batch4(uint64_t *a, uint32_t g0, uint32_t gend, uint32_t j, uint32_t k) {
+  const uint32_t jh = j >> 1;
+  uint32_t b[2];
+  uint64_t e[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const uint32_t g = g0 + 64u * u;
+    b[u] = ((g & ~(jh - 1)) << 2) | (g & (jh - 1));
+    if (g < gend) {
+      e[u][0] = a[b[u]]; e[u][1] = a[b[u] + jh]; e[u][2] = a[b[u] + j]; e[u][3] = a[b[u] + j + jh];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const uint32_t g = g0 + 64u * u;
+    if (g < gend) {
+      const bool up = (b[u] & k) == 0;
+      auto cx = [up](uint64_t &x, uint64_t &y) {
+        const bool sw = (x > y) == up;
+        const uint64_t lo = sw ? y : x, hi = sw ? x : y;
+        x = lo; y = hi;
+      };
+      cx(e[u][0], e[u][2]); cx(e[u][1], e[u][3]);   // stage j
+      cx(e[u][0], e[u][1]); cx(e[u][2], e[u][3]);   // stage j/2
+      a[b[u]] = e[u][0]; a[b[u] + jh] = e[u][1]; a[b[u] + j] = e[u][2]; a[b[u] + j + jh] = e[u][3];
+    }
+  }
+}
+
 // Ascending bitonic sort of a[0..p2) in LDS by a group of `nw` wavefronts (wave index w, lane).
 // p2 is a power of two and uniform over the WORKGROUP (every thread of the block must call this:
 // it contains __syncthreads()).  Wave w owns the segment [w*E, (w+1)*E), E = p2/nw_eff: every
@@ -235,18 +267,29 @@ __device__ __forceinline__ void bitonic_sort_tiled(uint64_t *a, uint32_t p2, uin
   const uint32_t E = p2 / nw_eff;
   const bool mine = act && w < nw_eff;
   bool prev_wide = true;   // the caller's fill of a[] came from other waves
+  // stages are taken two at a time (j, j/2) from the top of every merge phase: 36 LDS round trips instead
+  // of 66 at p2 = 2048; a phase with an odd number of stages ends with the single stage j = 1
 #pragma unroll 1
   for (uint32_t k = 2; k <= p2; k <<= 1) {
 #pragma unroll 1
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+    for (uint32_t j = k >> 1; j > 0;) {
       const bool wide = 2 * j > E;
       if (wide || prev_wide) __syncthreads();
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (mine) {
-        // comparators [w*E/2, (w+1)*E/2) touch only this wave's segment when !wide; for wide stages
-        // the same split is simply a partition of all p2/2 comparators
-        const uint32_t cbeg = w * (E >> 1), cend = cbeg + (E >> 1);
-        for (uint32_t c0 = cbeg + lane; c0 < cend; c0 += 256) bitonic_batch(a, c0, cend, j, k);
+      if (j >= 2) {
+        if (mine) {
+          // groups [w*E/4, (w+1)*E/4) touch only this wave's segment when !wide; for wide stages the same
+          // split is simply a partition of all p2/4 groups
+          const uint32_t gbeg = w * (E >> 2), gend = gbeg + (E >> 2);
+          for (uint32_t g0 = gbeg + lane; g0 < gend; g0 += 128) bitonic_batch4(a, g0, gend, j, k);
+        }
+        j >>= 2;
+      } else {
+        if (mine) {
+          const uint32_t cbeg = w * (E >> 1), cend = cbeg + (E >> 1);
+          for (uint32_t c0 = cbeg + lane; c0 < cend; c0 += 256) bitonic_batch(a, c0, cend, j, k);
+        }
+        j = 0;
       }
       prev_wide = wide;
     }
