@@ -13,6 +13,9 @@
 # C ABI is exercised through ctypes by tests/ (rayuela.jl_amd/*.py mirrors this file line by line).
 module RayuelaHIP
 
+# only quantize_rvq's singleton re-pick needs them (both are Rayuela.jl dependencies, Manifest.toml:79-83,135-139)
+import Clustering, Distances
+
 export quantize_pq, quantize_opq, quantize_rvq, linscan_pq, linscan_opq, linscan_lsq, linscan_cq, train_pq, train_opq, train_rvq
 
 # deps/build.jl:64-67 writes the library paths into deps/deps.jl; here one constant / env var.
@@ -231,7 +234,7 @@ end
 """
 function train_opq(X::Matrix{Float32}, m::Integer, h::Integer, niter::Integer, init::String, V::Bool=false; seed::Integer=0)
   d, n = size(X)
-  init in ("natural", "random") || error("Intialization \$init unknown")
+  init in ("natural", "random") || error("Intialization $init unknown")   # src/OPQ.jl:74
   Ccat = Vector{Float32}(undef, h * d)
   B    = Matrix{Int16}(undef, m, n)
   R    = Matrix{Float32}(undef, d, d)
