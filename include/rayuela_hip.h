@@ -170,7 +170,8 @@ int rq_dev_gram(float *G, const float *X, const float *CB, int64_t n, int d, voi
 /* train_pq (src/PQ.jl:68-99) and train_opq (src/OPQ.jl:49-139) on host pointers: X [n][d]; outputs
  * C (concat of the m [h][sub_i] codebooks), B1 [n][m] Int16 ONE-based, R [d][d] (memory image of Julia's R),
  * obj [niter+1], *error = qerror_pq of the result.  init: 0 "natural", 1 "random".  R0 / C0 may be NULL;
- * when given they replace the random initialisation (reproducible runs).  `seed` feeds the library's own
+ * when given they replace the random initialisation (same start; runs still differ at the 1e-4 level of the
+ * objective because the centre sums use order-dependent float atomics).  `seed` feeds the library's own
  * splitmix64 stream -- the reference uses Julia's global RNG, so equal seeds do not mean equal draws. */
 int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n, int d, int m, int h,
                 int niter, uint64_t seed);
