@@ -342,6 +342,10 @@ __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_
   uint64_t *tree = reinterpret_cast<uint64_t *>(lds + NS * 8 + NS * 4 + 128);   // splitters, BFS order
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __syncthreads();   // the previous user of `lds` is done
+  // number of splitters for this input: buckets of ~6-12 keys (fewer splitters = a shorter sample sort and
+  // search; the LDS areas are sized for the maximum, SS_NS)
+  const uint32_t depth = cnt >= 12000u ? 11u : cnt >= 6000u ? 10u : cnt >= 3000u ? 9u : 8u;
+  const uint32_t ns = 1u << depth;
   if (cnt <= NS) {
     // small input: the whole array is its own sample
     const uint32_t p2 = next_pow2(cnt);
@@ -357,18 +361,18 @@ __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_
   }
   unsigned long long t_s = SS_T();
   for (uint32_t i = tid; i < NS; i += NT) {
-    smp[i] = src[(uint32_t)(((uint64_t)i * cnt) >> 11)];
+    if (i < ns) smp[i] = src[(uint32_t)(((uint64_t)i * cnt) >> depth)];
     nxt[i] = 0;
   }
   if (tid == 0) { aux[16] = 0; aux[17] = 0; }
-  bitonic_sort_tiled(smp, NS, NT / 64, wave, lane, true);
-  // The 2047 splitters smp[0..2046] go into breadth-first (Eytzinger) order: a binary search over
-  // the SORTED array reads, at depth t, addresses that are all congruent modulo 2^(11-t) keys --
+  bitonic_sort_tiled(smp, ns, NT / 64, wave, lane, true);
+  // The ns-1 splitters smp[0..ns-2] go into breadth-first (Eytzinger) order: a binary search over
+  // the SORTED array reads, at depth t, addresses that are all congruent modulo 2^(depth-t) keys --
   // up to 64 distinct addresses in one LDS bank; in BFS order a level is contiguous.
-  for (uint32_t t = tid; t < NS; t += NT) {
+  for (uint32_t t = tid; t < ns; t += NT) {
     if (t) {
       const uint32_t lvl = 31u - (uint32_t)__builtin_clz(t), j = t - (1u << lvl);
-      tree[t] = smp[(((2u * j + 1u) << (10u - lvl))) - 1u];
+      tree[t] = smp[(((2u * j + 1u) << (depth - 1u - lvl))) - 1u];
     }
   }
   __syncthreads();
@@ -386,13 +390,13 @@ __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_
       k[u] = idx < cnt ? src[idx] : KEY_MAX;
       b[u] = 1;
     }
-#pragma unroll
-    for (int lvl = 0; lvl < 11; ++lvl) {
+#pragma unroll 1
+    for (uint32_t lvl = 0; lvl < depth; ++lvl) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) b[u] = 2u * b[u] + (uint32_t)(tree[b[u]] <= k[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) b[u] -= NS;
+    for (int u = 0; u < 4; ++u) b[u] -= ns;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint32_t idx = i0 + u * NT + tid;
