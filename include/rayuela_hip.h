@@ -178,14 +178,46 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
 int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, int64_t n, int d, int m,
                  int h, int niter, int init, uint64_t seed, const float *R0, const float *C0);
 
-/* ---- device-resident index handle (codes uploaded once; used by the Julia shim's
- * optional fast path and by multi-GPU deployments, one handle per process/GPU) ------------- */
+/* ---- device-resident index handle: codes uploaded once, searched many times -- on one device, or
+ * row-sharded over the GPUs of a node from ONE host process (what a Julia session is).
+ * Replaces, for a resident base, the per-call marshalling of src/Linscan.jl:5-26; the reference has no
+ * multi-device path (its only long-axis device is the 1e7-row chunking of deps/src/linscan_aqd.cpp:52-53).
+ *   rq_index_create          one shard on the calling thread's current device
+ *   rq_index_create_sharded  one shard per entry of devices[0..ndev); a device listed twice holds two
+ *                            LOGICAL shards.  Every device scans its rows for all queries on its own
+ *                            stream; the per-shard top-k key lists are gathered to devices[0] over xGMI
+ *                            (RCCL send/recv on a single-process ncclCommInitAll clique, or
+ *                            hipMemcpyPeerAsync when tuning EXCHANGE_PEER=1 / librccl is absent) and merged
+ *                            there.  (dist, id) keys are totally ordered and ids are global, so the result
+ *                            is bit-identical to one scan of the whole base.
+ *   rq_index_set_codes       rows are split into contiguous shards whose sizes differ by at most one;
+ *                            ids returned by searches are id_offset + row (+ id_base)
+ *   rq_index_set_codes_synth SIFT1B-shape synthetic base generated on the devices:
+ *                            code[i][j] = splitmix64(seed ^ (i*m+j)) >> 56
+ *   rq_index_search[_opq]    linscan_pq / linscan_opq (src/Linscan.jl:5-26, 93-103) against the resident base;
+ *                            host pointers, synchronous, 1 <= k <= min(n, RQ_MAX_K)
+ *   rq_index_info            out[0] shards, [1] distinct devices, [2] exchange (0 none, 1 peer copies, 2 RCCL),
+ *                            [3] rows, [4..] rows per shard (as many as fit in cap)
+ * The host-pointer calls rq_linscan_pq / rq_linscan_opq / linscan_aqd_query build such an index for the
+ * duration of the call when the environment variable RAYUELA_HIP_DEVICES lists more than one device
+ * ("0,1,2,3" or "all"), so the stock Julia signatures use every GPU without a code change. */
 typedef struct rq_index rq_index;
 rq_index *rq_index_create(int m, int d, const float *centers_host);
+rq_index *rq_index_create_sharded(int m, int d, const float *centers_host, const int *devices, int ndev);
 int rq_index_set_codes(rq_index *ix, const uint8_t *codes_host, int64_t n, uint32_t id_offset);
+int rq_index_set_codes_synth(rq_index *ix, int64_t n, uint64_t seed, uint32_t id_offset);
 int rq_index_search(rq_index *ix, float *dists, uint32_t *ids, const float *queries_host,
                     int64_t nq, int k, int id_base);
+int rq_index_search_opq(rq_index *ix, float *dists, uint32_t *ids, const float *queries_host,
+                        const float *R_host, int64_t nq, int k, int id_base);
+int rq_index_info(rq_index *ix, int64_t *out, int cap);
 void rq_index_destroy(rq_index *ix);
+
+/* Threading: every entry point may be called from any host thread.  Library scratch is keyed by
+ * (device, stream) and the launch sequences of one device are serialised internally, so concurrent
+ * calls on different streams or devices do not interfere; at most 8 distinct streams per device may
+ * use the rq_dev_* calls before rq_release_workspaces() (which frees the current device's scratch). */
+int rq_release_workspaces(void);
 
 /* Diagnostic knob used by tests and tuning runs (same effect as env RQ_<KEY>):
  *   SCAN_SLICES  force the number of row slices per shard (0 = automatic)

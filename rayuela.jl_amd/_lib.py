@@ -57,7 +57,12 @@ SIGNATURES = {
     "rq_train_pq": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _u64]),
     "rq_train_opq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _u64, _vp, _vp]),
     "rq_index_create": (_vp, [_i32, _i32, _vp]),
+    "rq_index_create_sharded": (_vp, [_i32, _i32, _vp, _vp, _i32]),
     "rq_index_set_codes": (_i32, [_vp, _vp, _i64, _u32]),
+    "rq_index_set_codes_synth": (_i32, [_vp, _i64, _u64, _u32]),
+    "rq_index_search_opq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
+    "rq_index_info": (_i32, [_vp, _vp, _i32]),
+    "rq_release_workspaces": (_i32, []),
     "rq_index_search": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rq_index_destroy": (None, [_vp]),
     "rq_set_tuning": (_i32, [C.c_char_p, _i32]),

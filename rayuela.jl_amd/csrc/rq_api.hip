@@ -24,6 +24,10 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
+void set_timing(double total_ms, double h2d_ms, double kernel_ms, double d2h_ms) {
+  g_t_total = total_ms; g_t_h2d = h2d_ms; g_t_kernel = kernel_ms; g_t_d2h = d2h_ms;
+}
+
 int fail_hip(hipError_t e, const char *what, const char *file, int line) {
   snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d in `%s`", (int)e, hipGetErrorString(e), file,
            line, what);
@@ -49,11 +53,23 @@ int tuning(const char *key, int dflt) {
 }
 
 // ---- device context -----------------------------------------------------------------------------
+// Scratch is keyed by (device, stream): two streams of one device never share candidate buffers or
+// work counters, so concurrent rq_dev_* calls on different streams cannot corrupt each other.  The
+// launch mutex serialises the memset + launch sequences of one device across host threads (a second
+// thread's counter reset must not slip between another call's reset and its kernel).
+constexpr int MAX_STREAM_WS = 8;
+struct StreamWs {
+  hipStream_t stream = nullptr;
+  bool used = false;
+  void *ws[WS_SLOTS] = {nullptr};
+  size_t ws_bytes[WS_SLOTS] = {0};
+};
 struct DevCtx {
   bool inited = false;
   DeviceInfo info;
-  void *ws[WS_SLOTS] = {nullptr};
-  size_t ws_bytes[WS_SLOTS] = {0};
+  StreamWs sw[MAX_STREAM_WS];
+  std::recursive_mutex launch_mu;
+  hipStream_t aux[2] = {nullptr, nullptr};   // compute / transfer streams of the host-pointer calls
 };
 static DevCtx g_dev[16];
 
@@ -78,24 +94,92 @@ int device_info(DeviceInfo *out) {
   return RQ_OK;
 }
 
-int workspace(int slot, size_t bytes, void **ptr) {
+// The device's persistent (compute, transfer) stream pair; callers hold the DeviceLock.
+int aux_streams(hipStream_t *cs, hipStream_t *xs) {
   int dev = 0;
   RQ_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_mu);
   DevCtx &c = g_dev[dev];
-  if (c.ws_bytes[slot] < bytes) {
-    if (c.ws[slot]) {
+  for (int i = 0; i < 2; ++i)
+    if (!c.aux[i]) RQ_HIP(hipStreamCreateWithFlags(&c.aux[i], hipStreamNonBlocking));
+  *cs = c.aux[0];
+  *xs = c.aux[1];
+  return RQ_OK;
+}
+
+DeviceLock::DeviceLock() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); dev = 0; }
+  mu_ = &g_dev[dev].launch_mu;
+  static_cast<std::recursive_mutex *>(mu_)->lock();
+}
+DeviceLock::~DeviceLock() { static_cast<std::recursive_mutex *>(mu_)->unlock(); }
+
+int workspace(int slot, size_t bytes, void **ptr, hipStream_t stream) {
+  int dev = 0;
+  RQ_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevCtx &c = g_dev[dev];
+  StreamWs *w = nullptr;
+  for (int i = 0; i < MAX_STREAM_WS && !w; ++i)
+    if (c.sw[i].used && c.sw[i].stream == stream) w = &c.sw[i];
+  for (int i = 0; i < MAX_STREAM_WS && !w; ++i)
+    if (!c.sw[i].used) { w = &c.sw[i]; w->used = true; w->stream = stream; }
+  if (!w)
+    return fail(RQ_EUNSUPPORTED, "more than %d distinct streams have used device %d (rq_release_workspaces frees them)",
+                MAX_STREAM_WS, dev);
+  if (w->ws_bytes[slot] < bytes) {
+    if (w->ws[slot]) {
       RQ_HIP(hipDeviceSynchronize());
-      RQ_HIP(hipFree(c.ws[slot]));
-      c.ws[slot] = nullptr;
-      c.ws_bytes[slot] = 0;
+      RQ_HIP(hipFree(w->ws[slot]));
+      w->ws[slot] = nullptr;
+      w->ws_bytes[slot] = 0;
     }
     size_t want = bytes + bytes / 4;
     want = (want + 255) & ~(size_t)255;
-    RQ_HIP(hipMalloc(&c.ws[slot], want));
-    c.ws_bytes[slot] = want;
+    RQ_HIP(hipMalloc(&w->ws[slot], want));
+    w->ws_bytes[slot] = want;
   }
-  *ptr = c.ws[slot];
+  *ptr = w->ws[slot];
+  return RQ_OK;
+}
+
+// Free the scratch of one stream of the current device (called before the stream is destroyed).
+int release_stream_workspace(hipStream_t stream) {
+  int dev = 0;
+  RQ_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevCtx &c = g_dev[dev];
+  for (int i = 0; i < MAX_STREAM_WS; ++i) {
+    if (!c.sw[i].used || c.sw[i].stream != stream) continue;
+    RQ_HIP(hipStreamSynchronize(stream));
+    for (int s = 0; s < WS_SLOTS; ++s) {
+      if (c.sw[i].ws[s]) (void)hipFree(c.sw[i].ws[s]);
+      c.sw[i].ws[s] = nullptr;
+      c.sw[i].ws_bytes[s] = 0;
+    }
+    c.sw[i].used = false;
+    c.sw[i].stream = nullptr;
+  }
+  return RQ_OK;
+}
+
+// Free every scratch buffer of the current device (streams that were destroyed leave theirs behind).
+int release_workspaces() {
+  int dev = 0;
+  RQ_HIP(hipGetDevice(&dev));
+  RQ_HIP(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevCtx &c = g_dev[dev];
+  for (int i = 0; i < MAX_STREAM_WS; ++i) {
+    for (int s = 0; s < WS_SLOTS; ++s) {
+      if (c.sw[i].ws[s]) (void)hipFree(c.sw[i].ws[s]);
+      c.sw[i].ws[s] = nullptr;
+      c.sw[i].ws_bytes[s] = 0;
+    }
+    c.sw[i].used = false;
+    c.sw[i].stream = nullptr;
+  }
   return RQ_OK;
 }
 
@@ -118,9 +202,9 @@ struct Timer {
 };
 
 // ---- shared implementation of the scan on device pointers --------------------------------------------
-static int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes, const float *centers,
-                       const float *queries, int64_t n, int64_t nq, int m, int d, int k, uint32_t id_offset,
-                       int id_base, hipStream_t stream, int lut_mode = LUT_PQ, const float *row_bias = nullptr) {
+int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes, const float *centers,
+                const float *queries, int64_t n, int64_t nq, int m, int d, int k, uint32_t id_offset,
+                int id_base, hipStream_t stream, int lut_mode, const float *row_bias) {
   if (nq <= 0) return RQ_OK;
   if (n < 1 || n >= (1LL << 31)) return fail(RQ_EINVAL, "n=%lld must be in [1, 2^31)", (long long)n);
   if (lut_mode < LUT_PQ || lut_mode > LUT_CQ) return fail(RQ_EINVAL, "lut_mode=%d", lut_mode);
@@ -134,28 +218,29 @@ static int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_
   if (((uintptr_t)codes & 15) != 0) return fail(RQ_EINVAL, "codes pointer must be 16-byte aligned");
   DeviceInfo di;
   RQ_TRY(device_info(&di));
+  DeviceLock launch_lock;   // workspace lookup + counter reset + launches of this device: one thread at a time
   const int mp = scan_padded_m(m);
   if (mp < 0) return fail(RQ_EUNSUPPORTED, "the ADC scan kernels cover 1 <= m <= 64 sub-quantizers; got m=%d", m);
   if (mp != m) {
     // row width not one of the tiled ones: zero-pad the rows (padding tables are all zero, so the
     // sequential sum is unchanged bit for bit)
     void *padded = nullptr;
-    RQ_TRY(workspace(WS_PAD, (size_t)n * mp, &padded));
+    RQ_TRY(workspace(WS_PAD, (size_t)n * mp, &padded, stream));
     RQ_TRY(pad_codes_launch((uint8_t *)padded, codes, n, m, mp, stream));
     codes = (const uint8_t *)padded;
   }
   ScanPlan pl;
   RQ_TRY(scan_plan(pl, n, nq, m, d, k, di.num_cu, tuning("SCAN_SLICES", 0)));
   void *cand = nullptr, *counter = nullptr;
-  RQ_TRY(workspace(WS_CAND, pl.cand_bytes, &cand));
-  RQ_TRY(workspace(WS_COUNTER, 256, &counter));
+  RQ_TRY(workspace(WS_CAND, pl.cand_bytes, &cand, stream));
+  RQ_TRY(workspace(WS_COUNTER, 256, &counter, stream));
   // whole items write the answer (or final keys) themselves; the sliced tail leaves per-slice key lists
   // that merge_topk turns into the same outputs for those queries
   const int64_t q_tail = std::min<int64_t>(nq, (int64_t)pl.whole * pl.qg);
   const bool sliced = pl.nslices > 1 && q_tail < nq;
   const bool both = keys && (dists || ids);      // keys requested together with dists/ids: unpack at the end
   void *part = nullptr;
-  if (sliced) RQ_TRY(workspace(WS_KEYS, (size_t)(nq - q_tail) * pl.nslices * k * sizeof(uint64_t), &part));
+  if (sliced) RQ_TRY(workspace(WS_KEYS, (size_t)(nq - q_tail) * pl.nslices * k * sizeof(uint64_t), &part, stream));
   RQ_TRY(scan_launch(pl, both ? nullptr : dists, both ? nullptr : ids, keys, (uint64_t *)part, codes, centers, queries,
                      n, nq, m, d, k, id_offset, id_base, (uint32_t *)counter, (uint64_t *)cand, stream, lut_mode,
                      row_bias));
@@ -189,18 +274,15 @@ static int scan_and_fetch(float *dists, uint32_t *ids, float *dd, uint32_t *di, 
     return RQ_OK;
   }
   struct Streams {
-    hipStream_t cs = nullptr, xs = nullptr;
+    hipStream_t cs = nullptr, xs = nullptr;   // the device's cached pair (compute, transfer): not owned
     hipEvent_t ev[2] = {nullptr, nullptr};
     ~Streams() {
       if (ev[0]) (void)hipEventDestroy(ev[0]);
       if (ev[1]) (void)hipEventDestroy(ev[1]);
-      if (cs) (void)hipStreamDestroy(cs);
-      if (xs) (void)hipStreamDestroy(xs);
     }
   } st;
   RQ_HIP(hipDeviceSynchronize());   // the uploads on the null stream are done
-  RQ_HIP(hipStreamCreateWithFlags(&st.cs, hipStreamNonBlocking));
-  RQ_HIP(hipStreamCreateWithFlags(&st.xs, hipStreamNonBlocking));
+  RQ_TRY(aux_streams(&st.cs, &st.xs));
   RQ_HIP(hipEventCreateWithFlags(&st.ev[0], hipEventDisableTiming));
   RQ_HIP(hipEventCreateWithFlags(&st.ev[1], hipEventDisableTiming));
   Timer t2;
@@ -236,8 +318,22 @@ static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const
   if (nq <= 0) return RQ_OK;
   if (n < 1 || m < 1 || d < m || d % m) return fail(RQ_EINVAL, "bad shape n=%lld m=%d d=%d", (long long)n, m, d);
   if (k < 1 || k > n) return fail(RQ_EINVAL, "k=%d must be in [1, n=%lld]", k, (long long)n);
+  {
+    // RAYUELA_HIP_DEVICES lists more than one entry: row-shard the base over those devices (rq_index.hip)
+    int devs[64];
+    const int nd = env_devices(devs, 64);
+    if (nd > 1) {
+      const int rc = host_linscan_sharded(dists, ids, codes, centers, queries, R, n, nq, m, d, k, id_base, devs, nd);
+      double tot, a, b, c;
+      rq_last_timing(&tot, &a, &b, &c);
+      set_timing(tt.ms(), a, b, c);
+      return rc;
+    }
+    if (nd == 1) RQ_HIP(hipSetDevice(devs[0]));
+  }
   DeviceInfo di;
   RQ_TRY(device_info(&di));
+  DeviceLock call_lock;   // host-pointer calls on one device run one at a time (shared scratch + streams)
   DevBuf dcodes, dcent, dq, dr, drq, dd, di_;
   const size_t cb = (size_t)n * m, ce = (size_t)m * 256 * (d / m) * 4, qb = (size_t)nq * d * 4;
   RQ_TRY(dcodes.alloc(cb)); RQ_TRY(dcent.alloc(ce)); RQ_TRY(dq.alloc(qb));
@@ -281,6 +377,7 @@ static int host_linscan_aq(float *dists, uint32_t *ids, const uint8_t *codes, co
   if (lut_mode == LUT_LSQ && !dbnorms) return fail(RQ_EINVAL, "dbnorms is NULL");
   DeviceInfo di;
   RQ_TRY(device_info(&di));
+  DeviceLock call_lock;   // host-pointer calls on one device run one at a time (shared scratch + streams)
   DevBuf dcodes, dcb, dq, dn, dr, drq, dd, di_;
   const size_t cb = (size_t)n * m, ce = (size_t)m * 256 * d * 4, qb = (size_t)nq * d * 4;
   RQ_TRY(dcodes.alloc(cb)); RQ_TRY(dcb.alloc(ce)); RQ_TRY(dq.alloc(qb));
@@ -324,6 +421,7 @@ static int host_encode(uint8_t *codes, int16_t *codes1, const float *X, const fl
   if (d < 1 || m < 1 || h < 1) return fail(RQ_EINVAL, "bad shape d=%d m=%d h=%d", d, m, h);
   DeviceInfo di;
   RQ_TRY(device_info(&di));
+  DeviceLock call_lock;   // host-pointer calls on one device run one at a time (shared scratch + streams)
   // chunk the rows so X never needs more than ~1 GiB of device memory per chunk
   const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (1LL << 30) / ((int64_t)d * 4)));
   DevBuf dX, dRX, dR, dC, dcodes, d16;
@@ -367,14 +465,6 @@ static int host_encode(uint8_t *codes, int16_t *codes1, const float *X, const fl
 
 using namespace rq;
 
-struct rq_index {
-  int m, d, device;
-  int64_t n;
-  uint32_t id_offset;
-  float *centers;
-  uint8_t *codes;
-};
-
 extern "C" {
 
 const char *rq_version(void) { return "rayuela-hip 0.1 (gfx950)"; }
@@ -414,11 +504,13 @@ int rq_scan_plan(int64_t n, int64_t nq, int m, int d, int k, int num_cu, int64_t
 int rq_scan_stats(unsigned long long *out8) {
   // diagnostics: phase cycle counters of the last scan launched with tuning SCAN_STATS=1
   void *counter = nullptr;
-  RQ_TRY(workspace(WS_COUNTER, 256, &counter));
+  RQ_TRY(workspace(WS_COUNTER, 256, &counter, nullptr));
   RQ_HIP(hipDeviceSynchronize());
   RQ_HIP(hipMemcpy(out8, (char *)counter + 64, 96, hipMemcpyDeviceToHost));
   return RQ_OK;
 }
+
+int rq_release_workspaces(void) { return release_workspaces(); }
 
 int rq_last_timing(double *total_ms, double *h2d_ms, double *kernel_ms, double *d2h_ms) {
   if (total_ms) *total_ms = g_t_total;
@@ -534,7 +626,7 @@ int rq_dev_encode_opq(uint8_t *codes, const float *X, const float *R, const floa
   DeviceInfo di;
   RQ_TRY(device_info(&di));
   void *tmp = nullptr;
-  RQ_TRY(workspace(WS_TMP, (size_t)n * d * 4, &tmp));
+  RQ_TRY(workspace(WS_TMP, (size_t)n * d * 4, &tmp, (hipStream_t)stream));
   RQ_TRY(rotate_launch((float *)tmp, R, X, d, n, di.num_cu, (hipStream_t)stream));
   return encode_launch(codes, (const float *)tmp, C, n, d, m, h, di.num_cu, (hipStream_t)stream);
 }
@@ -546,7 +638,7 @@ int rq_dev_encode_rvq(uint8_t *codes, float *Xr, const float *codebooks, int64_t
   DeviceInfo di;
   RQ_TRY(device_info(&di));
   void *tmp = nullptr;
-  RQ_TRY(workspace(WS_TMP, (size_t)n, &tmp));
+  RQ_TRY(workspace(WS_TMP, (size_t)n, &tmp, (hipStream_t)stream));
   return rvq_encode_launch(codes, Xr, (uint8_t *)tmp, counts, codebooks, n, d, m, h, di.num_cu, (hipStream_t)stream);
 }
 
@@ -559,6 +651,7 @@ static int host_encode_rvq(uint8_t *codes, int16_t *codes1, const float *X, cons
   if (d < 1 || m < 1 || h < 1 || h > 256) return fail(RQ_EINVAL, "rvq: bad shape d=%d m=%d h=%d", d, m, h);
   DeviceInfo di;
   RQ_TRY(device_info(&di));
+  DeviceLock call_lock;   // host-pointer calls on one device run one at a time (shared scratch + streams)
   const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (1LL << 30) / ((int64_t)d * 4)));
   DevBuf dX, dC, dcodes, dstage, d16, dcnt;
   RQ_TRY(dX.alloc((size_t)chunk * d * 4));
@@ -652,62 +745,6 @@ int rq_dev_gram(float *G, const float *X, const float *CB, int64_t n, int d, voi
   DeviceInfo di;
   RQ_TRY(device_info(&di));
   return gram_launch(G, X, CB, n, d, di.num_cu, (hipStream_t)stream);
-}
-
-rq_index *rq_index_create(int m, int d, const float *centers_host) {
-  if (m < 1 || d < m || d % m) { fail(RQ_EINVAL, "index: d %% m != 0"); return nullptr; }
-  rq_index *ix = new rq_index();
-  ix->m = m; ix->d = d; ix->n = 0; ix->id_offset = 0; ix->codes = nullptr; ix->centers = nullptr;
-  if (hipGetDevice(&ix->device) != hipSuccess) { delete ix; fail(RQ_ENODEVICE, "no device"); return nullptr; }
-  const size_t ce = (size_t)m * 256 * (d / m) * 4;
-  if (hipMalloc((void **)&ix->centers, ce) != hipSuccess ||
-      hipMemcpy(ix->centers, centers_host, ce, hipMemcpyHostToDevice) != hipSuccess) {
-    fail(RQ_ENODEVICE, "index: cannot upload the codebooks");
-    if (ix->centers) (void)hipFree(ix->centers);
-    delete ix;
-    return nullptr;
-  }
-  return ix;
-}
-
-int rq_index_set_codes(rq_index *ix, const uint8_t *codes_host, int64_t n, uint32_t id_offset) {
-  if (!ix) return fail(RQ_EINVAL, "index is NULL");
-  if (ix->codes) { RQ_HIP(hipFree(ix->codes)); ix->codes = nullptr; }
-  RQ_HIP(hipMalloc((void **)&ix->codes, (size_t)n * ix->m));
-  RQ_HIP(hipMemcpy(ix->codes, codes_host, (size_t)n * ix->m, hipMemcpyHostToDevice));
-  ix->n = n;
-  ix->id_offset = id_offset;
-  return RQ_OK;
-}
-
-int rq_index_search(rq_index *ix, float *dists, uint32_t *ids, const float *queries_host, int64_t nq, int k,
-                    int id_base) {
-  if (!ix || !ix->codes) return fail(RQ_EINVAL, "index has no codes");
-  if (nq <= 0) return RQ_OK;
-  Timer tt;
-  DevBuf dq, dd, di_;
-  RQ_TRY(dq.alloc((size_t)nq * ix->d * 4)); RQ_TRY(dd.alloc((size_t)nq * k * 4)); RQ_TRY(di_.alloc((size_t)nq * k * 4));
-  Timer t1;
-  RQ_HIP(hipMemcpy(dq.p, queries_host, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice));
-  g_t_h2d = t1.ms();
-  Timer t2;
-  RQ_TRY(dev_linscan(dd.as<float>(), di_.as<uint32_t>(), nullptr, ix->codes, ix->centers, dq.as<float>(), ix->n, nq,
-                     ix->m, ix->d, k, ix->id_offset, id_base, nullptr));
-  RQ_HIP(hipDeviceSynchronize());
-  g_t_kernel = t2.ms();
-  Timer t3;
-  RQ_HIP(hipMemcpy(dists, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-  RQ_HIP(hipMemcpy(ids, di_.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-  g_t_d2h = t3.ms();
-  g_t_total = tt.ms();
-  return RQ_OK;
-}
-
-void rq_index_destroy(rq_index *ix) {
-  if (!ix) return;
-  if (ix->codes) (void)hipFree(ix->codes);
-  if (ix->centers) (void)hipFree(ix->centers);
-  delete ix;
 }
 
 }  // extern "C"

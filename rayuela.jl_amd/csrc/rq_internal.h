@@ -35,10 +35,28 @@ struct DeviceInfo {
 };
 int device_info(DeviceInfo *out);
 
-// Grow-only per-device scratch, owned by the library.  Calls on one device are expected to be
-// issued from one stream at a time (the host-pointer API serialises them itself).
-int workspace(int slot, size_t bytes, void **ptr);
+// Grow-only scratch owned by the library, keyed by (current device, stream): launches on different
+// streams never share a buffer.  At most 8 distinct streams per device (release_workspaces() resets).
+int workspace(int slot, size_t bytes, void **ptr, hipStream_t stream);
+int release_workspaces();
+int release_stream_workspace(hipStream_t stream);
+int aux_streams(hipStream_t *compute, hipStream_t *transfer);
 enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_PAD = 4, WS_MERGE = 5, WS_SLOTS = 6 };
+
+// Per-device launch lock (recursive): held while a call looks up scratch, resets the work counter and
+// launches, so two host threads cannot interleave those sequences on one device.
+class DeviceLock {
+ public:
+  DeviceLock();
+  ~DeviceLock();
+  DeviceLock(const DeviceLock &) = delete;
+  DeviceLock &operator=(const DeviceLock &) = delete;
+ private:
+  void *mu_;
+};
+
+// Milliseconds reported by rq_last_timing() for the calling thread.
+void set_timing(double total_ms, double h2d_ms, double kernel_ms, double d2h_ms);
 
 // ---- ADC scan -------------------------------------------------------------------------------
 struct ScanPlan {
@@ -54,6 +72,12 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
                 hipStream_t stream, int lut_mode = 0, const float *row_bias = nullptr);
 enum { LUT_PQ = 0, LUT_LSQ = 1, LUT_CQ = 2 };
+// argument checks + planner + launches of one resident shard (rq_dev_linscan's body)
+int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes, const float *centers,
+                const float *queries, int64_t n, int64_t nq, int m, int d, int k, uint32_t id_offset,
+                int id_base, hipStream_t stream, int lut_mode = LUT_PQ, const float *row_bias = nullptr);
+// [P][nq][k] -> [nq][P][k] (lists gathered shard-major, merged query-major)
+int interleave_keys_launch(uint64_t *dst, const uint64_t *src, int64_t nq, int P, int k, hipStream_t stream);
 int scan_padded_m(int m);   // smallest tiled row width >= m (2,4,8,16,32,64) or -1
 int pad_codes_launch(uint8_t *dst, const uint8_t *src, int64_t n, int m, int mp, hipStream_t stream);
 int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t *keys_in, int64_t nq,
@@ -61,6 +85,12 @@ int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t
 int lut_launch(float *lut, const float *centers, const float *queries, int64_t nq, int m, int sub,
                hipStream_t stream);
 int synth_codes_launch(uint8_t *codes, int64_t n, int m, uint64_t seed, int64_t row0, hipStream_t stream);
+
+// ---- multi-device (rq_index.hip) ---------------------------------------------------------------
+int env_devices(int *out, int cap);   // RAYUELA_HIP_DEVICES -> device list (0 entries = unset)
+int host_linscan_sharded(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers, const float *queries,
+                         const float *R, int64_t n, int64_t nq, int m, int d, int k, int id_base, const int *devices,
+                         int ndev);
 
 // ---- encode / rotation ----------------------------------------------------------------------
 int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m, int h,

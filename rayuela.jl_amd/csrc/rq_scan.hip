@@ -929,7 +929,7 @@ int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t
     const uint32_t grid = (uint32_t)std::min<int64_t>(nq, 2LL * num_cu);
     const size_t per_wg = (size_t)P * K;
     void *ws = nullptr;
-    RQ_TRY(workspace(WS_MERGE, (size_t)grid * per_wg * (sizeof(uint64_t) + sizeof(uint16_t)) + 16, &ws));
+    RQ_TRY(workspace(WS_MERGE, (size_t)grid * per_wg * (sizeof(uint64_t) + sizeof(uint16_t)) + 16, &ws, stream));
     uint64_t *scratch = (uint64_t *)ws;
     uint16_t *bkt = (uint16_t *)(scratch + (size_t)grid * per_wg);
     RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(merge_topk_big_kernel),

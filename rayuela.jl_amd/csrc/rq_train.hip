@@ -198,7 +198,7 @@ int update_centers_launch(float *C, unsigned int *counts, const float *X, const 
   fill_offsets(p.off, d, m);
   const int grid = (int)std::min<int64_t>(num_cu, (n + 1023) / 1024);
   void *part = nullptr;
-  RQ_TRY(workspace(WS_TMP, (size_t)grid * ((size_t)h * d + (size_t)m * h) * sizeof(float), &part));
+  RQ_TRY(workspace(WS_TMP, (size_t)grid * ((size_t)h * d + (size_t)m * h) * sizeof(float), &part, stream));
   p.partial = (float *)part;
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(centers_partial_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -240,7 +240,7 @@ int gram_launch(float *G, const float *X, const float *CB, int64_t n, int d, int
   constexpr int NW = 16;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(num_cu, (n + 255) / 256));
   void *part = nullptr;
-  RQ_TRY(workspace(WS_TMP, (size_t)grid * d * d * sizeof(float), &part));
+  RQ_TRY(workspace(WS_TMP, (size_t)grid * d * d * sizeof(float), &part, stream));
   p.partial = (float *)part;
   hipLaunchKernelGGL(gram_partial_kernel<NW>, dim3(grid), dim3(NW * 64), 0, stream, p);
   RQ_HIP(hipGetLastError());

@@ -193,6 +193,7 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
   RQ_TRY(check_train(n, d, m, h, niter));
   DeviceInfo di;
   RQ_TRY(device_info(&di));
+  DeviceLock call_lock;
   int off[33];
   offsets(off, d, m);
   Rng rng{seed * 0x9E3779B97F4A7C15ull + 1};
@@ -243,6 +244,7 @@ int rq_train_rvq(float *C, int16_t *B1, double *error, const float *X, int64_t n
   if (n < h) return fail(RQ_EINVAL, "train_rvq: fewer training vectors (%lld) than codebook entries (%d)", (long long)n, h);
   DeviceInfo di;
   RQ_TRY(device_info(&di));
+  DeviceLock call_lock;
   int off1[2] = {0, d};
   Rng rng{seed * 0x9E3779B97F4A7C15ull + 3};
   DevMem dXr, dCi, dstage, dcnt, dcodes, dacc, d16;
@@ -291,6 +293,7 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
   if (init != 0 && init != 1) return fail(RQ_EINVAL, "train_opq: init must be 0 (natural) or 1 (random)");
   DeviceInfo di;
   RQ_TRY(device_info(&di));
+  DeviceLock call_lock;
   int off[33];
   offsets(off, d, m);
   Rng rng{seed * 0x9E3779B97F4A7C15ull + 2};

@@ -1,0 +1,149 @@
+"""GPU parity tests of the multi-device index behind the C ABI (rq_index_*): a base cut into several
+shards -- here LOGICAL shards of the one GPU the box has, the same code path as distinct devices up to the
+transport -- must return exactly what one scan of the whole base returns: ids and distance bits."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("nshards", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("name", ["scan_sift_mini", "scan_deep_mini", "scan_dups", "scan_all_ties"])
+def test_logical_shards_equal_reference_golden(rq, name, nshards):
+    g = golden(name)
+    m = g["codes"].shape[1]
+    d = g["queries"].shape[1]
+    C = [g["centers"][i] for i in range(m)]
+    with rq.Index(C, d, devices=[0] * nshards) as ix:
+        ix.set_codes(g["codes"])
+        info = ix.info()
+        assert info["shards"] == nshards and info["devices"] == 1 and sum(info["rows_per_shard"]) == g["codes"].shape[0]
+        for K in g["Ks"]:
+            dists, ids = ix.search(g["queries"], int(K), id_base=0)
+            assert np.array_equal(ids, g["ids_K%d" % K]), (name, nshards, K)
+            assert _eq_bits(dists, g["dists_K%d" % K]), (name, nshards, K)
+
+
+def test_shards_shorter_than_k_and_empty_shards(rq, oracle):
+    """n = 37 rows over 8 shards (4-5 rows each) with k = 20 > every shard, and n = 5 over 8 shards (3 empty)."""
+    import rayuela_jl_amd.synth as synth
+    m, d = 8, 32
+    X = synth.sift_like(2000, d, seed=5)
+    C = synth.codebooks(X, m, 256, seed=6, iters=1, sample=2000)
+    Q = synth.sift_like(9, d, seed=7)
+    for n, k in [(37, 20), (5, 5), (300, 64)]:
+        codes = synth.random_codes(n, m, seed=11 + n)
+        d0, i0 = oracle.linscan_aqd_query(codes, np.stack(C), Q, k)
+        with rq.Index(C, d, devices=[0] * 8) as ix:
+            ix.set_codes(codes)
+            dists, ids = ix.search(Q, k, id_base=0)
+        assert np.array_equal(ids, i0), (n, k)
+        assert _eq_bits(dists, d0), (n, k)
+
+
+@pytest.mark.parametrize("nshards", [3, 4])
+def test_sharded_equals_single_scan_large_k_and_offsets(rq, nshards):
+    """2e5 random rows, k = 1000 and k = 3000 (sample-sort finish + big merge), id_offset, one-based ids, OPQ."""
+    import rayuela_jl_amd.synth as synth
+    m, d, n, nq = 8, 64, 200_000, 40
+    X = synth.sift_like(4000, d, seed=21)
+    C = synth.codebooks(X, m, 256, seed=22, iters=1, sample=4000)
+    Q = synth.sift_like(nq, d, seed=23)
+    R = synth.rotation(d, seed=3)
+    codes = synth.random_codes(n, m, seed=99)
+    with rq.Index(C, d) as one, rq.Index(C, d, devices=[0] * nshards) as many:
+        one.set_codes(codes, id_offset=1000)
+        many.set_codes(codes, id_offset=1000)
+        for k in (1000, 3000):
+            d1, i1 = one.search(Q, k)
+            d2, i2 = many.search(Q, k)
+            assert np.array_equal(i1, i2) and _eq_bits(d1, d2), (nshards, k)
+            assert i1.min() >= 1001
+        d1, i1 = one.search(Q, 100, R=R)
+        d2, i2 = many.search(Q, 100, R=R)
+        assert np.array_equal(i1, i2) and _eq_bits(d1, d2)
+    # the handle's single-shard answer is the host-pointer API's answer
+    d3, i3 = rq.linscan_pq(codes, Q, C, 8 * m, 1000)
+    with rq.Index(C, d) as one:
+        one.set_codes(codes)
+        d1, i1 = one.search(Q, 1000)
+    assert np.array_equal(i1, i3) and _eq_bits(d1, d3)
+
+
+def test_synth_base_on_device_matches_host_generator(rq, oracle):
+    import rayuela_jl_amd.synth as synth
+    m, d, n, nq, k = 8, 128, 50_000, 16, 100
+    X = synth.sift_like(4000, d, seed=31)
+    C = synth.codebooks(X, m, 256, seed=32, iters=1, sample=4000)
+    Q = synth.sift_like(nq, d, seed=33)
+    codes = synth.random_codes(n, m, seed=synth.SEED_BASE)
+    d0, i0 = oracle.linscan_aqd_query(codes, np.stack(C), Q, k)
+    with rq.Index(C, d, devices=[0, 0, 0]) as ix:
+        ix.set_codes_synth(n, synth.SEED_BASE)
+        dists, ids = ix.search(Q, k, id_base=0)
+    assert np.array_equal(ids, i0) and _eq_bits(dists, d0)
+
+
+def test_env_device_list_shards_the_stock_entry_points(rq, monkeypatch):
+    """RAYUELA_HIP_DEVICES with more than one entry: linscan_pq / linscan_opq / the legacy symbol run the sharded path."""
+    g = golden("scan_sift_mini")
+    m = g["codes"].shape[1]
+    C = [g["centers"][i] for i in range(m)]
+    monkeypatch.setenv("RAYUELA_HIP_DEVICES", "0,0,0")
+    for K in g["Ks"]:
+        dists, ids = rq.linscan_aqd_query(g["codes"], g["centers"], g["queries"], int(K))
+        assert np.array_equal(ids, g["ids_K%d" % K]) and _eq_bits(dists, g["dists_K%d" % K])
+    dists, idx = rq.linscan_pq(g["codes"], g["queries"], C, 8 * m, 100)
+    assert np.array_equal(idx, g["ids_K100"] + 1) and _eq_bits(dists, g["dists_K100"])
+
+
+def test_index_argument_errors(rq):
+    g = golden("scan_sift_mini")
+    m = g["codes"].shape[1]
+    d = g["queries"].shape[1]
+    C = [g["centers"][i] for i in range(m)]
+    with pytest.raises(rq.RayuelaHipError):
+        rq.Index(C, d, devices=[0, 99])
+    with rq.Index(C, d, devices=[0, 0]) as ix:
+        with pytest.raises(rq.RayuelaHipError):
+            ix.search(g["queries"], 10)                       # no codes yet
+        ix.set_codes(g["codes"])
+        with pytest.raises(rq.RayuelaHipError):
+            ix.search(g["queries"], g["codes"].shape[0] + 1)  # k > n
+        with pytest.raises(rq.RayuelaHipError):
+            ix.search(g["queries"], 0)
+
+
+def test_two_host_threads_two_streams_do_not_interfere(rq):
+    """scratch is keyed by (device, stream) and launches are serialised per device."""
+    import threading
+    g = golden("scan_sift_mini")
+    m = g["codes"].shape[1]
+    d = g["queries"].shape[1]
+    C = [g["centers"][i] for i in range(m)]
+    errs = []
+
+    def worker(seed):
+        try:
+            with rq.Index(C, d, devices=[0, 0]) as ix:
+                ix.set_codes(g["codes"])
+                for _ in range(20):
+                    for K in (10, 1000):
+                        dists, ids = ix.search(g["queries"], K, id_base=0)
+                        if not (np.array_equal(ids, g["ids_K%d" % K]) and _eq_bits(dists, g["dists_K%d" % K])):
+                            errs.append((seed, K))
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:3]
