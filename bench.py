@@ -1,36 +1,48 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on MI355X: ADC queries/sec + encode vectors/sec at SIFT1M shape.
+"""bench.py -- BASELINE.json's metric on MI355X: ADC queries/sec + encode vectors/sec.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload pq|opq|deep] [--k 1000] [--nq 10000]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|pq|opq|deep|sift1b] [--k K] [--nq NQ]
 
-A "step" is one pass of the hot path over one batch of synthetic input that is already resident in
-HBM: (a) ADC scan + exact top-k of nq queries over the rank's 1e6-row shard (linscan_pq, the headline
-`value`), and, timed in its own bracket, (b) quantize_pq of the rank's 1e6 x d base (reported under
-"encode").  N > 1 ranks (one per GPU, RCCL): weak scaling -- every rank keeps a 1e6-row shard, so the
-base grows to N x 1e6 rows; the step then includes the all_to_all exchange of per-shard top-k keys, the
-merge and the gather to rank 0.  `value` counts one unit per (query x 1e6-row shard) processed, which at
-N = 1 is exactly queries/s against the SIFT1M-shape base.
+Workloads (BASELINE.json `configs`):
+  pq      SIFT1M-shape PQ  m=8 h=256: quantize_pq + linscan_pq            (config 2; default at N = 1)
+  opq     SIFT1M-shape OPQ m=8 h=256: rotation + encode + ADC               (config 3)
+  deep    Deep1M-shape OPQ d=96 m=16 h=256                                   (config 4)
+  sift1b  SIFT1B-shape base, 1e9 x 8 uint8 codes generated on the devices, nq=1024, k=100, rows sharded over
+          the N GPUs, per-shard top-k gathered over xGMI (RCCL) and merged    (config 5; default at N > 1)
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM: the ADC scan +
+exact top-k of nq queries over the WHOLE base (`value` = true queries/s against the whole base), and -- timed in
+its own bracket, reported under "encode" -- quantize_pq of the base.  N > 1 is STRONG scaling: the base is
+fixed and its rows are split over the ranks; a step then includes the exchange of per-shard top-k keys, the
+merge and the gather to rank 0.
+
+Launch: `python bench.py --gpus N` starts N ranks itself (python -m torch.distributed.run, one process per GPU,
+backend nccl == RCCL); started under torch.distributed.run it uses the ranks it is given.  `--inproc` runs the
+N-GPU search inside ONE process through the library's multi-device index (rq_index_create_sharded: what a Julia
+session gets) instead.
 
 Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
-  roofline      dominant kernel (ADC scan): algorithmic bytes nq*n*m per launch / measured launch time
-                vs the 8 TB/s HBM3E spec; LDS-gather bound quoted beside it
-  cpu_baseline  the reference's own deps/src/linscan_aqd.cpp (oracle/_ref, built by oracle/Makefile)
-                timed on this box's host cores on a bounded sample of the same workload
+  roofline      the dominant kernel (adc_scan_kernel) against the resource that binds it -- the LDS gather pipe:
+                algorithmic table bytes nq*n*m*4 per launch / kernel time vs 256 CU x 256 B/clk; the HBM side
+                (algorithmic code bytes nq*n*m and the PMC-measured traffic) is reported next to it
+  cpu_baseline  the reference's own deps/src/linscan_aqd.cpp (oracle/_ref, built by oracle/Makefile) timed on
+                this box's host cores on a bounded sample of the same workload
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TFLOPS = 157.3     # f32 MFMA == f32 vector peak
+NUM_CU, LDS_B_PER_CLK, CLK_GHZ = 256, 256, 2.4     # MI355X_MICROARCH.md section LDS: 256 B/clk/CU for ds_read_b128
+LDS_PEAK_GBS = NUM_CU * LDS_B_PER_CLK * CLK_GHZ    # 157 286 GB/s conflict-free
 
 
 def parse():
@@ -38,39 +50,36 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="pq", choices=["pq", "opq", "deep"])
-    ap.add_argument("--n", type=int, default=1_000_000, help="base rows per GPU")
-    ap.add_argument("--nq", type=int, default=10_000)
-    ap.add_argument("--k", type=int, default=1000)
+    ap.add_argument("--workload", default="auto", choices=["auto", "pq", "opq", "deep", "sift1b"])
+    ap.add_argument("--rows", dest="n", type=int, default=0, help="rows of the WHOLE base (default 1e6; sift1b: 1e9)")
+    ap.add_argument("--nq", type=int, default=0, help="queries per step (default 10000; sift1b: 1024)")
+    ap.add_argument("--k", type=int, default=0, help="neighbours (default 1000; sift1b: 100)")
+    ap.add_argument("--inproc", action="store_true", help="N GPUs from one process via rq_index_create_sharded")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-ref1", action="store_true", help="sift1b, N > 1: skip the same-workload single-GPU timing")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def make_data(n, nq, d, kind, rank, device):
-    """SIFT-like / Deep-like synthetic vectors generated on the device (seeded torch generator)."""
-    g = torch.Generator(device=device).manual_seed(1234 + 7919 * rank)
-    gq = torch.Generator(device=device).manual_seed(4321)
-    gc = torch.Generator(device=device).manual_seed(99)
-    if kind == "sift":
-        ncent = 65536   # ~15 base vectors per centre at 1e6 rows: near-duplicates like SIFT, but resolvable
-        cent = torch.randint(0, 128, (ncent, d), generator=gc, device=device).float()
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
-        def gen(rows, gen_):
-            cid = torch.randint(0, ncent, (rows,), generator=gen_, device=device)
-            noise = torch.randint(-16, 17, (rows, d, 4), generator=gen_, device=device).sum(-1).float()
-            return (cent[cid] + noise).clamp_(0, 255).contiguous()
-    else:
-        def gen(rows, gen_):
-            v = torch.rand((rows, d, 4), generator=gen_, device=device).sum(-1) - 2.0
-            return (v / v.norm(dim=1, keepdim=True)).float().contiguous()
-    X = torch.cat([gen(min(250_000, n - a), g) for a in range(0, n, 250_000)], 0)
-    Q = gen(nq, gq)
-    S = gen(20_000, gc)   # codebook training sample: identical on every rank
-    return X, Q, S
+
+def self_spawn(a):
+    """Plain `python bench.py --gpus N`: become N ranks, one per GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def timed(fn, steps, warmup, barrier):
+    import torch
     for _ in range(warmup):
         fn()
     barrier()
@@ -87,18 +96,74 @@ def timed(fn, steps, warmup, barrier):
     return e0.elapsed_time(e1), wall_ms
 
 
+def load_traffic(kernel_key):
+    """HBM/fabric bytes per launch of `kernel_key` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate runs; FETCH doubled per MI355X_MICROARCH.md section HBM)."""
+    for name in ("r2_traffic.json", "r1_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        if kernel_key in tj:
+            e = tj[kernel_key]
+            return 2.0 * e["FETCH_SIZE_KiB"] * 1024 + e["WRITE_SIZE_KiB"] * 1024, "profiles/%s (%s)" % (name, e.get("source", ""))
+    return None, None
+
+
+def scan_roofline(m, n_local, nq, K, kernel_ms):
+    """The ADC scan kernel against its binding resource.  Every (query, row, sub-quantizer) reads one 4-byte
+    table entry; ds_read_b128 delivers 256 B/clk/CU conflict-free, so the LDS-gather roof is
+    nq*n*m*4 B / (256 CU x 256 B/clk x 2.4 GHz).  HBM: algorithmic code bytes nq*n*m are shared
+    by the 8 queries of a group and mostly served by L2/MALL, so the PMC traffic is what reaches HBM."""
+    t = kernel_ms * 1e-3
+    table_bytes = float(nq) * n_local * m * 4.0
+    code_bytes = float(nq) * n_local * m
+    achieved = table_bytes / t / 1e9
+    traffic, src = load_traffic("adc_scan_kernel<%d> n=%d nq=%d k=%d" % (m, n_local, nq, K))
+    hbm = {"algorithmic_bytes_per_launch": code_bytes, "algorithmic_GBps": round(code_bytes / t / 1e9, 1),
+           "peak_GBps": HBM_PEAK_GBS, "traffic_bytes_per_launch": traffic, "traffic_source": src,
+           "traffic_GBps": None if traffic is None else round(traffic / t / 1e9, 1),
+           "frac_of_peak": None if traffic is None else round(traffic / t / 1e9 / HBM_PEAK_GBS, 4)}
+    return {"bound": "lds", "kernel": "adc_scan_kernel<%d>" % m, "achieved": round(achieved, 1), "peak": round(LDS_PEAK_GBS, 1),
+            "unit": "GB/s", "frac": round(achieved / LDS_PEAK_GBS, 4), "traffic": traffic,
+            "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": table_bytes,
+            "definition": "table bytes nq*n*m*4 per launch / kernel time vs %d CU x %d B/clk x %.1f GHz (conflict-free "
+                          "ds_read_b128); measured SQ_LDS_BANK_CONFLICT share in profiles/" % (NUM_CU, LDS_B_PER_CLK, CLK_GHZ),
+            "hbm": hbm}
+
+
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1 and not a.inproc:
+        sys.exit(self_spawn(a))
+    world = int(env_world) if env_world is not None and not a.inproc else 1
+    if not a.inproc and world != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; start it as `python bench.py --gpus N` or with "
+                         "torch.distributed.run --nproc-per-node N\n" % (a.gpus, world))
+        sys.exit(2)
+    rank = int(os.environ.get("RANK", "0")) if world > 1 else 0
+    local = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if torch.cuda.device_count() < (a.gpus if a.inproc else local + 1) and os.environ.get("RQ_BENCH_BACKEND") != "gloo":
+        sys.stderr.write("bench.py: %d GPUs requested, %d visible\n" % (a.gpus, torch.cuda.device_count()))
+        sys.exit(2)
+    # RQ_BENCH_BACKEND=gloo: debugging aid for a one-GPU box -- the ranks share the visible GPUs and the
+    # collectives run on host copies, so the N > 1 control flow can be exercised without N devices
+    debug_gloo = os.environ.get("RQ_BENCH_BACKEND") == "gloo"
+    if debug_gloo:
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if debug_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     def barrier():
         if world > 1:
@@ -106,94 +171,151 @@ def main():
 
     import rayuela_jl_amd as rq
     import rayuela_jl_amd.synth as synth
+    import rayuela_jl_amd.synth_torch as st
     from rayuela_jl_amd import device as rqd
-    from rayuela_jl_amd.sharded import ShardedIndex
+    from rayuela_jl_amd.sharded import ShardedIndex, shard_bounds
 
-    if a.workload == "deep":
-        d, m, kind, name = 96, 16, "deep", "Deep1M-shape OPQ d=96 m=16 h=256"
+    ngpu = a.gpus
+    wl = a.workload if a.workload != "auto" else ("pq" if ngpu == 1 else "sift1b")
+    big = wl == "sift1b"
+    if wl == "deep":
+        d, m, name = 96, 16, "Deep1M-shape OPQ d=96 m=16 h=256"
+    elif big:
+        d, m, name = 128, 8, "SIFT1B-shape base (synthetic uint8 codes) m=8 h=256"
     else:
-        d, m, kind = 128, 8, "sift"
-        name = "SIFT1M-shape %s m=8 h=256" % ("OPQ" if a.workload == "opq" else "PQ")
-    use_R = a.workload in ("opq", "deep")
-    h, n, nq, K = 256, a.n, a.nq, a.k
+        d, m = 128, 8
+        name = "SIFT1M-shape %s m=8 h=256" % ("OPQ" if wl == "opq" else "PQ")
+    use_R = wl in ("opq", "deep")
+    h = 256
+    n = a.n or (1_000_000_000 if big else 1_000_000)
+    nq = a.nq or (1024 if big else 10_000)
+    K = a.k or (100 if big else 1000)
+    nshards = ngpu
+    bounds = shard_bounds(n, nshards)
+    r0, r1 = (bounds[rank], bounds[rank + 1]) if not a.inproc else (0, n)
+    n_local = r1 - r0
 
-    X, Q, S = make_data(n, nq, d, kind, rank, device)
+    # ---- synthetic inputs: the splitmix64 generators of synth.py, run on the device --------------
+    def gen(rows, row0):
+        if wl == "deep":
+            return st.deep_like(rows, d, seed=synth.SEED_BASE, row0=row0, device=device)
+        return st.sift_like(rows, d, seed=synth.SEED_BASE, ncentres=65536, row0=row0, device=device)
+    # queries and the codebook training sample are rows of the same stream beyond any base row
+    Q = gen(nq, 3_000_000_000)
+    S = gen(20_000, 3_100_000_000)
     R = torch.from_numpy(synth.rotation(d)).to(device) if use_R else None
-    # codebooks: k-means on the (rotated, for OPQ) training sample -- harness side, untimed
     S_train = rqd.rotate_T(R, S) if use_R else S
-    C = synth.codebooks(S_train.cpu().numpy(), m, h, seed=synth.SEED_CODEBOOK, iters=5, sample=20000)
+    C = synth.codebooks(S_train.cpu().numpy(), m, h, seed=synth.SEED_CODEBOOK, iters=5, sample=20000)   # harness side, untimed
     Ccat = torch.from_numpy(synth.cat_codebooks(C)).to(device)
     centers = torch.from_numpy(np.stack(C)).to(device)
-
-    # ---- (b) encode: quantize_pq / quantize_opq of the resident base -----------------------------------
-    codes = torch.empty((n, m), dtype=torch.uint8, device=device)
-    if use_R:
-        enc = lambda: rqd.encode_opq(X, R, Ccat, m, h, out=codes)   # noqa: E731
-    else:
-        enc = lambda: rqd.encode_pq(X, Ccat, m, h, out=codes)       # noqa: E731
-    enc_ms, _ = timed(enc, a.steps, a.warmup, barrier)
-
-    # ---- (a) ADC scan + top-k -------------------------------------------------------------------------
     Qs = rqd.rotate_T(R, Q) if use_R else Q     # linscan_opq rotates the queries first (src/Linscan.jl:102)
-    if world == 1:
+
+    # ---- (b) encode: quantize_pq / quantize_opq of this rank's rows of the resident base -----------------------
+    enc_ms = None
+    X = None
+    if big:
+        codes = None if a.inproc else rqd.synth_codes(n_local, m, synth.SEED_BASE, row0=r0, device=device)
+    else:
+        X = torch.cat([gen(min(250_000, n_local - o), r0 + o) for o in range(0, n_local, 250_000)], 0)
+        codes = torch.empty((n_local, m), dtype=torch.uint8, device=device)
+        if use_R:
+            enc = lambda: rqd.encode_opq(X, R, Ccat, m, h, out=codes)   # noqa: E731
+        else:
+            enc = lambda: rqd.encode_pq(X, Ccat, m, h, out=codes)       # noqa: E731
+        enc_ms, _ = timed(enc, a.steps, a.warmup, barrier)
+
+    # ---- (a) ADC scan + top-k over the whole base ------------------------------------------------------------------
+    res = {}
+    ix_lib = None
+    if a.inproc:
+        ix_lib = rq.Index(C, d, devices=list(range(ngpu)))
+        if big:
+            ix_lib.set_codes_synth(n, synth.SEED_BASE)
+        else:
+            ix_lib.set_codes(codes.cpu().numpy())
+        Qh = Q.cpu().numpy()
+        Rh = None if R is None else R.cpu().numpy()
+
+        def scan():
+            res["r"] = ix_lib.search(Qh, K, R=Rh, id_base=0)
+    elif world == 1:
         out = (torch.empty((nq, K), dtype=torch.float32, device=device),
                torch.empty((nq, K), dtype=torch.int32, device=device))
-        scan = lambda: rqd.linscan(codes, centers, Qs, K, out=out)   # noqa: E731
+
+        def scan():
+            res["r"] = rqd.linscan(codes, centers, Qs, K, out=out)
     else:
-        ix = ShardedIndex(codes, centers, id_offset=rank * n)
-        res = {}
+        ix = ShardedIndex(codes, centers, id_offset=r0, host_staging=debug_gloo)
 
         def scan():
             res["r"] = ix.search(Qs, K)
     scan_ms, scan_wall = timed(scan, a.steps, a.warmup, barrier)
+    if a.inproc:
+        scan_ms = scan_wall      # the library's own streams do the work: host wall clock is the step time
 
-    t = torch.tensor([scan_ms, enc_ms, scan_wall], dtype=torch.float64, device=device)
+    # the scan kernel alone on this rank's shard (roofline): HIP events on the stream it is launched on
+    kern_ms = None
+    if not a.inproc:
+        kl = min(K, n_local)
+        kout = torch.empty((nq, kl), dtype=torch.int64, device=device)
+        kern_total, _ = timed(lambda: rqd.linscan(codes, centers, Qs, kl, id_offset=r0, want_keys=True, out=kout),
+                              max(2, min(a.steps, 10)), 1, barrier)
+        kern_ms = kern_total / max(2, min(a.steps, 10))
+
+    vals = [scan_ms, enc_ms or 0.0, scan_wall, kern_ms or 0.0]
     if world > 1:
+        t = torch.tensor(vals, dtype=torch.float64, device="cpu" if debug_gloo else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    scan_ms, enc_ms, scan_wall = [float(x) for x in t.tolist()]
+        vals = [float(x) for x in t.tolist()]
+    scan_ms, enc_ms_max, scan_wall, kern_ms_max = vals
     ms_step = scan_ms / a.steps
-    enc_ms_step = enc_ms / a.steps
-    qps = world * nq / (ms_step * 1e-3)
-    vps = world * n / (enc_ms_step * 1e-3)
+    qps = nq / (ms_step * 1e-3)                       # true queries/s against the whole n-row base
 
     if rank != 0:
         barrier()
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
-    # ---- roofline: algorithmic bytes per launch / measured launch time ---------------------
-    # HBM/fabric bytes per launch from the PMC passes of the same shape (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE, separate runs; FETCH doubled per MI355X_MICROARCH.md section HBM), committed under profiles/
-    traffic_bytes, traffic_src = None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-        key = "adc_scan_kernel<%d> n=%d nq=%d k=%d" % (m, n, nq, K)
-        if key in tj:
-            traffic_bytes = 2.0 * tj[key]["FETCH_SIZE_KiB"] * 1024 + tj[key]["WRITE_SIZE_KiB"] * 1024
-            traffic_src = "profiles/r1_traffic.json (%s)" % tj[key]["source"]
-    except Exception:
-        pass
-    scan_bytes = float(nq) * n * m                       # n*m code bytes per query
-    achieved = scan_bytes / (ms_step * 1e-3) / 1e9      # GB/s, per GPU
-    roof = {"bound": "hbm", "kernel": "adc_scan_kernel<%d>" % m, "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic_bytes, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": scan_bytes,
-            "note": "codes are read once per 8-query group, so algorithmic GB/s may exceed HBM; the binding "
-                    "resource is the LDS gather (ds_read_b128, 4 queries per gather)",
-            "lds_gathers_per_s": round(float(nq) * n * m / 4.0 / (ms_step * 1e-3), 1)}
-    enc_flops = 2.0 * d * h * n
-    enc_roof = {"bound": "mfma", "kernel": "encode_pq_kernel", "achieved": round(enc_flops / (enc_ms_step * 1e-3) / 1e12, 2),
-                "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(enc_flops / (enc_ms_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": None,
-                "hbm_GBps": round((4.0 * d + m) * n / (enc_ms_step * 1e-3) / 1e9, 1)}
-    if use_R:
-        enc_roof["note"] = "includes the R'X rotation kernel (2*d*d flop/vector more, not counted in achieved)"
+    # ---- roofline --------------------------------------------------------------------------------------------------
+    roof = scan_roofline(m, n_local, nq, min(K, n_local), kern_ms_max) if kern_ms is not None else None
+    encode = None
+    if enc_ms is not None:
+        enc_ms_step = enc_ms_max / a.steps
+        enc_flops = 2.0 * d * h * n_local           # per GPU
+        tf = enc_flops / (enc_ms_step * 1e-3) / 1e12
+        enc_roof = {"bound": "mfma", "kernel": "encode_pq_kernel", "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                    "hbm_GBps": round((4.0 * d + m) * n_local / (enc_ms_step * 1e-3) / 1e9, 1)}
+        if use_R:
+            enc_roof["note"] = "includes the R'X rotation kernel (2*d*d flop/vector more, not counted in achieved)"
+        encode = {"metric": "encode vectors/sec (%s)" % ("quantize_opq" if use_R else "quantize_pq"),
+                  "value": round(n / (enc_ms_step * 1e-3), 1), "unit": "vectors/s", "ms_per_step": round(enc_ms_step, 4),
+                  "roofline": enc_roof}
 
-    # ---- recall (sanity + parity: ids are bit-exact, so recall is identical by construction) ---------------
+    # ---- checks on the returned answer (size-independent) ----------------------------------------------------------
+    rd, ri = res["r"]
+    rd_h = rd.cpu().numpy() if hasattr(rd, "cpu") else rd
+    ri_h = (ri.cpu().numpy() if hasattr(ri, "cpu") else ri).view(np.uint32)
+    checks = {"ascending": bool((np.diff(rd_h, axis=1) >= 0).all()), "ids_in_range": bool(ri_h.max() < n),
+              "ids_unique_per_query": bool(all(len(np.unique(ri_h[q])) == K for q in range(min(nq, 64))))}
+    if big:
+        # regenerate the returned rows' codes from the hash (no device read) and redo their ADC sums on the host
+        from oracle import oracle
+        nchk = min(nq, 32)
+        qh = Qs[:nchk].cpu().numpy()
+        lut = np.stack([oracle.adc_lut(np.stack(C), qh[q]) for q in range(nchk)])       # [nchk][m][256], f32 like the reference
+        ids64 = ri_h[:nchk].astype(np.uint64)
+        e = ids64[:, :, None] * np.uint64(m) + np.arange(m, dtype=np.uint64)[None, None, :]
+        cb = (synth.splitmix64(e ^ np.uint64(synth.SEED_BASE)) >> np.uint64(56)).astype(np.int64)
+        acc = np.take_along_axis(lut[:, 0, :], cb[:, :, 0], axis=1)
+        for kk in range(1, m):                                                          # sequential f32 sum, :85-87
+            acc = acc + np.take_along_axis(lut[:, kk, :], cb[:, :, kk], axis=1)
+        checks["returned_dists_recomputed_bit_exact"] = bool(np.array_equal(acc.view(np.uint32), rd_h[:nchk].view(np.uint32)))
+        checks["queries_checked"] = nchk
+
+    # ---- recall (sanity + parity: ids are bit-exact, so recall is identical by construction) ------------------------
     recall = None
-    if world == 1:
+    if world == 1 and not a.inproc and X is not None:
         nrec = min(nq, 1000)
         best = torch.full((nrec,), float("inf"), device=device)
         arg = torch.zeros((nrec,), dtype=torch.long, device=device)
@@ -205,16 +327,16 @@ def main():
             upd = v < best
             best = torch.where(upd, v, best)
             arg = torch.where(upd, i + a0, arg)
-        ids = out[1][:nrec].long() & 0xFFFFFFFF
-        rec = rq.eval_recall(arg.cpu().numpy(), ids.cpu().numpy(), K, verbose=False)
+        rec = rq.eval_recall(arg.cpu().numpy(), ri_h[:nrec].astype(np.int64), K, verbose=False)
         recall = {"r@1": float(rec[0]), "r@10": float(rec[min(9, K - 1)]), "r@100": float(rec[min(99, K - 1)]),
                   "r@%d" % K: float(rec[K - 1]), "queries": nrec}
 
-    # ---- CPU baseline on this box's host cores (rank 0, N = 1 only) -----------------------------------------
+    # ---- CPU baseline on this box's host cores (rank 0, N = 1 only) -----------------------------------------------
     cpu = None
-    if world == 1 and not a.no_cpu:
+    if ngpu == 1 and not a.no_cpu:
         from oracle import oracle
-        codes_h = codes.cpu().numpy()
+        nb = min(n, 20_000_000)            # sift1b: the reference is timed on the first 2e7 rows of the base
+        codes_h = (codes[:nb] if codes is not None else rqd.synth_codes(nb, m, synth.SEED_BASE, device=device)).cpu().numpy()
         cen_h = centers.cpu().numpy()
         Q_h = Qs.cpu().numpy()
         cores = os.cpu_count() or 1
@@ -229,42 +351,74 @@ def main():
         t0 = time.perf_counter()
         d_cpu, i_cpu = fn(codes_h, cen_h, Q_h[:s1], K)
         dt1 = time.perf_counter() - t0
-        same = bool(np.array_equal(i_cpu, out[1][:s1].cpu().numpy().view(np.uint32)) and
-                    np.array_equal(d_cpu.view(np.uint32), out[0][:s1].cpu().numpy().view(np.uint32)))
-        ne = min(n, 1_000_000)
-        Xh = (rqd.rotate_T(R, X[:ne]) if use_R else X[:ne]).cpu().numpy()
-        t0 = time.perf_counter()
-        c_cpu = oracle.encode_pq(Xh, synth.cat_codebooks(C), m, h)
-        dte = time.perf_counter() - t0
-        cpu = {"value": round(s1 / dt1, 2), "unit": "queries/s", "cores": cores,
+        same = None
+        if nb == n:
+            same = bool(np.array_equal(i_cpu, ri_h[:s1]) and np.array_equal(d_cpu.view(np.uint32), rd_h[:s1].view(np.uint32)))
+        cpu = {"value": round(s1 / dt1 * (nb / n), 3), "unit": "queries/s", "cores": cores,
                "kind": "reference" if use_ref else "port",
-               "sample": "%d of the %d queries, full 1e6-row base, k=%d (%.1f s); deps/src/linscan_aqd.cpp built "
-                         "g++ -O3 -fopenmp as in deps/build.jl:23" % (s1, nq, K, dt1),
-               "gpu_matches_cpu_bit_exact": same,
-               "encode": {"value": round(ne / dte, 1), "unit": "vectors/s", "kind": "port", "cores": oracle.num_threads(),
-                          "sample": "%d vectors (%.2f s), oracle/rq_oracle.c" % (ne, dte),
-                          "codes_match": bool(np.array_equal(c_cpu, codes[:ne].cpu().numpy()))}}
+               "sample": "%d of the %d queries against %s, k=%d (%.1f s)%s; deps/src/linscan_aqd.cpp built g++ -O3 -fopenmp "
+                         "as in deps/build.jl:23" % (s1, nq, "the full %d-row base" % n if nb == n else
+                                                     "the first %d of the %d rows" % (nb, n), K, dt1,
+                                                     "" if nb == n else ", rate scaled by %g to the full base" % (nb / n)),
+               "gpu_matches_cpu_bit_exact": same}
+        if X is not None:
+            ne = min(n, 1_000_000)
+            Xh = (rqd.rotate_T(R, X[:ne]) if use_R else X[:ne]).cpu().numpy()
+            t0 = time.perf_counter()
+            c_cpu = oracle.encode_pq(Xh, synth.cat_codebooks(C), m, h)
+            dte = time.perf_counter() - t0
+            cpu["encode"] = {"value": round(ne / dte, 1), "unit": "vectors/s", "kind": "port", "cores": oracle.num_threads(),
+                             "sample": "%d vectors (%.2f s), oracle/rq_oracle.c" % (ne, dte),
+                             "codes_match": bool(np.array_equal(c_cpu, codes[:ne].cpu().numpy()))}
 
+    # ---- sift1b at N > 1: the same workload on ONE GPU (rank 0 alone), so the line carries its own scaling anchor ---
+    ref1 = None
+    if big and ngpu > 1 and not a.no_ref1 and n * m <= 64 * (1 << 30):
+        try:
+            if ix_lib is not None:
+                ix_lib.close()
+                ix_lib = None
+            codes = None
+            torch.cuda.empty_cache()
+            whole = rqd.synth_codes(n, m, synth.SEED_BASE, row0=0, device=device)
+            o1 = (torch.empty((nq, K), dtype=torch.float32, device=device), torch.empty((nq, K), dtype=torch.int32, device=device))
+            t_ms, _ = timed(lambda: rqd.linscan(whole, centers, Qs, K, out=o1), 2, 1, lambda: None)
+            same = bool(np.array_equal(o1[1].cpu().numpy().view(np.uint32), ri_h) and
+                        np.array_equal(o1[0].cpu().numpy().view(np.uint32), rd_h.view(np.uint32)))
+            ref1 = {"n_gpus": 1, "ms_per_step": round(t_ms / 2, 3), "value": round(nq / (t_ms / 2 * 1e-3), 1),
+                    "answer_identical_to_the_sharded_run": same}
+            del whole
+        except Exception as e:   # noqa: BLE001 -- an anchor, not the measurement
+            ref1 = {"error": repr(e)[:200]}
+
+    if a.inproc:
+        par = "one process, rq_index_create_sharded over %d device(s): exchange=%s" % (ngpu, ix_lib.info()["exchange"] if ix_lib else "?")
+    elif world > 1:
+        par = "one process per GPU (torch.distributed nccl=RCCL): rows sharded x%d, all_to_all of per-shard top-k keys + merge + gather to rank 0" % world
+    else:
+        par = "single GPU"
     line = {
-        "metric": "ADC queries/sec (linscan_pq, exact top-%d)" % K if not use_R else "ADC queries/sec (linscan_opq, exact top-%d)" % K,
-        "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "ADC queries/sec (%s, exact top-%d%s)" % ("linscan_opq" if use_R else "linscan_pq", K, ", %.0e-row base" % n if big else ""),
+        "value": round(qps, 1), "unit": "queries/s", "n_gpus": ngpu, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": name + " encode + ADC linscan", "n_base_per_gpu": n, "n_base_total": n * world,
-                   "nq": nq, "k": K, "d": d, "m": m, "h": h,
-                   "unit_of_value": "one query scanned against one 1e6-row shard; = queries/s at 1 GPU",
-                   "parallelism": "row-sharded base x%d, all_to_all top-k exchange + merge" % world if world > 1 else "single GPU"},
-        "encode": {"metric": "encode vectors/sec (%s)" % ("quantize_opq" if use_R else "quantize_pq"),
-                   "value": round(vps, 1), "unit": "vectors/s", "ms_per_step": round(enc_ms_step, 4), "roofline": enc_roof},
+        "debug_backend": "gloo (ranks share GPUs, collectives on host copies: NOT a measurement)" if debug_gloo and world > 1 else None,
+        "config": {"workload": name + (" ADC linscan + RCCL top-k merge" if big else " encode + ADC linscan"),
+                   "n_base_total": n, "n_base_per_gpu": (n + ngpu - 1) // ngpu, "nq": nq, "k": K, "d": d, "m": m, "h": h,
+                   "generator": "splitmix64 (rayuela.jl_amd/synth.py; seeds base 1234, codebooks 99, rotation 7)",
+                   "parallelism": par},
+        "encode": encode,
         "roofline": roof,
         "cpu_baseline": cpu,
         "recall": recall,
+        "checks": checks,
+        "same_workload_1gpu": ref1,
         "wall_ms_per_step": round(scan_wall / a.steps, 4),
     }
     print(json.dumps(line))
     sys.stdout.flush()
-    barrier()
     if world > 1:
+        barrier()
         dist.destroy_process_group()
 
 

@@ -45,9 +45,9 @@ def shard_bounds(n_total, world):
 
 
 class ShardedIndex:
-    _use_gather = True   # gather-to-root for the final collection (see search)
-
-    def __init__(self, codes_local, centers, id_offset, group=None, scan_fn=None, merge_fn=None):
+    def __init__(self, codes_local, centers, id_offset, group=None, scan_fn=None, merge_fn=None, host_staging=False):
+        # host_staging: run the collectives on CPU copies (debug aid: a gloo group over ranks that share one GPU)
+        self.host_staging = host_staging
         self.codes = codes_local          # [n_local][m] uint8, resident on this rank's device
         self.centers = centers            # [m][256][sub] float32, replicated
         self.id_offset = int(id_offset)
@@ -56,6 +56,12 @@ class ShardedIndex:
         self.merge_fn = merge_fn or _hip_merge
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # total rows of the base: k beyond it has no answer (the reference requires K <= N, linscan_aqd.cpp:91)
+        self.n_total = int(codes_local.shape[0])
+        if self.world > 1:
+            t = torch.tensor([self.n_total], dtype=torch.int64, device="cpu" if host_staging else codes_local.device)
+            dist.all_reduce(t, group=group)
+            self.n_total = int(t.item())
 
     def local_keys(self, queries, k):
         """[nq][k] int64 sorted keys of this shard, padded with KEY_MAX when the shard has < k rows."""
@@ -74,6 +80,8 @@ class ShardedIndex:
         """Scan + exchange + merge.  Returns (q_lo, q_hi, dists, ids) for the queries this rank owns."""
         W, r = self.world, self.rank
         nq = queries.shape[0]
+        if k < 1 or k > self.n_total:
+            raise ValueError("k=%d must be in [1, total rows = %d]" % (k, self.n_total))
         keys = self.local_keys(queries, k)
         per = (nq + W - 1) // W
         if W == 1:
@@ -82,8 +90,17 @@ class ShardedIndex:
         if per * W != nq:  # equal splits for all_to_all_single: pad the query axis
             pad = torch.full((per * W - nq, k), KEY_MAX, dtype=torch.int64, device=keys.device)
             keys = torch.cat([keys, pad], dim=0)
+        dev = keys.device
+        if self.host_staging:
+            keys = keys.cpu()
         recv = torch.empty_like(keys)                      # [W][per][k]: block s = rank s's lists of MY queries
-        dist.all_to_all_single(recv, keys, group=self.group)
+        if self.host_staging:                              # gloo has no all_to_all: W scatters do the same exchange
+            for src in range(W):
+                dist.scatter(recv.view(W, per, k)[src], list(keys.view(W, per, k).unbind(0)) if r == src else None,
+                             src=src, group=self.group)
+            recv = recv.to(dev)
+        else:
+            dist.all_to_all_single(recv, keys, group=self.group)
         mine = recv.view(W, per, k).permute(1, 0, 2).contiguous()   # [per][W][k]
         d, i = self.merge_fn(mine, k, id_base)
         q_lo = min(nq, r * per)
@@ -100,21 +117,15 @@ class ShardedIndex:
         # rank 0 collects the owned blocks (nq/W * k * 8 bytes per rank) with a gather-to-root: W-1 point-to-
         # point transfers over W-1 DISTINCT xGMI links.  (An all_gather moves the same blocks to every rank and
         # RCCL runs it as a ring, i.e. (W-1)/W of the whole result through ONE link per rank -- 70 MB at W = 8,
-        # k = 1000, more than the all_to_all above.)  ProcessGroupNCCL has gather since torch 1.11; should a
-        # build lack it the call raises before any traffic and the all_gather form is used from then on.
-        if ShardedIndex._use_gather:
-            gd = [torch.empty_like(d) for _ in range(W)] if self.rank == 0 else None
-            gi = [torch.empty_like(i) for _ in range(W)] if self.rank == 0 else None
-            try:
-                dist.gather(d, gd, dst=0, group=self.group)
-                dist.gather(i, gi, dst=0, group=self.group)
-            except (RuntimeError, NotImplementedError):
-                ShardedIndex._use_gather = False
-        if not ShardedIndex._use_gather:
-            gd = [torch.empty_like(d) for _ in range(W)]
-            gi = [torch.empty_like(i) for _ in range(W)]
-            dist.all_gather(gd, d, group=self.group)
-            dist.all_gather(gi, i, group=self.group)
+        # k = 1000, more than the all_to_all above.)  Every rank takes the same collective path unconditionally:
+        # an error is an error on all of them, never a divergence into different collectives.
+        if self.host_staging:
+            d, i = d.cpu(), i.cpu()
+        gd = [torch.empty_like(d) for _ in range(W)] if self.rank == 0 else None
+        gi = [torch.empty_like(i) for _ in range(W)] if self.rank == 0 else None
+        dist.gather(d, gd, dst=0, group=self.group)
+        dist.gather(i, gi, dst=0, group=self.group)
         if self.rank != 0:
             return None
-        return torch.cat(gd, dim=0)[:nq].contiguous(), torch.cat(gi, dim=0)[:nq].contiguous()
+        dev = queries.device
+        return torch.cat(gd, dim=0)[:nq].contiguous().to(dev), torch.cat(gi, dim=0)[:nq].contiguous().to(dev)

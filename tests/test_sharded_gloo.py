@@ -75,10 +75,34 @@ def _worker(rank, world, port, n, nq, K, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,nq,K", [(2, 5000, 11, 100), (3, 2000, 7, 900), (2, 64, 4, 50)])
+@pytest.mark.parametrize("world,n,nq,K", [(2, 5000, 11, 100), (3, 2000, 7, 900), (2, 64, 4, 50), (8, 3000, 13, 200)])
 def test_sharded_search_matches_single_scan(tmp_path, world, n, nq, K):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(world, _free_port(), n, nq, K, out), nprocs=world, join=True)
+    assert open(out).read() == "OK"
+
+
+def _worker_k_too_large(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rayuela_jl_amd.sharded import ShardedIndex
+    ix = ShardedIndex(torch.zeros((10, 8), dtype=torch.uint8), torch.zeros((8, 256, 4)), 10 * rank,
+                      scan_fn=lambda *a: None, merge_fn=lambda *a: None)
+    try:
+        ix.search(torch.zeros((3, 32)), 21)          # 20 rows in total
+        verdict = "NO ERROR"
+    except ValueError:
+        verdict = "OK"
+    if rank == 0:
+        open(out_path, "w").write(verdict if ix.n_total == 20 else "BAD TOTAL")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_k_beyond_the_total_row_count_raises_on_every_rank(tmp_path):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker_k_too_large, args=(2, _free_port(), out), nprocs=2, join=True)
     assert open(out).read() == "OK"
 
 
