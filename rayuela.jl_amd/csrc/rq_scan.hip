@@ -101,7 +101,10 @@ struct ScanCtrl {
   uint32_t item;
   uint32_t selmask;     // bit q == sel[q] (one LDS word the hot loop reads per block)
   uint32_t pad[2];
-  SelState<QG> st;
+  // integer pre-filter (FILT kernels): per-(sub-quantizer, query) table minima and the per-query scale
+  float fmin[16][QG];
+  float finv[QG];
+  SelState<QG> st;      // st.hist doubles as the per-wavefront queues of rows waiting for the exact evaluation
 };
 
 struct ScanParams {
@@ -129,6 +132,7 @@ struct ScanParams {
   unsigned long long *stats;  // optional [8]: cycles in lut, sample, stream, cuts, final cut, sort; #cuts; #fallbacks
   uint64_t *cand;           // [gridDim][QG][2][cap]
   uint16_t *bkt;            // [gridDim][cap] bucket ids of the large-K sample sort
+  int filter;               // 1: 8-bit lower-bound pre-filter in front of the exact evaluation (FILT kernels)
   int bigk;                 // K > SCAN_SS_MIN_K: finish with samplesort_topk instead of cut + LDS bitonic
   // outputs of whole items: dists/ids [nq][K], or packed keys [nq][K] when keys != nullptr;
   // of sliced items: part [(query - whole*QG)][nslices][K] packed keys
@@ -254,6 +258,163 @@ __device__ __forceinline__ void load_row(uint32_t *w, const uint8_t *codes, uint
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Survivors of one wave-row-step: lane `lane` holds the exact distances acc[q] of ONE row (key id `kid`) to the
+// QG queries; rows with acc[q] < tau[q] are appended to query q's candidate buffer.  ONE LDS atomic for all QG
+// queries: lane q reserves popc(mk[q]) slots of query q.
+// ------------------------------------------------------------------------------------------
+template <int QG>
+__device__ __forceinline__ void emit_survivors(const float (&acc)[QG], const float (&tau)[QG], bool valid, uint32_t kid,
+                                               uint32_t selmask, ScanCtrl<QG> *ctrl, uint64_t *cand_wg, uint32_t cap,
+                                               int lane) {
+  uint64_t mk[QG];
+  uint64_t any = 0;
+#pragma unroll
+  for (int q = 0; q < QG; ++q) {
+    mk[q] = __ballot(valid && (acc[q] < tau[q]));
+    any |= mk[q];
+  }
+  if (any) {
+    uint32_t want = 0;
+#pragma unroll
+    for (int q = 0; q < QG; ++q)
+      want = writelane_u32(want, (uint32_t)__popcll(mk[q]), q);
+    uint32_t got = 0;
+    if (lane < QG && want) got = atomicAdd(&ctrl->cnt[lane], want);
+#pragma unroll
+    for (int q = 0; q < QG; ++q) {
+      if (mk[q]) {
+        const uint32_t basep = __builtin_amdgcn_readlane(got, q);
+        if ((mk[q] >> lane) & 1ull) {
+          const uint32_t pos = basep + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
+          uint64_t *buf = cand_wg + ((size_t)q * 2 + ((selmask >> q) & 1u)) * cap;
+          buf[pos] = make_key(acc[q], kid);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Integer pre-filter (M = 8 tiles, LUT modes with entries >= 0).
+//
+// 63 % of the LDS cycles of the exact loop are bank-conflict replays of 16-byte gathers, and only ~0.3 % of
+// the (row, query) pairs survive the threshold.  So the hot loop first evaluates a LOWER BOUND of every
+// distance from a table of one BYTE per (sub-quantizer, code, query) -- ONE 8-byte gather serves the 8 queries
+// of the group, and one v_add_u32 accumulates 4 of them -- and only rows whose bound can still beat tau for
+// some query are queued (row id, per wavefront) for the exact f32 evaluation above, 64 queued rows at a time.
+//
+//   entry  e_q[k][r] = min( floor( (T_q[k][r] - min_r T_q[k][.]) * inv_q ), CLAMP ),   CLAMP = 255 / M
+//   inv_q  a little BELOW  THR / (tau_q (1 + 2^-19) - sum_k min_k (1 - 2^-20))
+//   pass   sum_k e_q[k][b_k] <= THR            (byte sums cannot wrap: M * CLAMP <= 255)
+//
+// Soundness (every row with f32 distance d < tau passes): the real sum S of the 8 table entries is within
+// 7 * 2^-24 relative of the sequential f32 sum d (all entries >= 0), so S < tau (1 + 2^-21); the margins in
+// inv_q dominate every rounding of its own computation and of (T - min) * inv, so the computed entry never
+// exceeds the real (T - min) * THR / range, and the real sum of those is < THR.  Clamping only lowers entries.
+// The filter therefore passes a SUPERSET of {d < tau}; the exact evaluation decides, so results do not change.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t FILT_THR = 95;          // < 128 (the byte-wise compare below relies on it)
+constexpr uint32_t FILT_QCAP = 256;        // queue entries per wavefront (= one SelState::hist row)
+
+template <int M>
+__device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const float4 *lut4, const float4 *gtab4,
+                                           uint2 *qtab, int tid) {
+  using Cfg = ScanCfg<M>;
+  constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD, KL = Cfg::KL;
+  static_assert(QG == 8 && NQUAD == 2 && SCAN_THREADS / 64 == M, "pre-filter tiling: 8 queries, one wavefront per sub-quantizer");
+  constexpr float CLAMP = (float)(255 / M);
+  const int k = tid >> 6, lane = tid & 63;
+  auto entry = [&](int kk, int quad, int r) -> float4 {
+    return kk < KL ? lut4[(kk * NQUAD + quad) * 256 + r] : gtab4[((kk - KL) * NQUAD + quad) * 256 + r];
+  };
+  // 1. minima of the 256 entries of (k, q): wavefront k, lane handles r = lane, lane + 64, ...
+  float mn[QG];
+#pragma unroll
+  for (int q = 0; q < QG; ++q) mn[q] = __uint_as_float(0x7f800000u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int quad = 0; quad < NQUAD; ++quad) {
+      const float4 v = entry(k, quad, lane + 64 * i);
+      mn[quad * 4 + 0] = fminf(mn[quad * 4 + 0], v.x);
+      mn[quad * 4 + 1] = fminf(mn[quad * 4 + 1], v.y);
+      mn[quad * 4 + 2] = fminf(mn[quad * 4 + 2], v.z);
+      mn[quad * 4 + 3] = fminf(mn[quad * 4 + 3], v.w);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int q = 0; q < QG; ++q) mn[q] = fminf(mn[q], __shfl_xor(mn[q], off));
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < QG; ++q) ctrl->fmin[k][q] = mn[q];
+  }
+  __syncthreads();
+  if (tid < QG) {
+    float base = 0.0f;
+    for (int kk = 0; kk < M; ++kk) base = base + ctrl->fmin[kk][tid];
+    const float tau = ctrl->tau[tid];
+    const float range = tau * (1.0f + 1.9073486328125e-6f) - base * (1.0f - 9.5367431640625e-7f);   // 2^-19, 2^-20
+    float inv = 0.0f;     // 0: every entry quantises to 0, i.e. the filter passes everything for this query
+    if (tau < __uint_as_float(0x7f800000u) && range > 0.0f && base >= 0.0f) {
+      const float step = range / (float)FILT_THR;
+      const float cand = (1.0f / step) * (1.0f - 9.5367431640625e-7f);
+      if (step > 0.0f && cand < __uint_as_float(0x7f800000u)) inv = cand;
+    }
+    ctrl->finv[tid] = inv;
+  }
+  __syncthreads();
+  // 2. one byte per (k, r, query)
+  for (int e = tid; e < M * 256; e += SCAN_THREADS) {
+    const int kk = e >> 8, r = e & 255;
+    uint32_t packed[2];
+#pragma unroll
+    for (int quad = 0; quad < NQUAD; ++quad) {
+      const float4 v = entry(kk, quad, r);
+      const float t[4] = {v.x, v.y, v.z, v.w};
+      uint32_t w = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float diff = t[c] - ctrl->fmin[kk][quad * 4 + c];
+        const float x = diff * ctrl->finv[quad * 4 + c];
+        w |= (uint32_t)fminf(fmaxf(x, 0.0f), CLAMP) << (8 * c);   // float -> uint conversion truncates = floor (x >= 0)
+      }
+      packed[quad] = w;
+    }
+    qtab[e] = make_uint2(packed[0], packed[1]);
+  }
+}
+
+// Exact evaluation of `count` (<= 64, wave-uniform) queued rows by the calling wavefront: lane i takes queue[i].
+template <int M, bool BIAS>
+__device__ __noinline__ void refine_rows(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, const uint8_t *codes,
+                                         const float *row_bias, uint32_t id_offset, uint32_t cap, const float4 *lut4,
+                                         const float4 *gtab, const uint32_t *queue, uint32_t count) {
+  constexpr int QG = ScanCfg<M>::QG;
+  const int lane = threadIdx.x & 63;
+  const bool valid = (uint32_t)lane < count;
+  const uint32_t row = queue[valid ? lane : 0];
+  uint32_t w1[(M + 3) / 4];
+  load_row<M>(w1, codes, row);
+  float acc[QG];
+  row_dists<M>(w1, 0, lut4, gtab, acc);
+  if (BIAS) {
+    const float bias = row_bias[row];
+#pragma unroll
+    for (int q = 0; q < QG; ++q) acc[q] = acc[q] + bias;
+  }
+  float tau[QG];
+#pragma unroll
+  for (int q = 0; q < QG; ++q) tau[q] = ctrl->tau[q];
+  const uint32_t selmask = __builtin_amdgcn_readfirstlane(ctrl->selmask);
+  emit_survivors<QG>(acc, tau, valid, row + id_offset, selmask, ctrl, cand_wg, cap, lane);
+}
+
 // Cut the candidate buffers of the flagged queries back to exactly K keys and refresh tau.
 template <int M>
 __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg,
@@ -311,7 +472,7 @@ __device__ __noinline__ void finish_bigk(const uint32_t *cnt_q, const uint32_t *
   }
 }
 
-template <int M, bool BIAS>
+template <int M, bool BIAS, bool FILT>
 __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p) {
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, RPT = Cfg::RPT, BLK = Cfg::BLK;
@@ -442,6 +603,17 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
       __syncthreads();
       RQ_STAT_ADD(1, t_ph);
     }
+    // ---- pre-filter tables for this threshold (they live where the sample minima were) ---------------------
+    const bool filt_on = FILT && p.filter && attempt == 0 && (uint64_t)rows >= 64ull * (uint64_t)Ks;
+    const uint2 *qtab = reinterpret_cast<const uint2 *>(samp);
+    uint32_t *myq = &ctrl->st.hist[0][0] + (size_t)(tid >> 6) * FILT_QCAP;
+    uint32_t qtail = 0;      // wave-uniform
+    if constexpr (FILT) {
+      if (filt_on) {
+        build_qtab<M>(ctrl, lut4, gtab, reinterpret_cast<uint2 *>(samp), tid);
+        __syncthreads();
+      }
+    }
     t_ph = RQ_STAT_T();
 
     // ---- stream the slice -----------------------------------------------------------------------
@@ -453,6 +625,15 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
       const bool maybe = ctrl->cnt[g] > p.trigger;
       if (__syncthreads_or(maybe)) {
         const unsigned long long t_c = RQ_STAT_T();
+        if (FILT && filt_on) {
+          // the cut uses st.hist: every wavefront first runs its queued rows through the exact evaluation
+          while (qtail) {
+            const uint32_t take = min(qtail, 64u);
+            refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - take), take);
+            qtail -= take;
+          }
+          __syncthreads();
+        }
         const bool need = ctrl->cnt[g] > p.trigger;
         compact_group<M>(ctrl, cand_wg, p, need, g, gi);
         RQ_STAT_ADD(3, t_c);
@@ -499,6 +680,42 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
         }
       }
 
+      if (FILT && filt_on) {
+        // ---- pre-filter: byte lower bounds for the 8 queries, 8 bytes per gather; rows that may still beat a
+        // threshold are queued for the exact evaluation, which runs 64 queued rows at a time
+#pragma unroll
+        for (int u = 0; u < Cfg::U; ++u) {
+          const uint32_t *w = wu[u];
+          const uint32_t row0 = base + (uint32_t)u * Cfg::SUB + (uint32_t)tid * RPT;
+#pragma unroll
+          for (int r = 0; r < RPT; ++r) {
+            uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+              const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
+              const uint2 e = qtab[k * 256 + byte];
+              a0 += e.x;
+              a1 += e.y;
+            }
+            // byte-wise "sum > THR" for the 8 queries: ((s | 0x80) - (THR+1)) has bit 7 set iff (s & 0x7f) > THR,
+            // and any s >= 0x80 is > THR as well; no borrow crosses a byte because (s | 0x80) >= THR + 1
+            constexpr uint32_t H = 0x80808080u, TC = (FILT_THR + 1u) * 0x01010101u;
+            const uint32_t g0 = ((a0 | H) - TC) | a0, g1 = ((a1 | H) - TC) | a1;
+            const bool cand = ((g0 & g1 & H) != H) && (row0 + r < r_end);
+            const uint64_t mq = __ballot(cand);
+            if (mq) {
+              if (cand) myq[qtail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u))] = row0 + r;
+              qtail += (uint32_t)__popcll(mq);
+            }
+          }
+          if (qtail >= 64u) {      // at most 2 * 64 rows were pushed since the last check: qtail < 64 + 128 <= FILT_QCAP
+            do {
+              refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - 64u), 64u);
+              qtail -= 64u;
+            } while (qtail >= 64u);
+          }
+        }
+      } else {
 #pragma unroll
       for (int u = 0; u < Cfg::U; ++u) {
       const uint32_t *w = wu[u];
@@ -513,37 +730,17 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
           for (int q = 0; q < QG; ++q) acc[q] = acc[q] + bias;
         }
         // ---- survivors: rows whose distance beats the query's threshold ------------------------
-        const bool valid = row0 + r < r_end;
-        uint64_t mk[QG];
-        uint64_t any = 0;
-#pragma unroll
-        for (int q = 0; q < QG; ++q) {
-          mk[q] = __ballot(valid && (acc[q] < tau[q]));
-          any |= mk[q];
-        }
-        if (any) {
-          // ONE LDS atomic for all QG queries: lane q reserves popc(mk[q]) slots of query q
-          uint32_t want = 0;
-#pragma unroll
-          for (int q = 0; q < QG; ++q)
-            want = writelane_u32(want, (uint32_t)__popcll(mk[q]), q);
-          uint32_t got = 0;
-          if (lane < QG && want) got = atomicAdd(&ctrl->cnt[lane], want);
-#pragma unroll
-          for (int q = 0; q < QG; ++q) {
-            if (mk[q]) {
-              const uint32_t basep = __builtin_amdgcn_readlane(got, q);
-              if ((mk[q] >> lane) & 1ull) {
-                const uint32_t pos = basep + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32),
-                                              __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
-                uint64_t *buf = cand_wg + ((size_t)q * 2 + ((selmask >> q) & 1u)) * p.cap;
-                buf[pos] = make_key(acc[q], row0 + r + p.id_offset);
-              }
-            }
-          }
-        }
+        emit_survivors<QG>(acc, tau, row0 + r < r_end, row0 + r + p.id_offset, selmask, ctrl, cand_wg, p.cap, lane);
       }
       }  // sub-steps
+      }
+    }
+    if (FILT && filt_on) {
+      while (qtail) {          // slice end: the rest of the queue
+        const uint32_t take = min(qtail, 64u);
+        refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - take), take);
+        qtail -= take;
+      }
     }
     __syncthreads();   // every append of the slice has landed
 
@@ -771,7 +968,15 @@ static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) 
   if (p.bigk) lds = std::max<size_t>(lds, CTRL_BYTES + SS_LDS_BYTES);
   // SCAN_SPREAD: asking for more than half of the LDS forces one workgroup per CU
   if (plan.spread) lds = std::max<size_t>(lds, 84 * 1024);
-  auto kern = p.row_bias ? adc_scan_kernel<M, true> : adc_scan_kernel<M, false>;
+  // the pre-filter is tiled for M = 8 (one wavefront per sub-quantizer builds its byte table) and needs
+  // non-negative table entries (PQ and CQ tables are sums of squares)
+  constexpr bool HAS_FILT = (M == 8) && SCAN_THREADS == 512;
+  void (*kern)(ScanParams) = p.row_bias ? adc_scan_kernel<M, true, false> : adc_scan_kernel<M, false, false>;
+  if constexpr (HAS_FILT) {
+    if (p.filter) kern = adc_scan_kernel<M, false, true>;
+  } else {
+    p.filter = 0;
+  }
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(SCAN_THREADS), lds, stream, p);
@@ -793,7 +998,8 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   const uint32_t slack = (uint32_t)slack_i;
   pl.trigger = (uint32_t)K + slack;
   pl.sample = (uint32_t)tuning("SCAN_SAMPLE", 16384);
-  pl.cap = pl.trigger + 2 * Cfg::BLK;
+  // + 2048: rows waiting in the pre-filter's queues (< 128 per wavefront) are appended outside their block
+  pl.cap = pl.trigger + 2 * Cfg::BLK + 2048;
   pl.p2 = next_pow2((uint32_t)K);
   // large K finishes with the global-memory sample sort: its LDS need does not grow with K
   pl.bigk = K > tuning("SCAN_SS_MIN_K", 1024);
@@ -896,6 +1102,7 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.gtab = reinterpret_cast<float4 *>(reinterpret_cast<char *>(cand) + pl.gtab_off);
   p.bkt = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(cand) + pl.bkt_off);
   p.bigk = pl.bigk ? 1 : 0;
+  p.filter = (lut_mode != LUT_LSQ && !row_bias && tuning("SCAN_FILTER", 1)) ? 1 : 0;
   p.stats = tuning("SCAN_STATS", 0) ? reinterpret_cast<unsigned long long *>(work_counter + 16) : nullptr;
   p.dists = dists; p.ids = ids; p.keys = keys; p.part = part;
   RQ_HIP(hipMemsetAsync(work_counter, 0, p.stats ? 256 : sizeof(uint32_t), stream));
