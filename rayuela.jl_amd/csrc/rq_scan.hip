@@ -90,6 +90,12 @@ struct ScanCfg {
   static constexpr int KL = M - KG;                 // sub-quantizers [0, KL) gather from LDS
   static constexpr int GTAB_F4 = KG * NQUAD * 256;  // entries (float4 for QPG = 4) of the global (L1) table
   static constexpr int LUT_LDS_BYTES = KL * QG * 1024;
+  // integer pre-filter (see build_qtab): one byte per (sub-quantizer, code, query); tiled for M = 8 and 16
+  static constexpr bool HAS_FILT = (M == 8 || M == 16) && SCAN_THREADS == 512;
+  static constexpr int NACC = HAS_FILT ? M / 8 : 1;                  // byte accumulators: 8 sub-quantizers each
+  static constexpr int QTAB_BYTES = HAS_FILT ? M * 256 * QG : 0;
+  // scratch behind the staged queries: the threshold sample's [QG][SCAN_THREADS] minima, later the filter table
+  static constexpr int AUX_BYTES = (QG * SCAN_THREADS * 4 > QTAB_BYTES) ? QG * SCAN_THREADS * 4 : QTAB_BYTES;
   static_assert(RPT >= 1, "M too large for this tiling");
 };
 
@@ -104,6 +110,7 @@ struct ScanCtrl {
   // integer pre-filter (FILT kernels): per-(sub-quantizer, query) table minima and the per-query scale
   float fmin[16][QG];
   float finv[QG];
+  uint32_t fpush;       // rows the pre-filter let through in the item's first block (it is switched off if too many)
   SelState<QG> st;      // st.hist doubles as the per-wavefront queues of rows waiting for the exact evaluation
 };
 
@@ -316,63 +323,73 @@ __device__ __forceinline__ void emit_survivors(const float (&acc)[QG], const flo
 // exceeds the real (T - min) * THR / range, and the real sum of those is < THR.  Clamping only lowers entries.
 // The filter therefore passes a SUPERSET of {d < tau}; the exact evaluation decides, so results do not change.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t FILT_THR = 95;          // < 128 (the byte-wise compare below relies on it)
-constexpr uint32_t FILT_QCAP = 256;        // queue entries per wavefront (= one SelState::hist row)
+// Byte accumulators hold the bounds of 8 sub-quantizers (8 * 31 <= 255).  M = 8: one accumulator set, compared
+// byte-wise against THR8 (< 128).  M = 16: two sets, widened to 16-bit fields and compared against THR16.
+constexpr uint32_t FILT_CLAMP = 31;
+constexpr uint32_t FILT_THR8 = 95;
+constexpr uint32_t FILT_THR16 = 159;
+
+template <int M> struct FiltVec;               // table entry: one byte per query of the group
+template <> struct FiltVec<8> { using type = uint2; };      // QG = 8: ds_read_b64
+template <> struct FiltVec<16> { using type = uint32_t; };  // QG = 4: ds_read_b32
 
 template <int M>
 __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const float4 *lut4, const float4 *gtab4,
-                                           uint2 *qtab, int tid) {
+                                           uint32_t *qtab, int tid) {
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD, KL = Cfg::KL;
-  static_assert(QG == 8 && NQUAD == 2 && SCAN_THREADS / 64 == M, "pre-filter tiling: 8 queries, one wavefront per sub-quantizer");
-  constexpr float CLAMP = (float)(255 / M);
-  const int k = tid >> 6, lane = tid & 63;
+  static_assert(Cfg::QPG == 4, "pre-filter tiling: float4 table entries");
+  constexpr float THR = (float)(M == 8 ? FILT_THR8 : FILT_THR16);
+  const int wave = tid >> 6, lane = tid & 63;
   auto entry = [&](int kk, int quad, int r) -> float4 {
     return kk < KL ? lut4[(kk * NQUAD + quad) * 256 + r] : gtab4[((kk - KL) * NQUAD + quad) * 256 + r];
   };
-  // 1. minima of the 256 entries of (k, q): wavefront k, lane handles r = lane, lane + 64, ...
-  float mn[QG];
+  // 1. minima of the 256 entries of (k, q): one wavefront per sub-quantizer, lane handles r = lane, lane + 64, ...
+  for (int k = wave; k < M; k += SCAN_THREADS / 64) {
+    float mn[QG];
 #pragma unroll
-  for (int q = 0; q < QG; ++q) mn[q] = __uint_as_float(0x7f800000u);
+    for (int q = 0; q < QG; ++q) mn[q] = __uint_as_float(0x7f800000u);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int quad = 0; quad < NQUAD; ++quad) {
-      const float4 v = entry(k, quad, lane + 64 * i);
-      mn[quad * 4 + 0] = fminf(mn[quad * 4 + 0], v.x);
-      mn[quad * 4 + 1] = fminf(mn[quad * 4 + 1], v.y);
-      mn[quad * 4 + 2] = fminf(mn[quad * 4 + 2], v.z);
-      mn[quad * 4 + 3] = fminf(mn[quad * 4 + 3], v.w);
+      for (int quad = 0; quad < NQUAD; ++quad) {
+        const float4 v = entry(k, quad, lane + 64 * i);
+        mn[quad * 4 + 0] = fminf(mn[quad * 4 + 0], v.x);
+        mn[quad * 4 + 1] = fminf(mn[quad * 4 + 1], v.y);
+        mn[quad * 4 + 2] = fminf(mn[quad * 4 + 2], v.z);
+        mn[quad * 4 + 3] = fminf(mn[quad * 4 + 3], v.w);
+      }
     }
-  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-    for (int q = 0; q < QG; ++q) mn[q] = fminf(mn[q], __shfl_xor(mn[q], off));
-  }
-  if (lane == 0) {
+      for (int q = 0; q < QG; ++q) mn[q] = fminf(mn[q], __shfl_xor(mn[q], off));
+    }
+    if (lane == 0) {
 #pragma unroll
-    for (int q = 0; q < QG; ++q) ctrl->fmin[k][q] = mn[q];
+      for (int q = 0; q < QG; ++q) ctrl->fmin[k][q] = mn[q];
+    }
   }
   __syncthreads();
   if (tid < QG) {
     float base = 0.0f;
     for (int kk = 0; kk < M; ++kk) base = base + ctrl->fmin[kk][tid];
     const float tau = ctrl->tau[tid];
-    const float range = tau * (1.0f + 1.9073486328125e-6f) - base * (1.0f - 9.5367431640625e-7f);   // 2^-19, 2^-20
+    // margins: 2^-19 on tau, 2^-20 on the minima and on 1/step; the f32 sum of M <= 16 non-negative entries is
+    // within 15 * 2^-24 < 2^-20 relative of the real sum
+    const float range = tau * (1.0f + 1.9073486328125e-6f) - base * (1.0f - 9.5367431640625e-7f);
     float inv = 0.0f;     // 0: every entry quantises to 0, i.e. the filter passes everything for this query
     if (tau < __uint_as_float(0x7f800000u) && range > 0.0f && base >= 0.0f) {
-      const float step = range / (float)FILT_THR;
+      const float step = range / THR;
       const float cand = (1.0f / step) * (1.0f - 9.5367431640625e-7f);
       if (step > 0.0f && cand < __uint_as_float(0x7f800000u)) inv = cand;
     }
     ctrl->finv[tid] = inv;
   }
   __syncthreads();
-  // 2. one byte per (k, r, query)
+  // 2. one byte per (k, r, query): QG bytes per entry
   for (int e = tid; e < M * 256; e += SCAN_THREADS) {
     const int kk = e >> 8, r = e & 255;
-    uint32_t packed[2];
 #pragma unroll
     for (int quad = 0; quad < NQUAD; ++quad) {
       const float4 v = entry(kk, quad, r);
@@ -382,11 +399,27 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
       for (int c = 0; c < 4; ++c) {
         const float diff = t[c] - ctrl->fmin[kk][quad * 4 + c];
         const float x = diff * ctrl->finv[quad * 4 + c];
-        w |= (uint32_t)fminf(fmaxf(x, 0.0f), CLAMP) << (8 * c);   // float -> uint conversion truncates = floor (x >= 0)
+        w |= (uint32_t)fminf(fmaxf(x, 0.0f), (float)FILT_CLAMP) << (8 * c);   // float -> uint truncates = floor (x >= 0)
       }
-      packed[quad] = w;
+      qtab[e * NQUAD + quad] = w;
     }
-    qtab[e] = make_uint2(packed[0], packed[1]);
+  }
+}
+
+// "Can this row still beat a threshold?" from the byte sums of the group's queries.
+//   M = 8 : a[0], a[1] hold 8 byte sums s <= 248.  ((s | 0x80) - (THR+1)) has bit 7 set iff (s & 0x7f) > THR, and any
+//           s >= 0x80 is > THR as well; no borrow crosses a byte because (s | 0x80) >= THR + 1.
+//   M = 16: two sets of 4 byte sums; per query sum = A + B <= 496, widened to 16-bit fields, same trick with bit 15.
+template <int M>
+__device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC * ScanCfg<M>::NQUAD]) {
+  if constexpr (M == 8) {
+    constexpr uint32_t H = 0x80808080u, TC = (FILT_THR8 + 1u) * 0x01010101u;
+    const uint32_t g0 = ((a[0] | H) - TC) | a[0], g1 = ((a[1] | H) - TC) | a[1];
+    return (g0 & g1 & H) != H;
+  } else {
+    constexpr uint32_t H = 0x80008000u, F = 0x00ff00ffu, TC = (FILT_THR16 + 1u) * 0x00010001u;
+    const uint32_t lo = (a[0] & F) + (a[1] & F), hi = ((a[0] >> 8) & F) + ((a[1] >> 8) & F);
+    return ((((lo | H) - TC) & ((hi | H) - TC)) & H) != H;
   }
 }
 
@@ -565,7 +598,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
       ctrl->tau[tid] = __uint_as_float(0x7f800000u);  // +inf: everything passes until the first cut
       ctrl->cnt[tid] = 0;
       ctrl->sel[tid] = 0;
-      if (tid == 0) ctrl->selmask = 0;
+      if (tid == 0) { ctrl->selmask = 0; ctrl->fpush = 0; }
     }
     __syncthreads();
     if (attempt == 1 && sampled) RQ_STAT_INC(7);
@@ -604,13 +637,17 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
       RQ_STAT_ADD(1, t_ph);
     }
     // ---- pre-filter tables for this threshold (they live where the sample minima were) ---------------------
-    const bool filt_on = FILT && p.filter && attempt == 0 && (uint64_t)rows >= 64ull * (uint64_t)Ks;
-    const uint2 *qtab = reinterpret_cast<const uint2 *>(samp);
-    uint32_t *myq = &ctrl->st.hist[0][0] + (size_t)(tid >> 6) * FILT_QCAP;
+    bool filt_on = FILT && p.filter && attempt == 0 && (uint64_t)rows >= 64ull * (uint64_t)Ks;
+    constexpr uint32_t FILT_QCAP = QG * 256 / (SCAN_THREADS / 64);   // queue entries per wavefront: st.hist split over the waves
+    static_assert(!FILT || FILT_QCAP >= 128, "a wavefront's queue holds 64 waiting rows + one row-step of pushes");
+    const uint32_t *qtab = samp;
+    // this wavefront's queue: the offset is wave-uniform, so it lives in an SGPR (a VGPR pointer got spilled to
+    // scratch and reloaded on every push: +10 % kernel time)
+    uint32_t *const myq = &ctrl->st.hist[0][0] + __builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6) * FILT_QCAP);
     uint32_t qtail = 0;      // wave-uniform
     if constexpr (FILT) {
       if (filt_on) {
-        build_qtab<M>(ctrl, lut4, gtab, reinterpret_cast<uint2 *>(samp), tid);
+        build_qtab<M>(ctrl, lut4, gtab, samp, tid);
         __syncthreads();
       }
     }
@@ -638,6 +675,22 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
         compact_group<M>(ctrl, cand_wg, p, need, g, gi);
         RQ_STAT_ADD(3, t_c);
         RQ_STAT_INC(6);
+      }
+      if constexpr (FILT) {
+        // The filter pays off while few rows pass it (0.5 - 5 % on clustered data).  Tables without contrast
+        // (e.g. random codes against random codebooks at m = 16) let a large share through; the first block's
+        // count decides for the rest of the item, and the exact loop takes over after the queues are drained.
+        if (filt_on && base == r_begin + BLK) {
+          constexpr uint32_t MAX_SHARE_PCT = (M == 8) ? 30u : 12u;
+          if (__builtin_amdgcn_readfirstlane(ctrl->fpush) * 100u > (uint32_t)BLK * MAX_SHARE_PCT) {
+            while (qtail) {
+              const uint32_t take = min(qtail, 64u);
+              refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - take), take);
+              qtail -= take;
+            }
+            filt_on = false;
+          }
+        }
       }
       float tau[QG];
 #pragma unroll
@@ -680,42 +733,70 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
         }
       }
 
-      if (FILT && filt_on) {
+      bool filtered = false;
+      if constexpr (FILT) {
+      if (filt_on) {
+        filtered = true;
+        uint32_t npush = 0;      // wave-uniform: rows this wavefront queued in this block
         // ---- pre-filter: byte lower bounds for the 8 queries, 8 bytes per gather; rows that may still beat a
         // threshold are queued for the exact evaluation, which runs 64 queued rows at a time
 #pragma unroll
         for (int u = 0; u < Cfg::U; ++u) {
           const uint32_t *w = wu[u];
           const uint32_t row0 = base + (uint32_t)u * Cfg::SUB + (uint32_t)tid * RPT;
+          // all RPT * M gathers of the sub-step are issued before the first sum (16 x ds_read_b64 / 32 x ds_read_b32)
+          using FV = typename FiltVec<M>::type;
+          const FV *qt = reinterpret_cast<const FV *>(qtab);
+          FV e[RPT][M];
 #pragma unroll
           for (int r = 0; r < RPT; ++r) {
-            uint32_t a0 = 0, a1 = 0;
 #pragma unroll
             for (int k = 0; k < M; ++k) {
               const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
-              const uint2 e = qtab[k * 256 + byte];
-              a0 += e.x;
-              a1 += e.y;
+              e[r][k] = qt[k * 256 + byte];
             }
-            // byte-wise "sum > THR" for the 8 queries: ((s | 0x80) - (THR+1)) has bit 7 set iff (s & 0x7f) > THR,
-            // and any s >= 0x80 is > THR as well; no borrow crosses a byte because (s | 0x80) >= THR + 1
-            constexpr uint32_t H = 0x80808080u, TC = (FILT_THR + 1u) * 0x01010101u;
-            const uint32_t g0 = ((a0 | H) - TC) | a0, g1 = ((a1 | H) - TC) | a1;
-            const bool cand = ((g0 & g1 & H) != H) && (row0 + r < r_end);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < RPT; ++r) {
+            uint32_t a[Cfg::NACC * Cfg::NQUAD];
+#pragma unroll
+            for (int i = 0; i < Cfg::NACC * Cfg::NQUAD; ++i) a[i] = 0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+              if constexpr (Cfg::NQUAD == 2) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(&e[r][k]);
+                a[(k >> 3) * 2 + 0] += v.x;
+                a[(k >> 3) * 2 + 1] += v.y;
+              } else {
+                a[k >> 3] += *reinterpret_cast<const uint32_t *>(&e[r][k]);
+              }
+            }
+            const bool cand = filt_alive<M>(a) && (row0 + r < r_end);
             const uint64_t mq = __ballot(cand);
             if (mq) {
               if (cand) myq[qtail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u))] = row0 + r;
               qtail += (uint32_t)__popcll(mq);
+              npush += (uint32_t)__popcll(mq);
+            }
+            if constexpr (FILT_QCAP < 64u * (RPT + 1)) {     // small queue: make room after every row
+              while (qtail >= 64u) {
+                refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - 64u), 64u);
+                qtail -= 64u;
+              }
             }
           }
-          if (qtail >= 64u) {      // at most 2 * 64 rows were pushed since the last check: qtail < 64 + 128 <= FILT_QCAP
+          if (qtail >= 64u) {      // at most RPT * 64 rows were pushed since the last check: qtail < 64 * (RPT + 1) <= FILT_QCAP
             do {
               refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - 64u), 64u);
               qtail -= 64u;
             } while (qtail >= 64u);
           }
         }
-      } else {
+        if (base == r_begin && lane == 0) atomicAdd(&ctrl->fpush, npush);
+      }
+      }
+      if (!filtered) {
 #pragma unroll
       for (int u = 0; u < Cfg::U; ++u) {
       const uint32_t *w = wu[u];
@@ -963,16 +1044,14 @@ template <int M>
 static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) {
   using Cfg = ScanCfg<M>;
   constexpr int CTRL_BYTES = (sizeof(ScanCtrl<Cfg::QG>) + 15) & ~15;
-  size_t lds = CTRL_BYTES + (size_t)std::max<size_t>(Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * (p.d + SCAN_THREADS) * 4,
+  size_t lds = CTRL_BYTES + (size_t)std::max<size_t>(Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * p.d * 4 + Cfg::AUX_BYTES,
                                                      (size_t)p.scratch_keys * 8);
   if (p.bigk) lds = std::max<size_t>(lds, CTRL_BYTES + SS_LDS_BYTES);
   // SCAN_SPREAD: asking for more than half of the LDS forces one workgroup per CU
   if (plan.spread) lds = std::max<size_t>(lds, 84 * 1024);
-  // the pre-filter is tiled for M = 8 (one wavefront per sub-quantizer builds its byte table) and needs
-  // non-negative table entries (PQ and CQ tables are sums of squares)
-  constexpr bool HAS_FILT = (M == 8) && SCAN_THREADS == 512;
+  // the pre-filter is tiled for M = 8 and 16 and needs non-negative table entries (PQ and CQ tables are sums of squares)
   void (*kern)(ScanParams) = p.row_bias ? adc_scan_kernel<M, true, false> : adc_scan_kernel<M, false, false>;
-  if constexpr (HAS_FILT) {
+  if constexpr (Cfg::HAS_FILT) {
     if (p.filter) kern = adc_scan_kernel<M, false, true>;
   } else {
     p.filter = 0;
@@ -1006,7 +1085,7 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   // LDS scratch for the final sort: at least one query, at most QG, within 160 KiB total
   const size_t lds_max = 160 * 1024 - CTRL_BYTES;
   size_t want_keys = (size_t)pl.p2 * Cfg::QG;
-  size_t base_keys = ((size_t)Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * (d + SCAN_THREADS) * 4) / 8;
+  size_t base_keys = ((size_t)Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * d * 4 + Cfg::AUX_BYTES) / 8;
   size_t keys = std::max(base_keys, std::min(want_keys, (size_t)64 * 1024 / 8 * 2));
   keys = std::max(keys, (size_t)pl.p2);
   if (pl.bigk) keys = std::max(base_keys, (size_t)(SS_LDS_BYTES + 7) / 8);
@@ -1058,7 +1137,7 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   pl.bkt_off = pl.cand_bytes;
   if (pl.bigk) pl.cand_bytes += ((size_t)pl.grid * pl.cap * sizeof(uint16_t) + 15) & ~(size_t)15;
   pl.lds_ok = (pl.bigk || (size_t)pl.p2 * 8 <= lds_max) &&
-              ((size_t)Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * (d + SCAN_THREADS) * 4 <= lds_max);
+              ((size_t)Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * d * 4 + Cfg::AUX_BYTES <= lds_max);
 }
 
 int scan_padded_m(int m) {

@@ -28,8 +28,36 @@ fails = 0
 t0 = time.time()
 for r in range(a.rounds):
     rng = np.random.default_rng(a.seed * 100003 + r)
-    kind = r % 3
-    if kind == 0:      # scan
+    kind = r % 4
+    if kind == 3:      # scan shapes that run the integer pre-filter (rows >= 64 k, m in {8, 16}) on hostile tables
+        m = int(rng.choice([8, 8, 16]))
+        sub = int(rng.choice([1, 2, 6]))
+        n = int(rng.choice([70000, 300000, 1000000]))
+        nq = int(rng.choice([3, 8, 40]))
+        K = int(rng.choice([1, 10, 100, 1000]))
+        style = int(rng.integers(0, 7))
+        centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+        queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+        codes = synth.random_codes(n, m, seed=r)
+        if style == 1:      # all table entries equal per sub-quantizer: no contrast at all
+            centers[:] = centers[:, :1, :]
+        elif style == 2:    # one sub-quantizer dominates the distance
+            centers[0] *= 1000.0
+        elif style == 3:    # integer tables: massive distance ties
+            centers = rng.integers(0, 3, (m, 256, sub)).astype(np.float32)
+            queries = rng.integers(0, 3, (nq, m * sub)).astype(np.float32)
+        elif style == 4:    # few distinct rows: the same codes again and again
+            codes = codes[rng.integers(0, 50, n)]
+        elif style == 5:    # large common offset: tau ~ sum of the table minima (cancellation in the filter's range)
+            queries += 1000.0
+        elif style == 6:    # clustered: a small share of rows is close, the rest far (high-contrast tables)
+            centers[:, 8:, :] += 30.0
+            queries *= 0.1
+        d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+        d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+        ok = np.array_equal(i0, i1) and np.array_equal(bits(d0), bits(d1))
+        desc = "filter-scan m=%d sub=%d n=%d nq=%d K=%d style=%d" % (m, sub, n, nq, K, style)
+    elif kind == 0:      # scan
         m = int(rng.choice([2, 4, 8, 8, 8, 16, 32, 64, 5, 11]))
         sub = int(rng.choice([1, 2, 4, 8]))
         n = int(rng.choice([3000, 40000, 90000, 250000]))
