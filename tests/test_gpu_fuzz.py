@@ -33,6 +33,46 @@ def test_scan_fuzz(rq, oracle, seed):
     assert _eq_bits(d0, d1), (m, sub, n, nq, K)
 
 
+@pytest.mark.parametrize("style", range(7))
+@pytest.mark.parametrize("m,K", [(8, 10), (8, 1000), (16, 100)])
+def test_scan_prefilter_on_hostile_tables(rq, oracle, style, m, K):
+    """Shapes that run the integer pre-filter (m in {8, 16}, rows >= 64 k) on tables built to break a lower-bound
+    filter: no contrast, one dominating sub-quantizer, massive ties, few distinct rows, a large common offset
+    (tau ~ sum of the table minima), high contrast.  The filter may only ever cost time: ids and distance bits
+    must equal the reference's."""
+    import rayuela_jl_amd.synth as synth
+    rng = np.random.default_rng(7000 + 10 * style + m)
+    sub, n, nq = 2, 300_000, 11
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=style)
+    if style == 1:
+        centers[:] = centers[:, :1, :]
+    elif style == 2:
+        centers[0] *= 1000.0
+    elif style == 3:
+        centers = rng.integers(0, 3, (m, 256, sub)).astype(np.float32)
+        queries = rng.integers(0, 3, (nq, m * sub)).astype(np.float32)
+    elif style == 4:
+        codes = codes[rng.integers(0, 50, n)]
+    elif style == 5:
+        queries += 1000.0
+    elif style == 6:
+        centers[:, 8:, :] += 30.0
+        queries *= 0.1
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+    assert np.array_equal(i0, i1), (style, m, K)
+    assert _eq_bits(d0, d1), (style, m, K)
+    # the same answer with the filter switched off (tuning knob): it is an accelerator, not part of the result
+    rq.set_tuning("SCAN_FILTER", 0)
+    try:
+        d2, i2 = rq.linscan_aqd_query(codes, centers, queries, K)
+    finally:
+        rq.set_tuning("SCAN_FILTER", 1)
+    assert np.array_equal(i1, i2) and _eq_bits(d1, d2)
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_encode_fuzz(rq, oracle, seed):
     import rayuela_jl_amd.synth as synth
