@@ -23,8 +23,8 @@ session gets) instead.
 
 Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
   roofline      the dominant kernel (adc_scan_kernel) against the resource that binds it -- the LDS gather pipe:
-                algorithmic table bytes nq*n*m*4 per launch / kernel time vs 256 CU x 256 B/clk; the HBM side
-                (algorithmic code bytes nq*n*m and the PMC-measured traffic) is reported next to it
+                algorithmic bytes nq*n*m per launch / kernel time vs 256 CU x 256 B/clk x 2.4 GHz; the HBM side
+                (the same bytes vs 8 TB/s, and the PMC-measured traffic) is reported next to it
   cpu_baseline  the reference's own deps/src/linscan_aqd.cpp (oracle/_ref, built by oracle/Makefile) timed on
                 this box's host cores on a bounded sample of the same workload
 """
@@ -111,24 +111,32 @@ def load_traffic(kernel_key):
 
 
 def scan_roofline(m, n_local, nq, K, kernel_ms):
-    """The ADC scan kernel against its binding resource.  Every (query, row, sub-quantizer) reads one 4-byte
-    table entry; ds_read_b128 delivers 256 B/clk/CU conflict-free, so the LDS-gather roof is
-    nq*n*m*4 B / (256 CU x 256 B/clk x 2.4 GHz).  HBM: algorithmic code bytes nq*n*m are shared
-    by the 8 queries of a group and mostly served by L2/MALL, so the PMC traffic is what reaches HBM."""
+    """The ADC scan kernel against the resource that binds it, the LDS gather pipe.
+
+    Algorithmic bytes per launch = nq * n * m (one table entry looked up per code byte per query).
+    Since round 2 the hot loop looks a ONE-byte lower bound up for (almost) every (query, row, sub-quantizer) --
+    8 queries per ds_read_b64 gather -- so nq*n*m is also the number of table bytes the LDS has to deliver, and
+    the roof is the conflict-free LDS rate, 256 CU x 256 B/clk x 2.4 GHz.  `frac` is what bank conflicts (~60 %
+    of the LDS cycles, profiles/), the exact re-evaluation of surviving rows and the top-k finish leave of it.
+    `f32_table_roof` keeps round 1's yardstick (4-byte entries, 4 queries per ds_read_b128) for continuity.
+    HBM: the same nq*n*m code bytes are shared by the 8 queries of a group and mostly served by L2/MALL, so
+    the PMC traffic is what reaches HBM."""
     t = kernel_ms * 1e-3
-    table_bytes = float(nq) * n_local * m * 4.0
     code_bytes = float(nq) * n_local * m
-    achieved = table_bytes / t / 1e9
+    achieved = code_bytes / t / 1e9
     traffic, src = load_traffic("adc_scan_kernel<%d> n=%d nq=%d k=%d" % (m, n_local, nq, K))
-    hbm = {"algorithmic_bytes_per_launch": code_bytes, "algorithmic_GBps": round(code_bytes / t / 1e9, 1),
-           "peak_GBps": HBM_PEAK_GBS, "traffic_bytes_per_launch": traffic, "traffic_source": src,
+    hbm = {"algorithmic_GBps": round(achieved, 1), "peak_GBps": HBM_PEAK_GBS,
+           "effective_frac": round(achieved / HBM_PEAK_GBS, 4),
+           "traffic_bytes_per_launch": traffic, "traffic_source": src,
            "traffic_GBps": None if traffic is None else round(traffic / t / 1e9, 1),
-           "frac_of_peak": None if traffic is None else round(traffic / t / 1e9 / HBM_PEAK_GBS, 4)}
+           "traffic_frac_of_peak": None if traffic is None else round(traffic / t / 1e9 / HBM_PEAK_GBS, 4)}
     return {"bound": "lds", "kernel": "adc_scan_kernel<%d>" % m, "achieved": round(achieved, 1), "peak": round(LDS_PEAK_GBS, 1),
             "unit": "GB/s", "frac": round(achieved / LDS_PEAK_GBS, 4), "traffic": traffic,
-            "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": table_bytes,
-            "definition": "table bytes nq*n*m*4 per launch / kernel time vs %d CU x %d B/clk x %.1f GHz (conflict-free "
-                          "ds_read_b128); measured SQ_LDS_BANK_CONFLICT share in profiles/" % (NUM_CU, LDS_B_PER_CLK, CLK_GHZ),
+            "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": code_bytes,
+            "definition": "nq*n*m one-byte table look-ups per launch / kernel time vs %d CU x %d B/clk x %.1f GHz "
+                          "(conflict-free LDS gather rate)" % (NUM_CU, LDS_B_PER_CLK, CLK_GHZ),
+            "f32_table_roof": {"achieved_GBps": round(4.0 * achieved, 1), "frac": round(4.0 * achieved / LDS_PEAK_GBS, 4),
+                               "note": "round-1 formula: 4-byte entries (nq*n*m*4 B); 0.31 in round 1"},
             "hbm": hbm}
 
 

@@ -747,9 +747,14 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
           // all RPT * M gathers of the sub-step are issued before the first sum (16 x ds_read_b64 / 32 x ds_read_b32)
           using FV = typename FiltVec<M>::type;
           const FV *qt = reinterpret_cast<const FV *>(qtab);
+          // gathers in flight together: 16 (M = 8: both rows of the sub-step; M = 16: one row -- 32 of them with
+          // their 32 addresses spill registers in this loop)
+          constexpr int RB = (RPT * M > 16) ? 1 : RPT;      // rows per gather batch
           FV e[RPT][M];
 #pragma unroll
-          for (int r = 0; r < RPT; ++r) {
+          for (int rb = 0; rb < RPT; rb += RB) {
+#pragma unroll
+          for (int r = rb; r < rb + RB; ++r) {
 #pragma unroll
             for (int k = 0; k < M; ++k) {
               const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int r = 0; r < RPT; ++r) {
+          for (int r = rb; r < rb + RB; ++r) {
             uint32_t a[Cfg::NACC * Cfg::NQUAD];
 #pragma unroll
             for (int i = 0; i < Cfg::NACC * Cfg::NQUAD; ++i) a[i] = 0;
@@ -786,6 +791,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
               }
             }
           }
+          __builtin_amdgcn_sched_barrier(0);
+          }  // gather batches
           if (qtail >= 64u) {      // at most RPT * 64 rows were pushed since the last check: qtail < 64 * (RPT + 1) <= FILT_QCAP
             do {
               refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - 64u), 64u);
