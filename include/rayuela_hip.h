@@ -159,7 +159,8 @@ int rq_dev_synth_codes(uint8_t *codes, int64_t n, int m, uint64_t seed, int64_t 
  *   reconstruct     CB[j][subdims_i] = C_i[:, b_ji]                        (src/OPQ.jl:101,128)
  *   qerror          *acc = sum_j |X_j - CB_j|^2 in double (divide by n on the host; src/OPQ.jl:108)
  *   gram            G[a][b] = sum_j X[j][a] * CB[j][b], the d x d input of the SVD at src/OPQ.jl:112
- * Float summation orders differ from the reference's sequential loops: tolerance parity (tests/). */
+ * Float summation orders differ from the reference's sequential loops: tolerance parity (tests/); the order
+ * is fixed (one owner thread per (code, dimension), rows ascending), so results are bit-reproducible. */
 int rq_dev_update_centers(float *C, uint32_t *counts, const float *X, const uint8_t *codes, int64_t n,
                           int d, int m, int h, void *stream);
 int rq_dev_reconstruct(float *CB, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h,
@@ -170,8 +171,8 @@ int rq_dev_gram(float *G, const float *X, const float *CB, int64_t n, int d, voi
 /* train_pq (src/PQ.jl:68-99) and train_opq (src/OPQ.jl:49-139) on host pointers: X [n][d]; outputs
  * C (concat of the m [h][sub_i] codebooks), B1 [n][m] Int16 ONE-based, R [d][d] (memory image of Julia's R),
  * obj [niter+1], *error = qerror_pq of the result.  init: 0 "natural", 1 "random".  R0 / C0 may be NULL;
- * when given they replace the random initialisation (same start; runs still differ at the 1e-4 level of the
- * objective because the centre sums use order-dependent float atomics).  `seed` feeds the library's own
+ * when given they replace the random initialisation.  Every training entry point is bit-reproducible for a
+ * given seed / start (fixed-order segment sums in update_centers, fixed reduction trees).  `seed` feeds the library's own
  * splitmix64 stream -- the reference uses Julia's global RNG, so equal seeds do not mean equal draws. */
 int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n, int d, int m, int h,
                 int niter, uint64_t seed);

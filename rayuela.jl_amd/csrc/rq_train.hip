@@ -32,33 +32,67 @@ struct TrainParams {
   int off[33];
 };
 
-// ---- update_centers, pass 1: per-workgroup partial sums in LDS --------------------------------------
-// LDS: sums [h][d] (column i of sub-quantizer q lives at [code][off_q + s]) + counts [m][h].
-__global__ __launch_bounds__(1024) void centers_partial_kernel(TrainParams p) {
+// ---- update_centers, pass 1: per-workgroup partial sums in LDS, DETERMINISTIC ----------------------------
+// Float addition is not associative, so bit-reproducible centres need a fixed summation order.  Every
+// accumulator (code, dimension) has exactly ONE owner thread and that thread adds the rows of the workgroup's
+// slice in ascending row order: thread t = (g, lane) with g = t / 128 owns the codes [32 g, 32 g + 32) of
+// dimension dc0 + lane -- all 1024 threads walk the slice, each accumulates the rows whose code falls into
+// its range (1/8 of them on average), no atomics on floats.  The slices are combined in fixed order by pass 2.
+// Dimensions are processed in chunks of <= 128 (p.dc0 .. p.dc0 + p.dcw), so h * 128 * 4 B of LDS serve any d.
+// LDS: sums [h][dcw] + counts [m][h] (integer atomics: order-free; written out by the chunk that holds the
+// sub-quantizer's first dimension).
+__global__ __launch_bounds__(1024) void centers_partial_kernel(TrainParams p, int dc0, int dcw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float *sums = reinterpret_cast<float *>(smem);              // h*d
-  float *cnts = sums + (size_t)p.h * p.d;                      // m*h
+  float *sums = reinterpret_cast<float *>(smem);                                 // h * dcw
+  unsigned int *cnts = reinterpret_cast<unsigned int *>(sums + (size_t)p.h * dcw);   // m * h
   const int tid = threadIdx.x;
-  const int hd = p.h * p.d, mh = p.m * p.h;
-  for (int i = tid; i < hd + mh; i += 1024) sums[i] = 0.0f;
+  const int hw = p.h * dcw, mh = p.m * p.h;
+  for (int i = tid; i < hw + mh; i += 1024) sums[i] = 0.0f;      // 0.0f and 0u share the bit pattern
   __syncthreads();
   const int64_t rows_per = (p.n + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(p.n, r0 + rows_per);
-  // one wavefront-lane per dimension group: thread t handles dimension (t % d) of rows t/d, t/d + 1024/d ...
-  // (d <= 1024); every lane of a wavefront touches a different LDS word unless two rows share a code
-  const int dim = tid % p.d, rsub = tid / p.d, rstep = 1024 / p.d;
-  int q = 0;
-  while (q + 1 < p.m && dim >= p.off[q + 1]) ++q;
-  if (rsub < rstep) {
-    for (int64_t r = r0 + rsub; r < r1; r += rstep) {
-      const int code = p.codes[r * p.m + q];
-      atomicAdd(&sums[(size_t)code * p.d + dim], p.X[r * p.d + dim]);
-      if (dim == p.off[q]) atomicAdd(&cnts[q * p.h + code], 1.0f);
+  const int ldim = tid & 127, g = tid >> 7, dim = dc0 + ldim;
+  if (ldim < dcw) {
+    int q = 0;
+    while (q + 1 < p.m && dim >= p.off[q + 1]) ++q;
+    const bool counts_here = (dim == p.off[q]);       // one dimension per sub-quantizer also counts the rows
+    const uint8_t *cq = p.codes + q;
+    const float *xd = p.X + dim;
+    constexpr int U = 8;
+    int64_t r = r0;
+    for (; r + U <= r1; r += U) {
+      int code[U];
+      float x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) code[u] = cq[(r + u) * p.m];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = ((code[u] >> 5) == g) ? xd[(r + u) * p.d] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if ((code[u] >> 5) == g) {
+          sums[code[u] * dcw + ldim] += x[u];
+          if (counts_here) atomicAdd(&cnts[q * p.h + code[u]], 1u);
+        }
+      }
+    }
+    for (; r < r1; ++r) {
+      const int code = cq[r * p.m];
+      if ((code >> 5) == g) {
+        sums[code * dcw + ldim] += xd[r * p.d];
+        if (counts_here) atomicAdd(&cnts[q * p.h + code], 1u);
+      }
     }
   }
   __syncthreads();
-  float *out = p.partial + (size_t)blockIdx.x * (hd + mh);
-  for (int i = tid; i < hd + mh; i += 1024) out[i] = sums[i];
+  // partial layout per workgroup: [h][d] sums, then [m][h] counts (u32 bit patterns)
+  float *out = p.partial + (size_t)blockIdx.x * ((size_t)p.h * p.d + (size_t)p.m * p.h);
+  for (int i = tid; i < hw; i += 1024) out[(size_t)(i / dcw) * p.d + dc0 + (i % dcw)] = sums[i];
+  // counts of the sub-quantizers whose first dimension lies in this chunk
+  unsigned int *oc = reinterpret_cast<unsigned int *>(out + (size_t)p.h * p.d);
+  for (int i = tid; i < mh; i += 1024) {
+    const int q0 = p.off[i / p.h];
+    if (q0 >= dc0 && q0 < dc0 + dcw) oc[i] = cnts[i];
+  }
 }
 
 // pass 2: fixed-order sum over the workgroup partials, mean, write C (empty clusters keep their value)
@@ -69,15 +103,16 @@ __global__ void centers_finish_kernel(TrainParams p, int nparts) {
   const int code = i / p.d, dim = i % p.d;
   int q = 0;
   while (q + 1 < p.m && dim >= p.off[q + 1]) ++q;
-  float s = 0.0f, c = 0.0f;
+  float s = 0.0f;
+  unsigned int c = 0;
   for (int w = 0; w < nparts; ++w) {
     const float *part = p.partial + (size_t)w * (hd + mh);
     s += part[i];
-    c += part[hd + q * p.h + code];
+    c += reinterpret_cast<const unsigned int *>(part + hd)[q * p.h + code];
   }
   const int sub = p.off[q + 1] - p.off[q];
-  if (c > 0.0f) p.C[(size_t)p.h * p.off[q] + (size_t)code * sub + (dim - p.off[q])] = s * (1.0f / c);
-  if (dim == p.off[q]) p.counts[q * p.h + code] = (unsigned int)c;
+  if (c > 0) p.C[(size_t)p.h * p.off[q] + (size_t)code * sub + (dim - p.off[q])] = s * (1.0f / (float)c);
+  if (dim == p.off[q]) p.counts[q * p.h + code] = c;
 }
 
 // ---- reconstruction ----------------------------------------------------------------------------------
@@ -93,8 +128,8 @@ __global__ void reconstruct_kernel(TrainParams p) {
   p.CB[e] = p.C[(size_t)p.h * p.off[q] + (size_t)code * sub + (dim - p.off[q])];
 }
 
-// ---- quantisation error: sum (X - CB)^2 in double ----------------------------------------------------
-__global__ __launch_bounds__(256) void qerror_kernel(TrainParams p) {
+// ---- quantisation error: sum (X - CB)^2 in double, fixed reduction tree (bit-reproducible) ---------------------
+__global__ __launch_bounds__(256) void qerror_kernel(TrainParams p, double *partial) {
   __shared__ double red[256];
   const int64_t total = p.n * p.d;
   double s = 0.0;
@@ -108,7 +143,20 @@ __global__ __launch_bounds__(256) void qerror_kernel(TrainParams p) {
     if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicAdd(p.acc, red[0]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void qerror_finish_kernel(double *acc, const double *partial, int nparts) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *acc = red[0];
 }
 
 // ---- G = X' CB  (d x d), reduced over rows ---------------------------------------------------------------
@@ -189,10 +237,8 @@ static void fill_offsets(int *off, int d, int m) {
 int update_centers_launch(float *C, unsigned int *counts, const float *X, const uint8_t *codes, int64_t n, int d,
                           int m, int h, int num_cu, hipStream_t stream) {
   if (n <= 0) return RQ_OK;
-  if (m < 1 || m > 32 || d < m || d > 1024 || h < 1 || h > 256)
-    return fail(RQ_EUNSUPPORTED, "update_centers covers m <= 32, d <= 1024, h <= 256 (got m=%d d=%d h=%d)", m, d, h);
-  const size_t lds = ((size_t)h * d + (size_t)m * h) * sizeof(float);
-  if (lds > 160 * 1024) return fail(RQ_EUNSUPPORTED, "update_centers: h*d*4 = %zu B exceeds the LDS", lds);
+  if (m < 1 || m > 32 || d < m || h < 1 || h > 256)
+    return fail(RQ_EUNSUPPORTED, "update_centers covers m <= 32, h <= 256 (got m=%d d=%d h=%d)", m, d, h);
   TrainParams p{};
   p.X = X; p.codes = codes; p.C = C; p.counts = counts; p.n = n; p.d = d; p.m = m; p.h = h;
   fill_offsets(p.off, d, m);
@@ -200,10 +246,15 @@ int update_centers_launch(float *C, unsigned int *counts, const float *X, const 
   void *part = nullptr;
   RQ_TRY(workspace(WS_TMP, (size_t)grid * ((size_t)h * d + (size_t)m * h) * sizeof(float), &part, stream));
   p.partial = (float *)part;
-  RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(centers_partial_kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(centers_partial_kernel, dim3(grid), dim3(1024), lds, stream, p);
-  RQ_HIP(hipGetLastError());
+  // dimension chunks of <= 128: h * 128 * 4 B of sums (+ m * h counters in the first chunk) always fit the LDS
+  for (int dc0 = 0; dc0 < d; dc0 += 128) {
+    const int dcw = std::min(128, d - dc0);
+    const size_t lds = ((size_t)h * dcw + (size_t)m * h) * sizeof(float);
+    RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(centers_partial_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(centers_partial_kernel, dim3(grid), dim3(1024), lds, stream, p, dc0, dcw);
+    RQ_HIP(hipGetLastError());
+  }
   hipLaunchKernelGGL(centers_finish_kernel, dim3((h * d + 255) / 256), dim3(256), 0, stream, p, grid);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
@@ -224,11 +275,18 @@ int reconstruct_launch(float *CB, const uint8_t *codes, const float *C, int64_t 
 
 int qerror_launch(double *acc_dev, const float *X, const float *CB, int64_t n, int d, int num_cu,
                   hipStream_t stream) {
-  RQ_HIP(hipMemsetAsync(acc_dev, 0, sizeof(double), stream));
-  if (n <= 0) return RQ_OK;
+  if (n <= 0) {
+    RQ_HIP(hipMemsetAsync(acc_dev, 0, sizeof(double), stream));
+    return RQ_OK;
+  }
   TrainParams p{};
   p.X = X; p.CB = const_cast<float *>(CB); p.acc = acc_dev; p.n = n; p.d = d;
-  hipLaunchKernelGGL(qerror_kernel, dim3(num_cu * 8), dim3(256), 0, stream, p);
+  const int grid = num_cu * 8;
+  void *part = nullptr;
+  RQ_TRY(workspace(WS_MERGE, (size_t)grid * sizeof(double), &part, stream));
+  hipLaunchKernelGGL(qerror_kernel, dim3(grid), dim3(256), 0, stream, p, (double *)part);
+  RQ_HIP(hipGetLastError());
+  hipLaunchKernelGGL(qerror_finish_kernel, dim3(1), dim3(256), 0, stream, acc_dev, (const double *)part, grid);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
 }
