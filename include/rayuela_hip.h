@@ -95,8 +95,8 @@ int rq_encode_rvq_i16(int16_t *codes1, const float *X, const float *codebooks, i
                       uint32_t *counts, float *Xr_out);
 /* train_rvq (src/RVQ.jl:86-127): one k-means of niter Lloyd iterations per stage on the running residual.
  * C [m][h][d] out; B1 [n][m] Int16 one-based out (== quantize_rvq(X, C)); *error = qerror(X, B, C).
- * Seeding: h residual rows drawn from the library's seeded stream (the reference uses kmeans++ with
- * Julia's global RNG), so results agree in objective, not bit for bit.  h*d*4 B must fit the LDS. */
+ * Seeding: kmeans++ on the running residual like the reference (rq_kmpp_seeds), from the library's seeded
+ * stream instead of Julia's global RNG, so results agree in objective, not bit for bit. */
 int rq_train_rvq(float *C, int16_t *B1, double *error, const float *X, int64_t n, int d, int m, int h, int niter,
                  uint64_t seed);
 /* device-pointer form: Xr [n][d] holds X on entry and the final residual on return */
@@ -176,6 +176,13 @@ int rq_dev_gram(float *G, const float *X, const float *CB, int64_t n, int d, voi
  * splitmix64 stream -- the reference uses Julia's global RNG, so equal seeds do not mean equal draws. */
 int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n, int d, int m, int h,
                 int niter, uint64_t seed);
+/* kmeans++ seeding as train_pq / train_rvq use it (Clustering.jl init=:kmpp, call sites src/PQ.jl:86 and
+ * src/RVQ.jl:104): per sub-space the first seed is a uniformly drawn row, every further one is drawn with
+ * probability proportional to the squared distance to the nearest seed so far.  seeds [m][h] (rows of X, may be
+ * NULL), C = concatenation of the m [h][sub_i] seed sub-vectors (may be NULL).  Bit-reproducible for a given
+ * `seed` (the library's splitmix64 stream; Julia's RNG draws differ).  tuning TRAIN_KMPP=0 makes the training
+ * entry points sample h rows uniformly instead. */
+int rq_kmpp_seeds(int64_t *seeds, float *C, const float *X, int64_t n, int d, int m, int h, uint64_t seed);
 int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, int64_t n, int d, int m,
                  int h, int niter, int init, uint64_t seed, const float *R0, const float *C0);
 

@@ -46,7 +46,8 @@ def train_pq(X, m, h, niter=25, V=False, seed=0):
 
     Lloyd's k-means in every subspace (all m subspaces per device pass), through rq_train_pq.
     C: list of m (h, sub_i) codebooks; B: (n, m) int16 one-based; error: qerror_pq of the result.
-    Initial centres come from the library's seeded stream, not Julia's RNG (see include/rayuela_hip.h)."""
+    Initial centres: kmeans++ like the reference (kmeans(..., init=:kmpp)), drawn from the library's seeded
+    stream rather than Julia's RNG (see include/rayuela_hip.h)."""
     X = _as_f32(X, "X")
     n, d = X.shape
     Ccat = np.empty(h * d, dtype=np.float32)
@@ -58,6 +59,17 @@ def train_pq(X, m, h, niter=25, V=False, seed=0):
     if V:
         print("  Error in training is %e" % err.value)
     return _split_codebooks(Ccat, d, m, h), B, float(err.value)
+
+
+def kmpp_seeds(X, m, h, seed=0):
+    """kmeans++ seeding of the m sub-spaces as train_pq uses it (Clustering.jl init=:kmpp, src/PQ.jl:86):
+    returns (seeds (m, h) int64 zero-based rows of X, C list of m (h, sub_i) seed sub-vectors)."""
+    X = _as_f32(X, "X")
+    n, d = X.shape
+    seeds = np.empty((m, h), dtype=np.int64)
+    Ccat = np.empty(h * d, dtype=np.float32)
+    _lib.check(_lib.lib().rq_kmpp_seeds(seeds.ctypes.data, Ccat.ctypes.data, X.ctypes.data, n, d, m, h, seed))
+    return seeds, _split_codebooks(Ccat, d, m, h)
 
 
 def _split_codebooks(Ccat, d, m, h):

@@ -13,7 +13,7 @@ from .OPQ import quantize_opq, rotate  # noqa: F401
 from .RVQ import quantize_rvq, quantize_rvq_u8  # noqa: F401
 
 
-from .PQ import train_pq  # noqa: F401,E402
+from .PQ import train_pq, kmpp_seeds  # noqa: F401,E402
 from .OPQ import train_opq  # noqa: F401,E402
 from .RVQ import train_rvq  # noqa: F401,E402
 from .Linscan import (linscan_pq, linscan_opq, linscan_lsq, linscan_cq, linscan_aqd_query,  # noqa: F401

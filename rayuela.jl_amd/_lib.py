@@ -54,6 +54,7 @@ SIGNATURES = {
     "rq_dev_reconstruct": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rq_dev_qerror": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "rq_dev_gram": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "rq_kmpp_seeds": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _u64]),
     "rq_train_pq": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _u64]),
     "rq_train_opq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _u64, _vp, _vp]),
     "rq_index_create": (_vp, [_i32, _i32, _vp]),

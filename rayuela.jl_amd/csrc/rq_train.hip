@@ -226,6 +226,184 @@ __global__ void gram_finish_kernel(GramParams p, int nparts) {
   p.G[i] = s;
 }
 
+// ---- kmeans++ seeding (D^2 sampling) ------------------------------------------------------------------------
+// Clustering.jl's `init=:kmpp` as used by train_pq / train_rvq (src/PQ.jl:86, src/RVQ.jl:104): the first seed is a
+// uniformly drawn point; every further seed is drawn with probability proportional to mincost[j] = the squared
+// distance of point j to its nearest seed so far (the chosen point's own cost is 0, so seeds are distinct while
+// any cost is left).  All m sub-spaces advance together (blockIdx.y); the h uniform numbers per sub-space come from
+// the library's seeded stream, uploaded once -- no host round trip inside the h steps.  Sums are taken in double
+// with fixed trees, so the seeds are bit-reproducible.
+//   kmpp_update : mincost <- min(mincost, |x - x_seed|^2) over the sub-space, per-block cost sums -> partial
+//   kmpp_select : (one workgroup per sub-space) block with the threshold u * total, then the row inside it;
+//                 writes seeds[i][step] and the seed's sub-vector into C_i[step]
+struct KmppParams {
+  const float *X;       // [n][d]
+  float *C;             // concat of [h][sub_i]
+  float *mincost;       // [m][n]
+  double *partial;      // [m][nblk]
+  long long *seeds;     // [m][h]
+  const double *u;      // [m][h] uniforms in [0, 1)
+  int64_t n, rows_per_blk;
+  int d, m, h, nblk;
+  int off[33];
+};
+
+constexpr int KMPP_THREADS = 1024;
+
+__device__ __forceinline__ double block_sum_1024(double v, double *red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for (int w = KMPP_THREADS / 2; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(KMPP_THREADS) void kmpp_update_kernel(KmppParams p, int step) {
+  __shared__ double red[KMPP_THREADS];
+  const int i = blockIdx.y, o = p.off[i], sub = p.off[i + 1] - o;
+  const long long seed = p.seeds[(size_t)i * p.h + step - 1];       // the seed chosen in the previous step
+  const float *xs = p.X + (size_t)seed * p.d + o;
+  float *mc = p.mincost + (size_t)i * p.n;
+  const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_blk, r1 = min(p.n, r0 + p.rows_per_blk);
+  double acc = 0.0;
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += KMPP_THREADS) {
+    const float *x = p.X + (size_t)r * p.d + o;
+    float dist = 0.0f;
+    for (int s = 0; s < sub; ++s) {
+      const float df = x[s] - xs[s];
+      dist = __builtin_fmaf(df, df, dist);
+    }
+    float c = (step == 1) ? dist : fminf(mc[r], dist);
+    if (r == seed) c = 0.0f;
+    mc[r] = c;
+    acc += (double)c;
+  }
+  const double tot = block_sum_1024(acc, red);
+  if (threadIdx.x == 0) p.partial[(size_t)i * p.nblk + blockIdx.x] = tot;
+}
+
+// first seed: row floor(u * n)
+__global__ void kmpp_first_kernel(KmppParams p) {
+  const int i = blockIdx.x, o = p.off[i], sub = p.off[i + 1] - o;
+  long long row = (long long)(p.u[(size_t)i * p.h] * (double)p.n);
+  row = min(max(row, 0ll), (long long)p.n - 1);
+  if (threadIdx.x == 0) p.seeds[(size_t)i * p.h] = row;
+  for (int s = threadIdx.x; s < sub; s += blockDim.x)
+    p.C[(size_t)p.h * o + s] = p.X[(size_t)row * p.d + o + s];
+}
+
+__global__ __launch_bounds__(KMPP_THREADS) void kmpp_select_kernel(KmppParams p, int step) {
+  __shared__ double red[KMPP_THREADS];
+  __shared__ double scan[KMPP_THREADS];
+  __shared__ long long pick[2];
+  __shared__ double resid;
+  const int tid = threadIdx.x, i = blockIdx.x, o = p.off[i], sub = p.off[i + 1] - o;
+  const double *part = p.partial + (size_t)i * p.nblk;
+  const float *mc = p.mincost + (size_t)i * p.n;
+  // inclusive scan of the block sums (nblk <= 1024: one per thread), Hillis-Steele in double
+  scan[tid] = tid < p.nblk ? part[tid] : 0.0;
+  __syncthreads();
+  for (int w = 1; w < KMPP_THREADS; w <<= 1) {
+    const double v = tid >= w ? scan[tid - w] : 0.0;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  const double total = scan[KMPP_THREADS - 1];
+  const double u = p.u[(size_t)i * p.h + step];
+  if (tid == 0) { pick[0] = -1; pick[1] = -1; }
+  __syncthreads();
+  long long row = -1;
+  if (!(total > 0.0)) {
+    // every point coincides with a seed: any point is as good as another (Clustering's wsample has no answer here)
+    row = min((long long)(u * (double)p.n), (long long)p.n - 1);
+  } else {
+    const double thr = u * total;
+    // first block whose inclusive sum exceeds the threshold (the last non-empty one if rounding leaves none)
+    const double before = tid ? scan[tid - 1] : 0.0;
+    if (tid < p.nblk && scan[tid] > thr && !(before > thr)) { pick[0] = tid; resid = thr - before; }
+    __syncthreads();
+    if (pick[0] < 0) {
+      if (tid == 0) {
+        int b = p.nblk - 1;
+        while (b > 0 && !(part[b] > 0.0)) --b;
+        pick[0] = b;
+        resid = part[b];       // past the end: the last row with a cost in that block
+      }
+      __syncthreads();
+    }
+    const int64_t r0 = pick[0] * p.rows_per_blk, r1 = min(p.n, r0 + p.rows_per_blk);
+    // rows of the block in 1024 contiguous chunks: chunk sums, scan over the chunks, then a walk inside one chunk
+    const int64_t chunk = (r1 - r0 + KMPP_THREADS - 1) / KMPP_THREADS;
+    const int64_t c0 = min(r1, r0 + (int64_t)tid * chunk), c1 = min(r1, c0 + chunk);
+    double cs = 0.0;
+    for (int64_t r = c0; r < c1; ++r) cs += (double)mc[r];
+    red[tid] = cs;
+    scan[tid] = cs;
+    __syncthreads();
+    for (int w = 1; w < KMPP_THREADS; w <<= 1) {
+      const double v = tid >= w ? scan[tid - w] : 0.0;
+      __syncthreads();
+      scan[tid] += v;
+      __syncthreads();
+    }
+    const double rthr = resid;
+    const double cbefore = tid ? scan[tid - 1] : 0.0;
+    if (scan[tid] > rthr && !(cbefore > rthr) && c1 > c0) {
+      double run = cbefore;
+      long long rr = -1;
+      for (int64_t r = c0; r < c1; ++r) {
+        run += (double)mc[r];
+        if (run > rthr && mc[r] > 0.0f) { rr = r; break; }
+      }
+      if (rr < 0)
+        for (int64_t r = c1 - 1; r >= c0; --r) if (mc[r] > 0.0f) { rr = r; break; }
+      pick[1] = rr;
+    }
+    __syncthreads();
+    if (pick[1] < 0 && tid == 0) {      // threshold beyond the block's re-summed total: last row with a cost
+      for (int64_t r = r1 - 1; r >= r0; --r) if (mc[r] > 0.0f) { pick[1] = r; break; }
+      if (pick[1] < 0) pick[1] = r0;
+    }
+    __syncthreads();
+    row = pick[1];
+  }
+  if (tid == 0) p.seeds[(size_t)i * p.h + step] = row;
+  for (int s = tid; s < sub; s += KMPP_THREADS)
+    p.C[(size_t)p.h * o + (size_t)step * sub + s] = p.X[(size_t)row * p.d + o + s];
+}
+
+int kmpp_init_launch(float *C, long long *seeds, float *mincost, double *partial, const double *u, const float *X,
+                     int64_t n, int d, int m, int h, hipStream_t stream) {
+  if (n < 1 || m < 1 || m > 32 || d < m || h < 1) return fail(RQ_EINVAL, "kmeans++: n=%lld d=%d m=%d h=%d", (long long)n, d, m, h);
+  KmppParams p{};
+  p.X = X; p.C = C; p.mincost = mincost; p.partial = partial; p.seeds = seeds; p.u = u;
+  p.n = n; p.d = d; p.m = m; p.h = h;
+  p.nblk = (int)std::min<int64_t>(KMPP_THREADS, (n + KMPP_THREADS - 1) / KMPP_THREADS);
+  p.rows_per_blk = (n + p.nblk - 1) / p.nblk;
+  p.nblk = (int)((n + p.rows_per_blk - 1) / p.rows_per_blk);
+  {
+    const int per = d / m, extra = d % m;
+    int pos = 0;
+    for (int i = 0; i < m; ++i) { p.off[i] = pos; pos += per + (i < extra ? 1 : 0); }
+    p.off[m] = pos;
+  }
+  hipLaunchKernelGGL(kmpp_first_kernel, dim3(m), dim3(64), 0, stream, p);
+  RQ_HIP(hipGetLastError());
+  for (int step = 1; step < h; ++step) {
+    hipLaunchKernelGGL(kmpp_update_kernel, dim3(p.nblk, m), dim3(KMPP_THREADS), 0, stream, p, step);
+    hipLaunchKernelGGL(kmpp_select_kernel, dim3(m), dim3(KMPP_THREADS), 0, stream, p, step);
+  }
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+int kmpp_partial_count(int64_t n) { return KMPP_THREADS; }
+
 // ------------------------------------------------------------------------------------------------------
 static void fill_offsets(int *off, int d, int m) {
   const int per = d / m, extra = d % m;

@@ -4,9 +4,10 @@
 // X is uploaded once and every O(n) step of every iteration runs on the device (encode, rotation and the
 // reductions of rq_train.hip).  What stays on the host is what the reference keeps in scalar Julia/LAPACK:
 // the d x d SVD of X CB' (a one-sided Jacobi in double here: no LAPACK dependency) and the bookkeeping.
-// Randomness (initial centres, re-seeding of empty clusters, init == random) comes from a splitmix64
-// stream seeded by the caller -- the reference draws from Julia's global RNG, so runs are comparable
-// statistically, not bit for bit (stated in DESIGN.md).
+// Initial centres of train_pq / train_rvq come from kmeans++ (D^2 sampling on the device, rq_train.hip), like the
+// reference's kmeans(..., init=:kmpp); train_opq samples h rows like src/OPQ.jl:82.  Randomness (the uniforms of
+// kmeans++, sampled rows, re-seeding of empty clusters, init == random) comes from a splitmix64 stream seeded by
+// the caller -- the reference draws from Julia's global RNG, so runs are comparable statistically, not bit for bit.
 #include <math.h>
 #include <string.h>
 
@@ -175,6 +176,24 @@ static int init_centers(float *dC, const float *dX, int64_t n, int d, int m, int
   return RQ_OK;
 }
 
+// initial centres by kmeans++ (src/PQ.jl:86 / src/RVQ.jl:104: kmeans(..., init=:kmpp)); seeds_out (host, may be NULL)
+// receives the m x h chosen rows.  TRAIN_KMPP=0 falls back to uniformly sampled rows.
+static int seed_centers(float *dC, const float *dX, int64_t n, int d, int m, int h, const int *off, Rng &rng,
+                        long long *seeds_out = nullptr) {
+  if (!tuning("TRAIN_KMPP", 1) && !seeds_out) return init_centers(dC, dX, n, d, m, h, off, rng);
+  DevMem dseeds, dmin, dpart, du;
+  RQ_TRY(dseeds.alloc((size_t)m * h * 8)); RQ_TRY(dmin.alloc((size_t)m * n * 4));
+  RQ_TRY(dpart.alloc((size_t)m * 1024 * 8)); RQ_TRY(du.alloc((size_t)m * h * 8));
+  std::vector<double> u((size_t)m * h);
+  for (auto &x : u) x = rng.uniform();
+  RQ_HIP(hipMemcpy(du.p, u.data(), u.size() * 8, hipMemcpyHostToDevice));
+  RQ_TRY(kmpp_init_launch(dC, dseeds.as<long long>(), dmin.as<float>(), dpart.as<double>(), du.as<double>(), dX, n, d, m,
+                          h, nullptr));
+  RQ_HIP(hipDeviceSynchronize());
+  if (seeds_out) RQ_HIP(hipMemcpy(seeds_out, dseeds.p, (size_t)m * h * 8, hipMemcpyDeviceToHost));
+  return RQ_OK;
+}
+
 static int check_train(int64_t n, int d, int m, int h, int niter) {
   if (n < 1 || d < 1 || m < 1 || m > 32 || d < m || h < 1 || h > 256 || niter < 0)
     return fail(RQ_EINVAL, "train: n=%lld d=%d m=%d h=%d niter=%d", (long long)n, d, m, h, niter);
@@ -187,6 +206,25 @@ static int check_train(int64_t n, int d, int m, int h, int niter) {
 using namespace rq;
 
 extern "C" {
+
+int rq_kmpp_seeds(int64_t *seeds, float *C, const float *X, int64_t n, int d, int m, int h, uint64_t seed) {
+  RQ_TRY(check_train(n, d, m, h, 0));
+  if (!seeds && !C) return fail(RQ_EINVAL, "rq_kmpp_seeds: nothing to return");
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  DeviceLock call_lock;
+  int off[33];
+  offsets(off, d, m);
+  Rng rng{seed * 0x9E3779B97F4A7C15ull + 1};
+  DevMem dX, dC;
+  RQ_TRY(dX.alloc((size_t)n * d * 4)); RQ_TRY(dC.alloc((size_t)h * d * 4));
+  RQ_HIP(hipMemcpy(dX.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice));
+  std::vector<long long> sd((size_t)m * h);
+  RQ_TRY(seed_centers(dC.as<float>(), dX.as<float>(), n, d, m, h, off, rng, sd.data()));
+  if (seeds) for (size_t i = 0; i < sd.size(); ++i) seeds[i] = (int64_t)sd[i];
+  if (C) RQ_HIP(hipMemcpy(C, dC.p, (size_t)h * d * 4, hipMemcpyDeviceToHost));
+  return RQ_OK;
+}
 
 int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n, int d, int m, int h, int niter,
                 uint64_t seed) {
@@ -202,7 +240,7 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
   RQ_TRY(dprev.alloc((size_t)n * m)); RQ_TRY(dcnt.alloc((size_t)m * h * 4)); RQ_TRY(dCB.alloc((size_t)n * d * 4));
   RQ_TRY(dacc.alloc(8)); RQ_TRY(d16.alloc((size_t)n * m * 2));
   RQ_HIP(hipMemcpy(dX.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice));
-  RQ_TRY(init_centers(dC.as<float>(), dX.as<float>(), n, d, m, h, off, rng));
+  RQ_TRY(seed_centers(dC.as<float>(), dX.as<float>(), n, d, m, h, off, rng));
   std::vector<unsigned int> counts((size_t)m * h);
   std::vector<uint8_t> cur((size_t)n * m), prev;
   for (int it = 0; it < niter; ++it) {
@@ -255,7 +293,7 @@ int rq_train_rvq(float *C, int16_t *B1, double *error, const float *X, int64_t n
   std::vector<unsigned int> counts((size_t)h);
   std::vector<uint8_t> cur((size_t)n), prev;
   for (int i = 0; i < m; ++i) {
-    RQ_TRY(init_centers(dCi.as<float>(), dXr.as<float>(), n, d, 1, h, off1, rng));
+    RQ_TRY(seed_centers(dCi.as<float>(), dXr.as<float>(), n, d, 1, h, off1, rng));
     prev.clear();
     for (int it = 0; it < niter; ++it) {
       RQ_TRY(encode_launch(dstage.as<uint8_t>(), dXr.as<float>(), dCi.as<float>(), n, d, 1, h, di.num_cu, nullptr));

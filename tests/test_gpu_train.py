@@ -160,3 +160,49 @@ def test_update_centers_any_width(rq):
         Cn = to.update_centers(C, X, codes, off, h)
         assert np.allclose(Ccat.cpu().numpy(), np.concatenate([c.reshape(-1) for c in Cn]), rtol=1e-5, atol=1e-5)
         assert np.array_equal(counts, np.stack([np.bincount(codes[:, i], minlength=h) for i in range(m)]))
+
+
+def test_kmeanspp_seeding(rq):
+    """init=:kmpp (src/PQ.jl:86): seeds are distinct rows of X, the returned centres are exactly their sub-vectors,
+    D^2 sampling covers well-separated clusters (uniform row sampling does not), and the draw is reproducible."""
+    rng = np.random.default_rng(3)
+    ncl, per, d, m = 48, 400, 16, 2
+    centres = rng.uniform(-1000, 1000, (ncl, d)).astype(np.float32)
+    X = (centres[np.repeat(np.arange(ncl), per)] + rng.standard_normal((ncl * per, d)).astype(np.float32)).astype(np.float32)
+    X = X[rng.permutation(X.shape[0])]
+    seeds, C = rq.kmpp_seeds(X, m, ncl, seed=11)
+    assert seeds.shape == (m, ncl) and seeds.min() >= 0 and seeds.max() < X.shape[0]
+    sub = d // m
+    for i in range(m):
+        assert len(set(seeds[i].tolist())) == ncl                                   # distinct points
+        assert np.array_equal(C[i], X[seeds[i], i * sub:(i + 1) * sub])             # centres ARE the chosen rows
+        # which cluster does every seed come from?  D^2 sampling: (almost) one seed per cluster
+        lab = ((X[seeds[i], None, i * sub:(i + 1) * sub] - centres[None, :, i * sub:(i + 1) * sub]) ** 2).sum(-1).argmin(1)
+        assert len(set(lab.tolist())) >= ncl - 2
+    s2, C2 = rq.kmpp_seeds(X, m, ncl, seed=11)
+    assert np.array_equal(seeds, s2)
+    s3, _ = rq.kmpp_seeds(X, m, ncl, seed=12)
+    assert not np.array_equal(seeds, s3)
+    # uniform row sampling of the same size leaves ~ncl/e clusters without a seed: the contrast the test relies on
+    uni = rng.integers(0, X.shape[0], ncl)
+    lab_u = ((X[uni, None, :sub] - centres[None, :, :sub]) ** 2).sum(-1).argmin(1)
+    assert len(set(lab_u.tolist())) < ncl - 5
+    # identical points: every cost is 0 after the first seed; the call must still return h valid rows
+    Z = np.ones((500, 8), dtype=np.float32)
+    sz, _ = rq.kmpp_seeds(Z, 1, 16, seed=1)
+    assert sz.min() >= 0 and sz.max() < 500
+
+
+def test_train_pq_with_kmeanspp_beats_uniform_seeding_on_clustered_data(rq):
+    rng = np.random.default_rng(4)
+    ncl, per, d = 64, 300, 32
+    centres = rng.uniform(-500, 500, (ncl, d)).astype(np.float32)
+    X = (centres[np.repeat(np.arange(ncl), per)] + rng.standard_normal((ncl * per, d))).astype(np.float32)
+    X = X[rng.permutation(X.shape[0])]
+    _, _, e_pp = rq.train_pq(X, 4, 64, niter=2, seed=5)
+    rq.set_tuning("TRAIN_KMPP", 0)
+    try:
+        _, _, e_uni = rq.train_pq(X, 4, 64, niter=2, seed=5)
+    finally:
+        rq.set_tuning("TRAIN_KMPP", 1)
+    assert e_pp < e_uni
