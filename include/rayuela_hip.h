@@ -103,7 +103,10 @@ int rq_train_rvq(float *C, int16_t *B1, double *error, const float *X, int64_t n
 int rq_dev_encode_rvq(uint8_t *codes, float *Xr, const float *codebooks, int64_t n, int d, int m, int h,
                       uint32_t *counts, void *stream);
 
-/* ---- host-pointer entry points (what the julia/ shims ccall) ---------------------------------- */
+/* ---- host-pointer entry points (what the julia/ shims ccall) ----------------------------------
+ * rq_encode_*: X is uploaded in ~128 MB chunks while the previous chunk is encoded (the call is PCIe-bound).  With
+ * RAYUELA_HIP_DEVICES listing several devices the rows are split over them, one host thread and one PCIe link
+ * per device; rq_linscan_* then shard the base (see the index handle below). */
 /* linscan_pq (src/Linscan.jl:5-26).  id_base = 1 folds Julia's `res .+= 1` into the kernel. */
 int rq_linscan_pq(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers,
                   const float *queries, int64_t n, int64_t nq, int m, int d, int k, int id_base);
@@ -121,6 +124,15 @@ int rq_encode_pq_i16(int16_t *codes1, const float *X, const float *C, int64_t n,
                      int h);
 int rq_encode_opq_i16(int16_t *codes1, const float *X, const float *R, const float *C, int64_t n,
                       int d, int m, int h);
+/* A base set kept on the device: upload X [n][d] once (to the calling thread's current device), encode it as often
+ * as needed -- quantize_pq and quantize_opq of the same Xb with different codebooks / rotations pay PCIe once
+ * (from host memory quantize_pq is upload-bound: ~9 ms of PCIe against 0.7 ms of kernel per 1e6 x 128).
+ * rq_dataset_encode: R == NULL -> quantize_pq (src/PQ.jl:18-48), else quantize_opq (src/OPQ.jl:19-27); codes
+ * [n][m] uint8 zero-based and/or codes1 m x n Int16 one-based (either may be NULL). */
+typedef struct rq_dataset rq_dataset;
+rq_dataset *rq_dataset_upload(const float *X, int64_t n, int d);
+int rq_dataset_encode(rq_dataset *ds, uint8_t *codes, int16_t *codes1, const float *R, const float *C, int m, int h);
+void rq_dataset_free(rq_dataset *ds);
 /* RX = R' * X (src/OPQ.jl:26, src/Linscan.jl:102). */
 int rq_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n);
 

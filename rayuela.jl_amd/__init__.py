@@ -19,7 +19,7 @@ from .RVQ import train_rvq  # noqa: F401,E402
 from .Linscan import (linscan_pq, linscan_opq, linscan_lsq, linscan_cq, linscan_aqd_query,  # noqa: F401
                       linscan_aqd_query_extra_byte, eval_recall)
 
-from .index import Index  # noqa: F401,E402
+from .index import Index, Dataset  # noqa: F401,E402
 
 __all__ = ["quantize_pq", "quantize_opq", "linscan_pq", "linscan_opq", "linscan_lsq", "linscan_cq",
            "eval_recall", "splitarray"]

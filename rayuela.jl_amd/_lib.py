@@ -42,6 +42,9 @@ SIGNATURES = {
     "rq_encode_rvq_i16": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "rq_train_rvq": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, C.c_uint64]),
     "rq_dev_encode_rvq": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "rq_dataset_upload": (_vp, [_vp, _i64, _i32]),
+    "rq_dataset_encode": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32]),
+    "rq_dataset_free": (None, [_vp]),
     "rq_rotate_T": (_i32, [_vp, _vp, _vp, _i32, _i64]),
     "rq_dev_encode_pq": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rq_dev_rotate_T": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp]),

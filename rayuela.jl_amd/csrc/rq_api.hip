@@ -7,6 +7,7 @@
 #include <chrono>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include <vector>
 #include "rq_internal.h"
@@ -413,51 +414,112 @@ static int host_linscan_aq(float *dists, uint32_t *ids, const uint8_t *codes, co
   return RQ_OK;
 }
 
-static int host_encode(uint8_t *codes, int16_t *codes1, const float *X, const float *R, const float *C,
-                       int64_t n, int d, int m, int h) {
-  Timer tt;
-  g_t_h2d = g_t_kernel = g_t_d2h = 0;
-  if (n <= 0) return RQ_OK;
-  if (d < 1 || m < 1 || h < 1) return fail(RQ_EINVAL, "bad shape d=%d m=%d h=%d", d, m, h);
+// quantize_pq / quantize_opq of rows [0, n) of a HOST matrix on the current device.  The rows are uploaded in
+// chunks of ~128 MB on a transfer stream while the previous chunk is rotated / encoded on the compute stream
+// (two device buffers; the codes stay on the device and come back in ONE copy at the end -- a pageable D2H per
+// chunk would make the host wait for each kernel and serialise the pipeline).  PCIe is the bound of this call
+// (57 GB/s from pageable memory): the kernels now hide behind the uploads instead of adding to them.
+static int encode_host_rows(uint8_t *codes, int16_t *codes1, const float *X, const float *R, const float *C,
+                            int64_t n, int d, int m, int h, double *t_h2d, double *t_tail) {
   DeviceInfo di;
   RQ_TRY(device_info(&di));
   DeviceLock call_lock;   // host-pointer calls on one device run one at a time (shared scratch + streams)
-  // chunk the rows so X never needs more than ~1 GiB of device memory per chunk
-  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (1LL << 30) / ((int64_t)d * 4)));
-  DevBuf dX, dRX, dR, dC, dcodes, d16;
-  RQ_TRY(dX.alloc((size_t)chunk * d * 4));
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, std::max<int64_t>(32768, (1LL << 27) / ((int64_t)d * 4))));
+  const bool piped = tuning("HOST_OVERLAP", 1) && n > chunk;
+  DevBuf dX[2], dRX, dR, dC, dcodes, d16;
+  RQ_TRY(dX[0].alloc((size_t)chunk * d * 4));
+  if (piped) RQ_TRY(dX[1].alloc((size_t)chunk * d * 4));
   RQ_TRY(dC.alloc((size_t)h * d * 4));
-  RQ_TRY(dcodes.alloc((size_t)chunk * m));
-  if (codes1) RQ_TRY(d16.alloc((size_t)chunk * m * 2));
+  RQ_TRY(dcodes.alloc((size_t)n * m));
+  if (codes1) RQ_TRY(d16.alloc((size_t)n * m * 2));
   RQ_HIP(hipMemcpy(dC.p, C, (size_t)h * d * 4, hipMemcpyHostToDevice));
   if (R) {
     RQ_TRY(dR.alloc((size_t)d * d * 4));
     RQ_TRY(dRX.alloc((size_t)chunk * d * 4));
     RQ_HIP(hipMemcpy(dR.p, R, (size_t)d * d * 4, hipMemcpyHostToDevice));
   }
-  for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+  hipStream_t cs = nullptr, xs = nullptr;
+  RQ_TRY(aux_streams(&cs, &xs));
+  struct Events {
+    hipEvent_t up[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    ~Events() { for (int i = 0; i < 2; ++i) { if (up[i]) (void)hipEventDestroy(up[i]); if (done[i]) (void)hipEventDestroy(done[i]); } }
+  } ev;
+  for (int i = 0; i < 2; ++i) {
+    RQ_HIP(hipEventCreateWithFlags(&ev.up[i], hipEventDisableTiming));
+    RQ_HIP(hipEventCreateWithFlags(&ev.done[i], hipEventDisableTiming));
+  }
+  RQ_HIP(hipDeviceSynchronize());      // the small uploads on the null stream are done
+  int k = 0;
+  for (int64_t r0 = 0; r0 < n; r0 += chunk, ++k) {
     const int64_t nr = std::min(chunk, n - r0);
+    const int b = piped ? (k & 1) : 0;
+    if (k >= (piped ? 2 : 1)) RQ_HIP(hipEventSynchronize(ev.done[b]));   // the kernels that read this buffer are done
     Timer t1;
-    RQ_HIP(hipMemcpy(dX.p, X + (size_t)r0 * d, (size_t)nr * d * 4, hipMemcpyHostToDevice));
-    g_t_h2d += t1.ms();
-    Timer t2;
-    const float *src = dX.as<float>();
+    RQ_HIP(hipMemcpyAsync(dX[b].p, X + (size_t)r0 * d, (size_t)nr * d * 4, hipMemcpyHostToDevice, xs));
+    RQ_HIP(hipEventRecord(ev.up[b], xs));
+    *t_h2d += t1.ms();
+    RQ_HIP(hipStreamWaitEvent(cs, ev.up[b], 0));
+    const float *src = dX[b].as<float>();
     if (R) {
-      RQ_TRY(rotate_launch(dRX.as<float>(), dR.as<float>(), dX.as<float>(), d, nr, di.num_cu, nullptr));
+      RQ_TRY(rotate_launch(dRX.as<float>(), dR.as<float>(), dX[b].as<float>(), d, nr, di.num_cu, cs));
       src = dRX.as<float>();
     }
-    RQ_TRY(encode_launch(dcodes.as<uint8_t>(), src, dC.as<float>(), nr, d, m, h, di.num_cu, nullptr));
-    if (codes1) RQ_TRY(widen_codes_launch(d16.as<int16_t>(), dcodes.as<uint8_t>(), nr * m, nullptr));
-    RQ_HIP(hipDeviceSynchronize());
-    g_t_kernel += t2.ms();
-    Timer t3;
-    if (codes1)
-      RQ_HIP(hipMemcpy(codes1 + (size_t)r0 * m, d16.p, (size_t)nr * m * 2, hipMemcpyDeviceToHost));
-    else
-      RQ_HIP(hipMemcpy(codes + (size_t)r0 * m, dcodes.p, (size_t)nr * m, hipMemcpyDeviceToHost));
-    g_t_d2h += t3.ms();
+    RQ_TRY(encode_launch(dcodes.as<uint8_t>() + (size_t)r0 * m, src, dC.as<float>(), nr, d, m, h, di.num_cu, cs));
+    RQ_HIP(hipEventRecord(ev.done[b], cs));
   }
+  Timer t2;
+  if (codes1) RQ_TRY(widen_codes_launch(d16.as<int16_t>(), dcodes.as<uint8_t>(), n * m, cs));
+  RQ_HIP(hipStreamSynchronize(cs));
+  if (codes1) RQ_HIP(hipMemcpy(codes1, d16.p, (size_t)n * m * 2, hipMemcpyDeviceToHost));
+  else RQ_HIP(hipMemcpy(codes, dcodes.p, (size_t)n * m, hipMemcpyDeviceToHost));
+  *t_tail += t2.ms();
+  return RQ_OK;
+}
+
+static int host_encode(uint8_t *codes, int16_t *codes1, const float *X, const float *R, const float *C,
+                       int64_t n, int d, int m, int h) {
+  Timer tt;
+  g_t_h2d = g_t_kernel = g_t_d2h = 0;
+  if (n <= 0) return RQ_OK;
+  if (d < 1 || m < 1 || h < 1) return fail(RQ_EINVAL, "bad shape d=%d m=%d h=%d", d, m, h);
+  int devs[64];
+  const int nd = env_devices(devs, 64);
+  if (nd > 1 && n >= 2 * nd) {
+    // RAYUELA_HIP_DEVICES lists several devices: the rows are independent, so every device encodes its own
+    // contiguous share.  One host thread per device -- pageable uploads block the issuing thread, and every GPU
+    // has its own PCIe link, so the host-to-device rate scales with the devices.
+    std::vector<std::thread> th;
+    std::vector<int> rc(nd, RQ_OK);
+    std::vector<std::string> msg(nd);
+    std::vector<double> h2d(nd, 0.0), tail(nd, 0.0);
+    const int64_t per = n / nd, extra = n % nd;
+    int64_t row = 0;
+    for (int i = 0; i < nd; ++i) {
+      const int64_t cnt = per + (i < extra ? 1 : 0), r0 = row;
+      row += cnt;
+      th.emplace_back([&, i, r0, cnt]() {
+        if (hipSetDevice(devs[i]) != hipSuccess) { rc[i] = RQ_ENODEVICE; msg[i] = "hipSetDevice failed"; return; }
+        rc[i] = encode_host_rows(codes ? codes + (size_t)r0 * m : nullptr, codes1 ? codes1 + (size_t)r0 * m : nullptr,
+                                 X + (size_t)r0 * d, R, C, cnt, d, m, h, &h2d[i], &tail[i]);
+        if (rc[i] != RQ_OK) msg[i] = g_err;
+      });
+    }
+    for (auto &t : th) t.join();
+    for (int i = 0; i < nd; ++i)
+      if (rc[i] != RQ_OK) return fail(rc[i], "device %d: %s", devs[i], msg[i].c_str());
+    g_t_h2d = *std::max_element(h2d.begin(), h2d.end());
+    g_t_d2h = *std::max_element(tail.begin(), tail.end());
+    g_t_total = tt.ms();
+    g_t_kernel = 0;
+    return RQ_OK;
+  }
+  if (nd == 1) RQ_HIP(hipSetDevice(devs[0]));
+  double h2d = 0, tail = 0;
+  RQ_TRY(encode_host_rows(codes, codes1, X, R, C, n, d, m, h, &h2d, &tail));
+  g_t_h2d = h2d;
+  g_t_d2h = tail;          // what is left after the last upload: last chunk's kernels + the one copy back
   g_t_total = tt.ms();
+  g_t_kernel = std::max(0.0, g_t_total - h2d - tail);
   return RQ_OK;
 }
 
@@ -594,6 +656,84 @@ int rq_encode_opq_i16(int16_t *codes1, const float *X, const float *R, const flo
                       int h) {
   if (!R) return fail(RQ_EINVAL, "R is NULL");
   return host_encode(nullptr, codes1, X, R, C, n, d, m, h);
+}
+
+// ---- resident dataset: X uploaded once, encoded as often as needed ------------------------------------------
+struct rq_dataset_impl {
+  int device, d;
+  int64_t n;
+  float *X, *RX;
+};
+
+rq_dataset *rq_dataset_upload(const float *X, int64_t n, int d) {
+  if (!X || n < 1 || d < 1) { fail(RQ_EINVAL, "rq_dataset_upload: bad arguments"); return nullptr; }
+  DeviceInfo di;
+  if (device_info(&di) != RQ_OK) return nullptr;
+  rq_dataset_impl *ds = new rq_dataset_impl{di.device, d, n, nullptr, nullptr};
+  if (hipMalloc((void **)&ds->X, (size_t)n * d * 4) != hipSuccess ||
+      hipMemcpy(ds->X, X, (size_t)n * d * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    fail(RQ_ENODEVICE, "rq_dataset_upload: cannot place %lld x %d floats on device %d", (long long)n, d, di.device);
+    (void)hipGetLastError();
+    if (ds->X) (void)hipFree(ds->X);
+    delete ds;
+    return nullptr;
+  }
+  return reinterpret_cast<rq_dataset *>(ds);
+}
+
+int rq_dataset_encode(rq_dataset *handle, uint8_t *codes, int16_t *codes1, const float *R, const float *C, int m, int h) {
+  rq_dataset_impl *ds = reinterpret_cast<rq_dataset_impl *>(handle);
+  if (!ds || !C || (!codes && !codes1)) return fail(RQ_EINVAL, "rq_dataset_encode: bad arguments");
+  if (m < 1 || h < 1 || ds->d < m) return fail(RQ_EINVAL, "bad shape d=%d m=%d h=%d", ds->d, m, h);
+  Timer tt;
+  int cur = 0;
+  RQ_HIP(hipGetDevice(&cur));
+  struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{cur};
+  RQ_HIP(hipSetDevice(ds->device));
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  DeviceLock call_lock;
+  const int d = ds->d;
+  const int64_t n = ds->n;
+  DevBuf dC, dR, dcodes, d16;
+  RQ_TRY(dC.alloc((size_t)h * d * 4)); RQ_TRY(dcodes.alloc((size_t)n * m));
+  RQ_HIP(hipMemcpy(dC.p, C, (size_t)h * d * 4, hipMemcpyHostToDevice));
+  const float *src = ds->X;
+  if (R) {
+    RQ_TRY(dR.alloc((size_t)d * d * 4));
+    RQ_HIP(hipMemcpy(dR.p, R, (size_t)d * d * 4, hipMemcpyHostToDevice));
+    if (!ds->RX) RQ_HIP(hipMalloc((void **)&ds->RX, (size_t)n * d * 4));
+    RQ_TRY(rotate_launch(ds->RX, dR.as<float>(), ds->X, d, n, di.num_cu, nullptr));
+    src = ds->RX;
+  }
+  RQ_TRY(encode_launch(dcodes.as<uint8_t>(), src, dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
+  if (codes1) {
+    RQ_TRY(d16.alloc((size_t)n * m * 2));
+    RQ_TRY(widen_codes_launch(d16.as<int16_t>(), dcodes.as<uint8_t>(), n * m, nullptr));
+  }
+  RQ_HIP(hipDeviceSynchronize());
+  g_t_h2d = 0;
+  g_t_kernel = tt.ms();
+  Timer t3;
+  if (codes1) RQ_HIP(hipMemcpy(codes1, d16.p, (size_t)n * m * 2, hipMemcpyDeviceToHost));
+  if (codes) RQ_HIP(hipMemcpy(codes, dcodes.p, (size_t)n * m, hipMemcpyDeviceToHost));
+  g_t_d2h = t3.ms();
+  g_t_total = tt.ms();
+  return RQ_OK;
+}
+
+void rq_dataset_free(rq_dataset *handle) {
+  rq_dataset_impl *ds = reinterpret_cast<rq_dataset_impl *>(handle);
+  if (!ds) return;
+  int cur = 0;
+  const bool have = hipGetDevice(&cur) == hipSuccess;
+  if (hipSetDevice(ds->device) == hipSuccess) {
+    if (ds->X) (void)hipFree(ds->X);
+    if (ds->RX) (void)hipFree(ds->RX);
+  }
+  if (have) (void)hipSetDevice(cur);
+  (void)hipGetLastError();
+  delete ds;
 }
 
 int rq_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n) {

@@ -80,3 +80,41 @@ class Index:
 
     def __exit__(self, *exc):
         self.close()
+
+
+class Dataset:
+    """A base set resident on the device (rq_dataset_*): uploaded once, encoded as often as needed."""
+
+    def __init__(self, X):
+        X = _as_f32(X, "X")
+        self.n, self.d = X.shape
+        self._h = _lib.lib().rq_dataset_upload(X.ctypes.data, self.n, self.d)
+        if not self._h:
+            raise _lib.RayuelaHipError("rq_dataset_upload: " + _lib.lib().rq_last_error().decode("utf-8", "replace"))
+
+    def quantize(self, C_list, R=None, one_based=True):
+        """quantize_pq(X, C) (R is None) or quantize_opq(X, R, C): (n, m) int16 one-based like the reference's
+        return value, or uint8 zero-based (the scan's wire format) with one_based=False."""
+        from .utils import cat_codebooks
+        m = len(C_list)
+        h = C_list[0].shape[0]
+        Cc = np.ascontiguousarray(cat_codebooks(C_list), dtype=np.float32)
+        Rp = None if R is None else _as_f32(R, "R")
+        out = np.empty((self.n, m), dtype=np.int16 if one_based else np.uint8)
+        _lib.check(_lib.lib().rq_dataset_encode(self._h, None if one_based else out.ctypes.data,
+                                                out.ctypes.data if one_based else None,
+                                                None if Rp is None else Rp.ctypes.data, Cc.ctypes.data, m, h))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().rq_dataset_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

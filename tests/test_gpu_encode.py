@@ -105,3 +105,41 @@ def test_device_entry_points_and_full_size(rq, oracle):
     codes_o = rqd.encode_opq(X, R, Ccat, m, h)
     ref_o = oracle.encode_opq(X[sel].cpu().numpy(), R.cpu().numpy(), synth.cat_codebooks(C), m, h)
     assert np.array_equal(codes_o[sel].cpu().numpy(), ref_o)
+
+
+def test_host_path_pipelined_chunks_and_device_list(rq, oracle, monkeypatch):
+    """rq_encode_* uploads X in chunks while the previous chunk is encoded; with RAYUELA_HIP_DEVICES the rows are
+    split over the listed devices (here the same GPU three times: three host threads, three row ranges)."""
+    import rayuela_jl_amd.synth as synth
+    n, d, m, h = 300_001, 128, 8, 256          # > one 262144-row chunk, ragged
+    X = synth.sift_like(n, d, seed=77)
+    C = synth.codebooks(X, m, h, seed=78, iters=1, sample=4000)
+    R = synth.rotation(d, seed=79)
+    ref = oracle.encode_pq(X, synth.cat_codebooks(C), m, h)
+    ref_o = oracle.encode_opq(X, R, synth.cat_codebooks(C), m, h)
+    assert np.array_equal(rq.quantize_pq_u8(X, C), ref)
+    assert np.array_equal(rq.quantize_opq(X, R, C), ref_o.astype(np.int16) + 1)
+    monkeypatch.setenv("RAYUELA_HIP_DEVICES", "0,0,0")
+    assert np.array_equal(rq.quantize_pq_u8(X, C), ref)
+    assert np.array_equal(rq.quantize_pq(X, C), ref.astype(np.int16) + 1)
+    assert np.array_equal(rq.quantize_opq(X, R, C), ref_o.astype(np.int16) + 1)
+    monkeypatch.delenv("RAYUELA_HIP_DEVICES")
+    rq.set_tuning("HOST_OVERLAP", 0)
+    try:
+        assert np.array_equal(rq.quantize_pq_u8(X, C), ref)
+    finally:
+        rq.set_tuning("HOST_OVERLAP", 1)
+
+
+def test_resident_dataset_encodes_match_the_host_calls(rq, oracle):
+    import rayuela_jl_amd.synth as synth
+    n, d, m, h = 50_000, 96, 16, 256
+    X = synth.deep_like(n, d, seed=5)
+    C = synth.codebooks(X, m, h, seed=6, iters=1, sample=4000)
+    C2 = synth.codebooks(X, 8, 64, seed=7, iters=1, sample=4000)
+    R = synth.rotation(d, seed=8)
+    with rq.Dataset(X) as ds:
+        assert np.array_equal(ds.quantize(C), rq.quantize_pq(X, C))
+        assert np.array_equal(ds.quantize(C, R=R), rq.quantize_opq(X, R, C))
+        assert np.array_equal(ds.quantize(C2, one_based=False), oracle.encode_pq(X, synth.cat_codebooks(C2), 8, 64))
+        assert np.array_equal(ds.quantize(C), rq.quantize_pq(X, C))        # X itself is untouched by the OPQ call
