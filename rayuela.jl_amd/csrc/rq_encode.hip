@@ -647,6 +647,72 @@ __global__ __launch_bounds__(NWAVES * 64) void rotate_kernel(RotParams p) {
   }
 }
 
+// Rotation for any d (GIST-960, MNIST-784, ...): neither R nor a 32 x d tile of X fits the LDS, so both are
+// chunked.  A wavefront owns 32 vectors and keeps TG = 8 output tiles (256 outputs, 128 accumulator registers)
+// alive across the k chunks; per chunk of KC = 32 dimensions the workgroup stages the 256 x 32 panel of R in
+// A-fragment order (32 KiB) and every wavefront its 32 x 32 slice of X (transposed, stride 33).  The chain of an
+// output is still k = 0..d-1 in order (zero padding adds fma(0, x, acc) = acc), i.e. the oracle's fmaf chain.
+// X is re-read ceil(d / 256) times; this path is about coverage, not the roofline (the BASELINE shapes take
+// the register-resident kernels above).
+template <int NWAVES, int TG, int KC>
+__global__ __launch_bounds__(NWAVES * 64) void rotate_wide_kernel(RotParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int KS = KC / 2;
+  float *RA = reinterpret_cast<float *>(smem);                     // TG * KS * 64
+  float *xs_all = RA + (size_t)TG * KS * 64;                        // NWAVES * KC * XS_STRIDE
+  const int d = p.d, NT = p.NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  float *xs = xs_all + (size_t)wave * (KC * XS_STRIDE);
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t nbatches = (ntiles + NWAVES - 1) / NWAVES;
+  for (int64_t batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
+    const int64_t tile = batch * NWAVES + wave;
+    const int64_t row0 = tile * 32;
+    for (int g0 = 0; g0 < NT; g0 += TG) {
+      f32x16 acc[TG];
+#pragma unroll
+      for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+      for (int k0 = 0; k0 < d; k0 += KC) {
+        __syncthreads();
+        for (int idx = tid; idx < TG * KS * 64; idx += NWAVES * 64) {
+          const int l = idx & 63, kk = (idx >> 6) % KS, t = (idx >> 6) / KS;
+          const int i = (g0 + t) * 32 + (l & 31), k = k0 + 2 * kk + (l >> 5);
+          RA[idx] = (i < d && k < d) ? p.R[(size_t)i * d + k] : 0.0f;
+        }
+        for (int e = lane; e < 32 * KC; e += 64) {
+          const int row = e / KC, c = e - row * KC;
+          int64_t gr = row0 + row;
+          if (gr >= p.n) gr = p.n - 1;
+          xs[c * XS_STRIDE + row] = (k0 + c < d) ? p.X[gr * d + k0 + c] : 0.0f;
+        }
+        __syncthreads();
+        const float *xb = xs + hi * XS_STRIDE + j;
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+          const float *ra = RA + (size_t)t * KS * 64 + lane;
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk * 64], xb[2 * kk * XS_STRIDE], acc[t], 0, 0, 0);
+        }
+      }
+      if (row0 + j < p.n) {
+        float *o = p.RX + (size_t)(row0 + j) * d;
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = (g0 + t) * 32 + 4 * hi + 8 * (r >> 2) + (r & 3);
+            if (i < d) o[i] = acc[t][r];
+          }
+        }
+      }
+    }
+  }
+}
+
 // lanes 32-63 of a  <->  lanes 0-31 of b   (v_permlane32_swap_b32)
 __device__ __forceinline__ void swap32(float &a, float &b) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -855,7 +921,17 @@ int rotate_launch(float *RX, const float *R, const float *X, int d, int64_t n, i
   }
   constexpr int NW = 4;
   const size_t lds = ((size_t)p.NT * p.KK * 64 + (size_t)NW * 2 * p.KK * XS_STRIDE) * sizeof(float);
-  if (lds > 160 * 1024) return fail(RQ_EUNSUPPORTED, "rotation with d=%d needs %zu B LDS (> 160 KiB)", d, lds);
+  if (lds > 160 * 1024) {
+    // R does not fit the LDS: chunked kernel (any d)
+    constexpr int TG = 8, KC = 32;
+    const size_t wlds = ((size_t)TG * (KC / 2) * 64 + (size_t)NW * KC * XS_STRIDE) * sizeof(float);
+    auto wk = rotate_wide_kernel<NW, TG, KC>;
+    RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+    const int64_t nb = ((n + 31) / 32 + NW - 1) / NW;
+    hipLaunchKernelGGL(wk, dim3((int)std::min<int64_t>(2 * (int64_t)num_cu, nb)), dim3(NW * 64), wlds, stream, p);
+    RQ_HIP(hipGetLastError());
+    return RQ_OK;
+  }
   auto kern = rotate_kernel<NW>;
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

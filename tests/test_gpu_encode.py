@@ -82,6 +82,26 @@ def test_rotation_odd_dims(rq, oracle):
         assert np.array_equal(rq.rotate(R, X).view(np.uint32), oracle.rotate_T(R, X).view(np.uint32)), d
 
 
+def test_rotation_and_opq_beyond_the_lds_resident_widths(rq, oracle):
+    """d where R (d*d*4 B) no longer fits the LDS: the chunked rotation kernel keeps the oracle's k-ordered chain;
+    quantize_opq at GIST-960 / MNIST-784 width (these returned RQ_EUNSUPPORTED)."""
+    import rayuela_jl_amd.synth as synth
+    for d, n in [(200, 333), (257, 100), (784, 600), (960, 1001)]:
+        X = synth.deep_like(n, d, seed=d)
+        R = synth.rotation(d, seed=d)
+        assert np.array_equal(rq.rotate(R, X).view(np.uint32), oracle.rotate_T(R, X).view(np.uint32)), d
+    d, n, m, h = 960, 3000, 8, 64
+    X = synth.deep_like(n, d, seed=1)
+    R = synth.rotation(d, seed=2)
+    C = synth.codebooks(oracle.rotate_T(R, X), m, h, seed=3, iters=1, sample=2000)
+    assert np.array_equal(rq.quantize_opq(X, R, C), oracle.encode_opq(X, R, synth.cat_codebooks(C), m, h).astype(np.int16) + 1)
+    # train_opq at a width above 128 (update_centers in dimension chunks, rotation chunked)
+    Xt = synth.deep_like(4000, 200, seed=4)
+    Ct, Bt, Rt, obj = rq.train_opq(Xt, 4, 32, 3, "natural", seed=1)
+    assert (np.diff(obj) <= 1e-5 * obj[:-1]).all() and np.abs(Rt @ Rt.T - np.eye(200)).max() < 1e-4
+    assert np.array_equal(rq.quantize_opq(Xt, Rt, Ct), Bt)
+
+
 def test_device_entry_points_and_full_size(rq, oracle):
     """SIFT1M-shape encode at full size on resident data; oracle-checked on a 60k-row sample,
     plus determinism (two runs identical)."""
