@@ -17,6 +17,12 @@ module RayuelaHIP
 import Clustering, Distances
 
 export quantize_pq, quantize_opq, quantize_rvq, linscan_pq, linscan_opq, linscan_lsq, linscan_cq, train_pq, train_opq, train_rvq
+export HipIndex, set_codes!, set_codes_synth!, search, HipDataset, quantize
+
+# Multi-GPU without touching a call site: with ENV["RAYUELA_HIP_DEVICES"] = "0,1,2,3" (or "all") set before the
+# call, linscan_pq / linscan_opq below shard B row-wise over those devices inside the library (per-device scan,
+# RCCL gather of the per-shard top-k keys, merge on the first device) and quantize_pq / quantize_opq split X over
+# them (one PCIe link each).  The results are bit-identical to the single-GPU ones.
 
 # deps/build.jl:64-67 writes the library paths into deps/deps.jl; here one constant / env var.
 const librayuela_hip = get(ENV, "RAYUELA_HIP_LIB",
@@ -101,8 +107,9 @@ end
 
 """
     train_rvq(X, m, h, niter=25, V=false; seed=0) -> C, B, error     (src/RVQ.jl:86-127)
-One k-means per stage on the running residual, on the device.  Seeding comes from the library's seeded
-stream (the reference: kmeans++ with Julia's RNG), so runs agree in objective, not bit for bit.
+One k-means per stage on the running residual, on the device, seeded by kmeans++ like the reference's
+`kmeans(Xr, h, init=:kmpp, maxiter=niter)` -- with the library's seeded stream instead of Julia's RNG, so runs
+agree in objective, not bit for bit (and are bit-reproducible for a given `seed`).
 """
 function train_rvq(X::Matrix{Float32}, m::Integer, h::Integer, niter::Integer=25, V::Bool=false; seed::Integer=0)
   d, n = size(X)
@@ -216,7 +223,7 @@ end
 
 """
     train_pq(X, m, h, niter=25, V=false) -> C, B, error     (src/PQ.jl:68-99)
-k-means per subspace on the device.  Initial centres come from the library's seeded stream.
+k-means per subspace on the device, kmeans++ seeding (`init=:kmpp`, src/PQ.jl:86) from the library's seeded stream.
 """
 function train_pq(X::Matrix{Float32}, m::Integer, h::Integer, niter::Integer=25, V::Bool=false; seed::Integer=0)
   d, n = size(X)
@@ -245,6 +252,87 @@ function train_opq(X::Matrix{Float32}, m::Integer, h::Integer, niter::Integer, i
     Ccat, B, R, obj, X, Int64(n), Cint(d), Cint(m), Cint(h), Cint(niter), Cint(init == "natural" ? 0 : 1),
     UInt64(seed), C_NULL, C_NULL))
   return _split_codebooks(Ccat, d, Int(m), Int(h)), B, R, obj
+end
+
+# ---- resident handles (no counterpart in the reference: they remove its per-call marshalling) ----------------
+
+"""
+    HipIndex(C, d; devices=nothing)
+Codes uploaded once, searched many times.  `devices = [0, 1, ...]`: one row shard per entry (RCCL gather of the
+per-shard top-k + merge inside the library); `nothing`: the current device.  `search` returns what `linscan_pq`
+returns (k-by-nq `dists`, ONE-based `idx`).
+"""
+mutable struct HipIndex
+  h::Ptr{Cvoid}
+  m::Int
+  d::Int
+  function HipIndex(C::Vector{Matrix{Cfloat}}, d::Int; devices::Union{Nothing,Vector{<:Integer}}=nothing)
+    m = length(C)
+    cen = cat(C..., dims=3)
+    h = devices === nothing ?
+      ccall((:rq_index_create, librayuela_hip), Ptr{Cvoid}, (Cint, Cint, Ptr{Cfloat}), Cint(m), Cint(d), cen) :
+      ccall((:rq_index_create_sharded, librayuela_hip), Ptr{Cvoid}, (Cint, Cint, Ptr{Cfloat}, Ptr{Cint}, Cint),
+            Cint(m), Cint(d), cen, convert(Vector{Cint}, devices), Cint(length(devices)))
+    h == C_NULL && error("rq_index_create: " * unsafe_string(ccall((:rq_last_error, librayuela_hip), Cstring, ())))
+    ix = new(h, m, d)
+    finalizer(x -> (x.h != C_NULL && ccall((:rq_index_destroy, librayuela_hip), Cvoid, (Ptr{Cvoid},), x.h); x.h = C_NULL), ix)
+    return ix
+  end
+end
+
+function set_codes!(ix::HipIndex, B::Matrix{UInt8}; id_offset::Integer=0)      # B zero-based m-by-n
+  _check(ccall((:rq_index_set_codes, librayuela_hip), Cint, (Ptr{Cvoid}, Ptr{Cuchar}, Int64, UInt32),
+               ix.h, B, Int64(size(B, 2)), UInt32(id_offset)))
+  return ix
+end
+set_codes!(ix::HipIndex, B::Matrix{T}; id_offset::Integer=0) where T <: Integer =
+  set_codes!(ix, convert(Matrix{UInt8}, B .- 1); id_offset=id_offset)
+
+function set_codes_synth!(ix::HipIndex, n::Integer, seed::Integer; id_offset::Integer=0)
+  _check(ccall((:rq_index_set_codes_synth, librayuela_hip), Cint, (Ptr{Cvoid}, Int64, UInt64, UInt32),
+               ix.h, Int64(n), UInt64(seed), UInt32(id_offset)))
+  return ix
+end
+
+function search(ix::HipIndex, X::Matrix{Cfloat}, k::Int=10000; R::Union{Nothing,Matrix{Cfloat}}=nothing)
+  d, nq = size(X)
+  dists = Matrix{Cfloat}(undef, k, nq)
+  res   = Matrix{Cuint}(undef, k, nq)
+  if R === nothing
+    _check(ccall((:rq_index_search, librayuela_hip), Cint,
+      (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cuint}, Ptr{Cfloat}, Int64, Cint, Cint), ix.h, dists, res, X, Int64(nq), Cint(k), Cint(1)))
+  else
+    _check(ccall((:rq_index_search_opq, librayuela_hip), Cint,
+      (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cuint}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cint, Cint),
+      ix.h, dists, res, X, R, Int64(nq), Cint(k), Cint(1)))
+  end
+  return dists, res
+end
+
+"""
+    HipDataset(X)
+`X` (d-by-n) uploaded once; `quantize(ds, C)` == `quantize_pq(X, C)`, `quantize(ds, C; R=R)` == `quantize_opq(X, R, C)`.
+"""
+mutable struct HipDataset
+  h::Ptr{Cvoid}
+  n::Int
+  function HipDataset(X::Matrix{Float32})
+    d, n = size(X)
+    h = ccall((:rq_dataset_upload, librayuela_hip), Ptr{Cvoid}, (Ptr{Cfloat}, Int64, Cint), X, Int64(n), Cint(d))
+    h == C_NULL && error("rq_dataset_upload: " * unsafe_string(ccall((:rq_last_error, librayuela_hip), Cstring, ())))
+    ds = new(h, n)
+    finalizer(x -> (x.h != C_NULL && ccall((:rq_dataset_free, librayuela_hip), Cvoid, (Ptr{Cvoid},), x.h); x.h = C_NULL), ds)
+    return ds
+  end
+end
+
+function quantize(ds::HipDataset, C::Vector{Matrix{Float32}}; R::Union{Nothing,Matrix{Float32}}=nothing)
+  m, h = length(C), size(C[1], 2)
+  B = Matrix{Int16}(undef, m, ds.n)
+  _check(ccall((:rq_dataset_encode, librayuela_hip), Cint,
+    (Ptr{Cvoid}, Ptr{Cuchar}, Ptr{Int16}, Ptr{Cfloat}, Ptr{Cfloat}, Cint, Cint),
+    ds.h, C_NULL, B, R === nothing ? C_NULL : R, _cat_codebooks(C), Cint(m), Cint(h)))
+  return B
 end
 
 end # module
