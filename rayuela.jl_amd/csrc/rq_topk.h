@@ -44,6 +44,7 @@ struct SelState {
   uint64_t prefix[G];   // radix prefix found so far; after 8 passes the k-th smallest key
   uint32_t krem[G];     // rank still to resolve inside the current bucket (1-based)
   uint32_t newcnt[G];   // compaction cursor
+  uint32_t bcnt[G];     // population of the bucket chosen in the last pass
   uint32_t hist[G][256];
 };
 
@@ -124,9 +125,22 @@ __device__ __forceinline__ void radix_select(SelState<G> *st, const uint64_t *__
             if (r > c2) { r -= c2; b = 3; } } }
         st->prefix[g] |= (uint64_t)(gi * 4 + b) << shift;
         st->krem[g] = r;
+        st->bcnt[g] = b == 0 ? c0 : b == 1 ? c1 : b == 2 ? c2 : c3;
       }
     }
-    __syncthreads();
+    if (NPASS == 8 && pass == 3) {
+      // The distance half is resolved.  If every key of that distance is wanted (rank inside the bucket ==
+      // its population -- always the case without distance ties) the answer is "all ids of this distance":
+      // the id half needs no passes.  Uniform over the workgroup: all query-lanes must agree to stop.
+      const bool done = !active || st->bcnt[g] == st->krem[g];
+      if (__syncthreads_and(done)) {
+        if (gi == 0 && active) st->prefix[g] |= 0xFFFFFFFFull;
+        __syncthreads();
+        return;
+      }
+    } else {
+      __syncthreads();
+    }
   }
 }
 
