@@ -247,8 +247,10 @@ int rq_release_workspaces(void);
 int rq_set_tuning(const char *key, int value);
 /* Diagnostics: with tuning SCAN_STATS=1, summed shader-clock cycles (thread 0 of every workgroup) of the
  * last scan: [0] LUT build [1] threshold sample [2] streaming [3] in-stream cuts [4] final cut [5] sort+write,
- * [6] number of in-stream cuts, [7] number of exact fallbacks, [8] the row part of [1]; out has 12 slots. */
-int rq_scan_stats(unsigned long long *out12);
+ * [6] number of in-stream cuts, [7] number of exact fallbacks, [8] the row part of [1], [9..11] sort load / stages /
+ * write-out, [12] cycles in the exact re-evaluation of pre-filtered rows (part of [2]), [13] its calls (64 rows each);
+ * out has 16 slots. */
+int rq_scan_stats(unsigned long long *out16);
 
 /* Diagnostics (pure host code, no device needed): the scan planner's decision for a shard of n rows, nq queries,
  * m sub-quantizers, dimension d, k neighbours on a device with num_cu compute units.  out[0] queries per group,

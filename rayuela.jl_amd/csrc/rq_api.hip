@@ -568,7 +568,7 @@ int rq_scan_stats(unsigned long long *out8) {
   void *counter = nullptr;
   RQ_TRY(workspace(WS_COUNTER, 256, &counter, nullptr));
   RQ_HIP(hipDeviceSynchronize());
-  RQ_HIP(hipMemcpy(out8, (char *)counter + 64, 96, hipMemcpyDeviceToHost));
+  RQ_HIP(hipMemcpy(out8, (char *)counter + 64, 128, hipMemcpyDeviceToHost));
   return RQ_OK;
 }
 

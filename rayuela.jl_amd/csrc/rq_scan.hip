@@ -794,10 +794,14 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
           __builtin_amdgcn_sched_barrier(0);
           }  // gather batches
           if (qtail >= 64u) {      // at most RPT * 64 rows were pushed since the last check: qtail < 64 * (RPT + 1) <= FILT_QCAP
+            // (two 64-row batches per call would overlap the call's dependent latencies -- ~2 us for queue -> code
+            // bytes -> table gathers -- but the larger callee makes every call save more registers: 3.64 -> 4.16 ms)
+            const unsigned long long t_r = RQ_STAT_T();
             do {
               refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - 64u), 64u);
               qtail -= 64u;
             } while (qtail >= 64u);
+            RQ_STAT_ADD(12, t_r);
           }
         }
         if (base == r_begin && lane == 0) atomicAdd(&ctrl->fpush, npush);
