@@ -553,9 +553,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     __syncthreads();
     unsigned long long t_ph = RQ_STAT_T();
     build_lut<M>(lut, gtab, qstage, p.centers, p.sub, p.d, p.lut_mode, p.m_real, tid);
+    // The L1-gathered part of the table lives in global memory and is written by all wavefronts of the
+    // workgroup: every wavefront RELEASES its stores before the barrier (s_waitcnt vmcnt(0): they have reached
+    // L2) and ACQUIRES after it (buffer_inv: this CU's L1 may still hold the previous item's lines).
+    // tests/test_isa.py asserts that sequence in the generated code.
+    if (Cfg::KG > 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    // the L1 part of the table was written by other wavefronts (and the previous item's lines may
-    // still sit in this CU's L1): drop them before the first gather
     if (Cfg::KG > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     RQ_STAT_ADD(0, t_ph);
     const uint32_t r_begin = sliced ? slice * p.rows_per_slice : 0u;
@@ -796,12 +799,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
           if (qtail >= 64u) {      // at most RPT * 64 rows were pushed since the last check: qtail < 64 * (RPT + 1) <= FILT_QCAP
             // (two 64-row batches per call would overlap the call's dependent latencies -- ~2 us for queue -> code
             // bytes -> table gathers -- but the larger callee makes every call save more registers: 3.64 -> 4.16 ms)
-            const unsigned long long t_r = RQ_STAT_T();
+            // (timing this call with clock64 costs two live VGPRs here, which spilled the code words of the block)
             do {
               refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - 64u), 64u);
               qtail -= 64u;
+              RQ_STAT_INC(13);
             } while (qtail >= 64u);
-            RQ_STAT_ADD(12, t_r);
           }
         }
         if (base == r_begin && lane == 0) atomicAdd(&ctrl->fpush, npush);

@@ -1,0 +1,69 @@
+"""CPU (hipcc cross-compiles): properties of the GENERATED gfx950 code of the scan kernels that the C++ source
+cannot express and a compiler bump could silently break.
+
+1. The part of the look-up table that is gathered through L1 lives in global memory and is written by all
+   wavefronts of a workgroup before a barrier: every wavefront must release its stores BEFORE the barrier
+   (buffer_wbl2 + s_waitcnt vmcnt(0)) and invalidate its L1 AFTER it (buffer_inv) -- VERDICT r1's latent issue.
+2. The pre-filter's hot loop must not touch scratch memory: a spilled queue pointer cost 10 %, spilled code
+   words 8 % + 4 GB of writes per launch in round 2."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def scan_asm(tmp_path_factory):
+    if not os.path.isfile(HIPCC):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa") / "rq_scan.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
+                           "--cuda-device-only", os.path.join(ROOT, "rayuela.jl_amd", "csrc", "rq_scan.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _kernel(asm, m, filt):
+    name = "_ZN2rq15adc_scan_kernelILi%dELb0ELb%dEEEvNS_10ScanParamsE" % (m, 1 if filt else 0)
+    start = asm.index("\n" + name + ":")
+    end = asm.index("s_endpgm", start)
+    return [ln for ln in asm[start:end].splitlines() if ln.strip() and not ln.lstrip().startswith(";")]
+
+
+@pytest.mark.parametrize("m,filt", [(8, True), (8, False), (16, True), (4, False), (32, False)])
+def test_l1_table_release_acquire_around_the_barrier(scan_asm, m, filt):
+    body = _kernel(scan_asm, m, filt)
+    inv = [i for i, ln in enumerate(body) if "buffer_inv" in ln]
+    assert inv, "no buffer_inv: the acquire fence after the table build is gone"
+    i = inv[0]
+    b = max(j for j in range(i) if "s_barrier" in body[j])
+    assert i - b <= 3, "the acquire (buffer_inv) does not follow the table-build barrier"
+    # release side: write-back, and every global store issued before the barrier has been waited for
+    st = max(j for j in range(b) if re.search(r"\bglobal_store", body[j]))
+    between = body[st + 1:b]
+    assert any("buffer_wbl2" in ln for ln in body[b - 4:b]), "\n".join(body[b - 6:b + 2])
+    assert any(re.search(r"s_waitcnt[^\n]*vmcnt\(0\)", ln) for ln in between), \
+        "no s_waitcnt vmcnt(0) between the last table store and the barrier:\n" + "\n".join(body[b - 8:b + 2])
+
+
+@pytest.mark.parametrize("m,const", [(8, "0x9f9f9fa0"), (16, "0x80008000")])
+def test_prefilter_hot_loop_has_no_scratch_traffic(scan_asm, m, const):
+    body = _kernel(scan_asm, m, True)
+    hits = [i for i, ln in enumerate(body) if const in ln]
+    assert len(hits) >= 4, "cannot find the filter's byte-compare constants in the generated code"
+    # the unrolled sub-steps of one block: from the first gather batch before the first compare to the last compare
+    lo, hi = hits[0], hits[-1]
+    while lo > 0 and "s_barrier" not in body[lo]:
+        lo -= 1
+    region = body[lo:hi + 1]
+    gathers = sum(1 for ln in region if re.search(r"\bds_read_b(64|32)\b", ln))
+    assert gathers >= 32, gathers
+    stores = [ln for ln in region if "scratch_store" in ln]
+    loads = [ln for ln in region if "scratch_load" in ln]
+    # one reload in the block prologue is tolerated; anything per sub-step (4 per block) is a regression
+    assert not stores and len(loads) <= 1, "scratch access in the pre-filter loop:\n" + "\n".join((stores + loads)[:8])
