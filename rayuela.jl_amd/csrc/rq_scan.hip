@@ -554,10 +554,16 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     unsigned long long t_ph = RQ_STAT_T();
     build_lut<M>(lut, gtab, qstage, p.centers, p.sub, p.d, p.lut_mode, p.m_real, tid);
     // The L1-gathered part of the table lives in global memory and is written by all wavefronts of the
-    // workgroup: every wavefront RELEASES its stores before the barrier (s_waitcnt vmcnt(0): they have reached
-    // L2) and ACQUIRES after it (buffer_inv: this CU's L1 may still hold the previous item's lines).
-    // tests/test_isa.py asserts that sequence in the generated code.
-    if (Cfg::KG > 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // workgroup, and read back only by it: every wavefront RELEASES its stores at workgroup scope before the
+    // barrier (s_waitcnt vmcnt(0): the write-through stores are complete; an agent-scope release would also write
+    // the whole L2 back, 0.2 ms per launch) and ACQUIRES after it at agent scope (buffer_inv: this CU's L1 may
+    // still hold the previous item's lines).  tests/test_isa.py asserts that sequence in the generated code.
+    if (Cfg::KG > 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      // LLVM's gfx942/gfx950 memory model needs no wait here (the wavefronts of a workgroup share the CU's L1 and
+      // its request order); the explicit drain makes the hand-over independent of that reasoning -- once per item
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     if (Cfg::KG > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     RQ_STAT_ADD(0, t_ph);
@@ -803,7 +809,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
             do {
               refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - 64u), 64u);
               qtail -= 64u;
-              RQ_STAT_INC(13);
             } while (qtail >= 64u);
           }
         }

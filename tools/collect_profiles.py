@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of gpurun_out/r2 (written by tools/profile_round2.sh on the GPU box) into profiles/:
+bench lines, the library's rows of the rocprofv3 kernel stats, the PMC table and the FETCH/WRITE traffic per launch."""
+import csv
+import json
+import os
+import re
+import shutil
+
+O = "gpurun_out/r2"
+for f in ("bench_pq", "bench_opq", "bench_deep", "bench_pq_k10000", "bench_sift1b_1gpu", "bench_sift1b_inproc"):
+    open("profiles/r2_%s.json" % f, "w").write(open("%s/%s.json" % (O, f)).read().strip().splitlines()[-1] + "\n")
+for w in ("pq", "opq", "deep", "k10000", "sift1b"):
+    rows = list(csv.reader(open("%s/stats_%s/s_kernel_stats.csv" % (O, w))))
+    csv.writer(open("profiles/r2_bench_%s_kernel_stats.csv" % w, "w")).writerows([rows[0]] + [r for r in rows[1:] if "rq::" in r[0]])
+shutil.copy(O + "/pmc_summary.txt", "profiles/r2_pmc_counters.md")
+shape = {"pmc_FETCH_SIZE": "adc_scan_kernel<8> n=1000000 nq=10000 k=1000", "pmc_WRITE_SIZE": "adc_scan_kernel<8> n=1000000 nq=10000 k=1000",
+         "pmc_deep_FETCH_SIZE": "adc_scan_kernel<16> n=1000000 nq=10000 k=1000", "pmc_deep_WRITE_SIZE": "adc_scan_kernel<16> n=1000000 nq=10000 k=1000",
+         "pmc_sift1b_FETCH_SIZE": "adc_scan_kernel<8> n=1000000000 nq=1024 k=100", "pmc_sift1b_WRITE_SIZE": "adc_scan_kernel<8> n=1000000000 nq=1024 k=100"}
+t = {}
+for line in open("profiles/r2_pmc_counters.md"):
+    m = re.match(r"\| (pmc_\S+) \| (.*?) \| (\S+) \| (\d+) \| (\S+) \|", line)
+    if not m or m.group(3) not in ("FETCH_SIZE", "WRITE_SIZE") or "adc_scan" not in m.group(2):
+        continue
+    e = t.setdefault(shape[m.group(1)], {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py of that "
+                                                   "workload (tools/profile_round2.sh); profiles/r2_pmc_counters.md"})
+    e[m.group(3) + "_KiB"] = float(m.group(5))
+json.dump(t, open("profiles/r2_traffic.json", "w"), indent=1)
+for f in sorted(os.listdir("profiles")):
+    if f.startswith("r2_bench") and f.endswith(".json"):
+        d = json.load(open("profiles/" + f))
+        r = d.get("roofline") or {}
+        print(f, d["value"], d["ms_per_step"], "frac", r.get("frac"), "f32roof", (r.get("f32_table_roof") or {}).get("frac"),
+              "enc", (d.get("encode") or {}).get("ms_per_step"), "cpu", (d.get("cpu_baseline") or {}).get("value"),
+              (d.get("cpu_baseline") or {}).get("gpu_matches_cpu_bit_exact"))
+print(json.dumps(t, indent=1))
