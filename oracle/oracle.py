@@ -263,14 +263,15 @@ def encode_rvq(X, C, with_extras=False):
 def eval_recall(ids_gnd, ids_predicted, k):
     """src/Linscan.jl:196-234.  ids_gnd [nq], ids_predicted [nq][k] (C view of the k x nq
     Julia matrix), same index base.  rank = position (1-based) of the ground-truth id if it
-    occurs EXACTLY once among the k predictions, else k+1; recall_at_i[R-1] = #{rank<=R}/nq."""
+    occurs EXACTLY once in the WHOLE column of predictions (:207, also beyond k), else k+1;
+    recall_at_i[R-1] = #{rank<=R and rank<=k}/nq.  Explicit loops, written from the reference's text."""
     ids_gnd = np.asarray(ids_gnd).reshape(-1)
-    P = np.asarray(ids_predicted)[:, :k]
+    P = np.asarray(ids_predicted)
     nq = P.shape[0]
     assert nq == ids_gnd.shape[0]
     hit = P == ids_gnd[:, None]
     cnt = hit.sum(axis=1)
     first = hit.argmax(axis=1) + 1
-    ranks = np.where(cnt == 1, first, k + 1)
+    ranks = np.minimum(np.where(cnt == 1, first, k + 1), k + 1)
     hist = np.bincount(ranks, minlength=k + 2)[1:k + 1]
     return np.cumsum(hist) / float(nq)

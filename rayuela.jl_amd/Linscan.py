@@ -149,15 +149,16 @@ def linscan_aqd_query(codes, centers, queries, K):
 def eval_recall(ids_gnd, ids_predicted, k, verbose=True):
     """eval_recall(gt, idx, k) -> recall_at_i     (src/Linscan.jl:196-234)
 
-    rank_i = position of gt[i] in idx[i, :k] if it occurs exactly once, else k+1;
+    rank_i = position of gt[i] in idx[i, :] (the whole row, like the reference) if it occurs exactly once, else k+1;
     recall_at_i[R-1] = #{rank <= R} / nq.  Prints r@{1,2,5,...} * 100 like the reference."""
     ids_gnd = np.asarray(ids_gnd).reshape(-1)
-    P = np.asarray(ids_predicted)[:, :k]
+    P = np.asarray(ids_predicted)             # the WHOLE column is searched (src/Linscan.jl:207), also beyond k
     nq = P.shape[0]
     assert nq == ids_gnd.shape[0]
     hit = P == ids_gnd[:, None]
     cnt = hit.sum(axis=1)
-    ranks = np.where(cnt == 1, hit.argmax(axis=1) + 1, k + 1)
+    ranks = np.where(cnt == 1, hit.argmax(axis=1) + 1, k + 1)        # :209-213: exactly one occurrence, else k+1
+    ranks = np.minimum(ranks, k + 1)                                  # a rank beyond k counts for no R <= k (:228)
     hist = np.bincount(ranks, minlength=k + 2)[1:k + 1]
     recall = np.cumsum(hist) / float(nq)
     if verbose:

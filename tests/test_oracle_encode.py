@@ -60,3 +60,18 @@ def test_eval_recall_golden(oracle):
     g = golden("recall_tiny")
     r = oracle.eval_recall(g["gt"], g["idx"], int(g["k"]))
     assert np.allclose(r, g["recall"])
+
+
+def test_eval_recall_searches_the_whole_column(oracle, rq):
+    """src/Linscan.jl:207 looks for the ground-truth id in the WHOLE column of predictions, also when it is longer
+    than k: a second occurrence beyond k makes the query a miss, a single occurrence beyond k counts for no R <= k."""
+    k = 4
+    gt = np.array([7, 8, 9, 5], dtype=np.uint32)
+    idx = np.array([[7, 1, 2, 3, 4, 6],      # rank 1
+                    [1, 8, 2, 3, 8, 6],      # twice (once beyond k) -> k+1
+                    [1, 2, 3, 4, 6, 9],      # once, beyond k -> counts nowhere
+                    [1, 2, 3, 5, 6, 0]], dtype=np.uint32)   # rank 4
+    # by hand from :206-230: ranks = [1, 5, 6 -> excluded, 4]
+    want = np.array([1, 1, 1, 2], dtype=np.float64) / 4.0
+    assert np.allclose(oracle.eval_recall(gt, idx, k), want)
+    assert np.allclose(rq.eval_recall(gt, idx, k, verbose=False), want)
