@@ -1,0 +1,129 @@
+// micro-benchmark: how fast can the byte pre-filter stream alone (no exact path, no top-k in the kernel)?
+// Workgroup = NT threads, byte tables of QGB queries in LDS ([set of 8][k][256] uint2), persistent over
+// (query group, row slice) items, codes [n][8] streamed 16 B per lane.  Alive rows are pushed to a per-wave
+// LDS queue and dropped (the refine would take them from there).  Prints ms for n = 1e6 rows x nq = 1e4 queries.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/filter_lean.hip -o /tmp/filter_lean && /tmp/filter_lean
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+template <int NT, int QGB>
+__global__ __launch_bounds__(NT) void filt_kernel(const uint8_t *__restrict__ codes, const uint2 *__restrict__ tabs, uint32_t n,
+                                                  uint32_t ngroups, uint32_t nslices, uint32_t rows_per_slice,
+                                                  uint32_t thr, unsigned long long *alive_out, uint32_t *counter) {
+  constexpr int NS = QGB / 8;           // 8-query sets
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint2 *qt = reinterpret_cast<uint2 *>(smem);                       // [NS][8][256]
+  uint32_t *queue = reinterpret_cast<uint32_t *>(qt + NS * 8 * 256);  // [NT/64][256]
+  __shared__ uint32_t s_item;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t *myq = queue + __builtin_amdgcn_readfirstlane(wave * 256);
+  unsigned long long alive_total = 0;
+  const uint32_t nitems = ngroups * nslices;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_item = atomicAdd(counter, 1u);
+    __syncthreads();
+    const uint32_t item = s_item;
+    if (item >= nitems) break;
+    const uint32_t group = item % ngroups, slice = item / ngroups;
+    for (int i = tid; i < NS * 8 * 256; i += NT) qt[i] = tabs[(size_t)group * NS * 8 * 256 + i];
+    __syncthreads();
+    const uint32_t r_begin = slice * rows_per_slice, r_end = min(n, r_begin + rows_per_slice);
+    uint32_t qtail = 0;
+    constexpr int U = 2;
+    for (uint32_t base = r_begin; base < r_end; base += NT * 2 * U) {
+      uint4 wu[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t row0 = base + u * NT * 2 + tid * 2;
+        wu[u] = row0 + 2 <= r_end ? *reinterpret_cast<const uint4 *>(codes + (size_t)row0 * 8) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t w[4] = {wu[u].x, wu[u].y, wu[u].z, wu[u].w};
+        const uint32_t row0 = base + u * NT * 2 + tid * 2;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          uint2 e[2][8];
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[r][k] = qt[(s * 8 + k) * 256 + ((w[(r * 8 + k) >> 2] >> (8 * ((r * 8 + k) & 3))) & 0xffu)];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a0 += e[r][k].x; a1 += e[r][k].y; }
+            constexpr uint32_t H = 0x80808080u;
+            const uint32_t TC = (thr + 1u) * 0x01010101u;
+            const uint32_t g0 = ((a0 | H) - TC) | a0, g1 = ((a1 | H) - TC) | a1;
+            const bool cand = ((g0 & g1 & H) != H) && (row0 + r < r_end);
+            const uint64_t mq = __ballot(cand);
+            if (mq) {
+              if (cand) myq[(qtail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u))) & 255u] = (row0 + r) | (s << 29);
+              qtail += (uint32_t)__popcll(mq);
+            }
+          }
+        }
+      }
+    }
+    alive_total += qtail;
+  }
+  if (lane == 0) atomicAdd(alive_out, alive_total);
+}
+
+template <int NT, int QGB>
+static void run(const uint8_t *codes, const uint2 *tabs, uint32_t n, uint32_t nq, uint32_t thr, int wgs_per_cu) {
+  constexpr int NS = QGB / 8;
+  const uint32_t ngroups = nq / QGB;
+  const uint32_t grid = 256 * wgs_per_cu;
+  uint32_t nslices = ngroups >= grid ? 1 : (grid + ngroups - 1) / ngroups;
+  uint32_t rps = (n + nslices - 1) / nslices;
+  rps = (rps + NT * 4 - 1) / (NT * 4) * (NT * 4);
+  nslices = (n + rps - 1) / rps;
+  unsigned long long *alive; uint32_t *counter;
+  hipMalloc(&alive, 8); hipMalloc(&counter, 4);
+  const size_t lds = (size_t)NS * 8 * 256 * 8 + (size_t)(NT / 64) * 256 * 4;
+  hipFuncSetAttribute(reinterpret_cast<const void *>(filt_kernel<NT, QGB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9;
+  unsigned long long al = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    hipMemset(alive, 0, 8); hipMemset(counter, 0, 4);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((filt_kernel<NT, QGB>), dim3(grid), dim3(NT), lds, 0, codes, tabs, n, ngroups, nslices, rps, thr, alive, counter);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+    hipMemcpy(&al, alive, 8, hipMemcpyDeviceToHost);
+  }
+  printf("NT=%4d QGB=%2d WGs/CU=%d slices=%u lds=%zu KB: %.3f ms  alive (row,set) share %.3f%%  err=%s\n", NT, QGB, wgs_per_cu, nslices, lds / 1024, best,
+         100.0 * (double)al / ((double)n * (nq / 8)), hipGetErrorString(hipGetLastError()));
+}
+
+int main() {
+  const uint32_t n = 1000000, nq = 10016;   // multiple of 32
+  std::vector<uint8_t> hc((size_t)n * 8);
+  for (auto &c : hc) c = (uint8_t)(rand() >> 8);
+  std::vector<uint8_t> ht((size_t)(nq / 8) * 8 * 256 * 8);
+  for (auto &t : ht) t = (uint8_t)((rand() >> 8) % 28);        // entries 0..27: sums ~108 +- 23
+  uint8_t *codes; uint2 *tabs;
+  hipMalloc(&codes, hc.size()); hipMalloc(&tabs, ht.size());
+  hipMemcpy(codes, hc.data(), hc.size(), hipMemcpyHostToDevice);
+  hipMemcpy(tabs, ht.data(), ht.size(), hipMemcpyHostToDevice);
+  const uint32_t thr = 62;   // ~ a few % of (row, set) pairs alive
+  run<512, 8>(codes, tabs, n, nq, thr, 2);
+  run<512, 8>(codes, tabs, n, nq, thr, 4);
+  run<1024, 8>(codes, tabs, n, nq, thr, 2);
+  run<512, 16>(codes, tabs, n, nq, thr, 2);
+  run<512, 16>(codes, tabs, n, nq, thr, 4);
+  run<1024, 16>(codes, tabs, n, nq, thr, 2);
+  run<512, 32>(codes, tabs, n, nq, thr, 2);
+  run<1024, 32>(codes, tabs, n, nq, thr, 2);
+  run<1024, 32>(codes, tabs, n, nq, thr, 1);
+  return 0;
+}
