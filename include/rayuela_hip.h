@@ -85,7 +85,7 @@ int rq_dev_linscan_aq(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t
 /* ---- quantize_rvq (src/RVQ.jl:18-66) -----------------------------------------
  * m full-dimensional stages on the running residual: stage i = pairwise SqEuclidean + first-index
  * argmin against C[i] (d x h in Julia = [h][d] here; codebooks = the m matrices back to back), then
- * Xr .-= C[i][:, B[i]] (:56).  Any d (d % 4 == 0).  codes [n][m] uint8 zero-based / Int16 one-based m x n
+ * Xr .-= C[i][:, B[i]] (:56).  Any d.  codes [n][m] uint8 zero-based / Int16 one-based m x n
  * (:60-62).  counts [m][h] (may be NULL) = update_assignments!'s per-centre counts (:43-47): a zero marks
  * an `unused` centre, for which the reference re-picks a singleton with Julia's RNG (:50-53) -- that
  * random re-pick stays on the caller's side.  Xr_out [n][d] (may be NULL) receives the final residual. */
