@@ -206,3 +206,26 @@ def test_train_pq_with_kmeanspp_beats_uniform_seeding_on_clustered_data(rq):
     finally:
         rq.set_tuning("TRAIN_KMPP", 1)
     assert e_pp < e_uni
+
+
+def test_results_survive_an_hdf5_round_trip(rq, tmp_path):
+    """train_opq -> save_results_opq (demos/experiment_utils.jl:28-38 layout) -> load -> the reloaded model encodes and
+    searches exactly like the one in memory."""
+    import rayuela_jl_amd.synth as synth
+    h5 = rq.h5results
+    if not h5.available():
+        pytest.skip("libhdf5 not found")
+    d, m, h, knn = 32, 4, 64, 20
+    Xb = synth.deep_like(6000, d, seed=31)
+    Xq = synth.deep_like(16, d, seed=32)
+    C, B, R, obj = rq.train_opq(Xb[:3000], m, h, 3, "natural", seed=2)
+    B_base = rq.quantize_opq(Xb, R, C)
+    dists, idx = rq.linscan_opq(B_base, Xq, C, 8 * m, R, knn)
+    path = str(tmp_path / "opq.h5")
+    h5.save_results_opq(path, 1, C, B, R, obj[-1], B_base, np.linspace(0, 1, knn))
+    C2, B2, R2, err = h5.load_opq(path, m, 1)
+    assert np.array_equal(B2, B) and float(np.asarray(err)) == float(obj[-1])
+    Bb2 = h5.h5read(path, "1/B_base")                       # zero-based UInt8: the scan's wire format, used as it is
+    assert np.array_equal(rq.quantize_opq(Xb, R2, C2), B_base)
+    d2, i2 = rq.linscan_opq(Bb2, Xq, C2, 8 * m, R2, knn)
+    assert np.array_equal(i2, idx) and np.array_equal(d2.view(np.uint32), dists.view(np.uint32))
