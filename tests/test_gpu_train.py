@@ -215,7 +215,7 @@ def test_results_survive_an_hdf5_round_trip(rq, tmp_path):
     h5 = rq.h5results
     if not h5.available():
         pytest.skip("libhdf5 not found")
-    d, m, h, knn = 32, 4, 64, 20
+    d, m, h, knn = 32, 4, 256, 20          # the scan is for h = 256 (uint8 codes)
     Xb = synth.deep_like(6000, d, seed=31)
     Xq = synth.deep_like(16, d, seed=32)
     C, B, R, obj = rq.train_opq(Xb[:3000], m, h, 3, "natural", seed=2)
