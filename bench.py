@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--inproc", action="store_true", help="N GPUs from one process via rq_index_create_sharded")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-ref1", action="store_true", help="sift1b, N > 1: skip the same-workload single-GPU timing")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (PCIe-inclusive) timing")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -379,6 +380,29 @@ def main():
                              "sample": "%d vectors (%.2f s), oracle/rq_oracle.c" % (ne, dte),
                              "codes_match": bool(np.array_equal(c_cpu, codes[:ne].cpu().numpy()))}
 
+    # ---- what a Julia ccall pays: the same calls on HOST arrays (PCIe in both directions inside the timed region) ----
+    host = None
+    if ngpu == 1 and X is not None and not a.no_host and not a.inproc:
+        Xh, Qh = X.cpu().numpy(), Q.cpu().numpy()
+        Rh = None if R is None else R.cpu().numpy()
+        best_e = best_s = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            Bh = rq.quantize_pq_u8(Xh, C) if Rh is None else (rq.quantize_opq(Xh, Rh, C) - 1).astype(np.uint8)
+            best_e = min(best_e, time.perf_counter() - t0)
+        same_codes = bool(np.array_equal(Bh, codes.cpu().numpy()))
+        for _ in range(3):
+            t0 = time.perf_counter()
+            dh, ih = rq.linscan_pq(Bh, Qh, C, 8 * m, K) if Rh is None else rq.linscan_opq(Bh, Qh, C, 8 * m, Rh, K)
+            best_s = min(best_s, time.perf_counter() - t0)
+            ts = rq.last_timing()
+        host = {"note": "host pointers in, host pointers out (pageable numpy arrays), best of 3; `value` and `encode.value` above are the resident rates",
+                "encode_ms": round(best_e * 1e3, 3), "encode_vectors_per_s": round(n / best_e, 1),
+                "scan_ms": round(best_s * 1e3, 3), "scan_queries_per_s": round(nq / best_s, 1),
+                "scan_split_ms": {k: round(v, 3) for k, v in ts.items()},
+                "same_answer_as_resident": bool(same_codes and np.array_equal(ih - 1, ri_h) and
+                                                np.array_equal(dh.view(np.uint32), rd_h.view(np.uint32)))}
+
     # ---- sift1b at N > 1: the same workload on ONE GPU (rank 0 alone), so the line carries its own scaling anchor ---
     ref1 = None
     if big and ngpu > 1 and not a.no_ref1 and n * m <= 64 * (1 << 30):
@@ -420,6 +444,7 @@ def main():
         "cpu_baseline": cpu,
         "recall": recall,
         "checks": checks,
+        "host_path": host,
         "same_workload_1gpu": ref1,
         "wall_ms_per_step": round(scan_wall / a.steps, 4),
     }

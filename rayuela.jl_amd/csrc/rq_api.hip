@@ -261,7 +261,8 @@ int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *code
 // against 7 ms of kernel.  scan(q0, nqc, stream) launches the scan of queries [q0, q0+nqc) into dd/di.
 template <class ScanFn>
 static int scan_and_fetch(float *dists, uint32_t *ids, float *dd, uint32_t *di, int64_t nq, int k, ScanFn scan) {
-  const int64_t chunk = (nq >= 8192 && tuning("HOST_OVERLAP", 1)) ? 4096 : nq;
+  const int64_t hc = std::max(256, tuning("HOST_CHUNK", 4096));
+  const int64_t chunk = (nq >= 2 * hc && tuning("HOST_OVERLAP", 1)) ? hc : nq;
   const size_t row = (size_t)k * 4;
   if (chunk >= nq) {
     Timer t2;
