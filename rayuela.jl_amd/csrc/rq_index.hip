@@ -166,6 +166,7 @@ struct rq_index {
   // exchange
   ncclComm_t comms[16] = {nullptr};
   int exchange = 0;     // 0 none (one device), 1 peer copies, 2 RCCL
+  bool selftest = false;   // tuning EXCHANGE_SELFTEST on ONE device: logical shards 1.. travel through RCCL send/recv to self
   std::mutex mu;
 };
 
@@ -236,6 +237,12 @@ static int index_build(rq_index *ix, int m, int d, const float *centers_host, co
     ix->shards.push_back(sh);
   }
   const int nd = (int)ix->devs.size();
+  if (nd == 1 && ix->shards.size() > 1 && tuning("EXCHANGE_SELFTEST", 0) && rccl_load()) {
+    // one-GPU boxes: run the RCCL transport anyway (a clique of one, every list but the first sent to self), so
+    // that dlopen, communicator, group semantics and datatypes are exercised on real hardware
+    int list[1] = {ix->devs[0].device};
+    if (g_rccl.CommInitAll(ix->comms, 1, list) == ncclSuccess) { ix->exchange = 2; ix->selftest = true; }
+  }
   if (nd > 1) {
     // direct xGMI paths root <-> every other device (a failure only means staged copies)
     const int root = ix->devs[0].device;
@@ -356,7 +363,7 @@ int index_search(rq_index *ix, float *dists, uint32_t *ids, const float *queries
       IxDev &dv = ix->devs[s.dev];
       RQ_HIP(hipSetDevice(dv.device));
       uint64_t *out = ix->gathered + (size_t)si * cnt;       // shards of the root device write in place
-      if (s.dev != 0) {
+      if (s.dev != 0 || (ix->selftest && si > 0)) {
         RQ_TRY(grow((void **)&s.keys, &s.keys_cap, cnt * 8));
         out = s.keys;
       }
@@ -379,7 +386,7 @@ int index_search(rq_index *ix, float *dists, uint32_t *ids, const float *queries
       RQ_NCCL(g_rccl.GroupStart());
       for (int si = 0; si < P; ++si) {
         IxShard &s = ix->shards[si];
-        if (s.dev == 0) continue;
+        if (s.dev == 0 && !(ix->selftest && si > 0)) continue;
         IxDev &dv = ix->devs[s.dev];
         RQ_NCCL(g_rccl.Send(s.keys, cnt, ncclUint64, 0, ix->comms[s.dev], dv.stream));
         RQ_NCCL(g_rccl.Recv(ix->gathered + (size_t)si * cnt, cnt, ncclUint64, s.dev, ix->comms[0], root.stream));

@@ -147,3 +147,25 @@ def test_two_host_threads_two_streams_do_not_interfere(rq):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs[:3]
+
+
+def test_rccl_transport_selftest_on_one_gpu(rq):
+    """The RCCL exchange itself (dlopen of librccl, single-process communicator, grouped ncclSend/ncclRecv of uint64
+    key lists) cannot meet a second GPU on this box; with EXCHANGE_SELFTEST every logical shard but the first sends
+    its list to rank 0 = itself through that very code path."""
+    g = golden("scan_sift_mini")
+    m = g["codes"].shape[1]
+    d = g["queries"].shape[1]
+    C = [g["centers"][i] for i in range(m)]
+    rq.set_tuning("EXCHANGE_SELFTEST", 1)
+    try:
+        with rq.Index(C, d, devices=[0, 0, 0, 0]) as ix:
+            ix.set_codes(g["codes"])
+            info = ix.info()
+            if info["exchange"] != "rccl":
+                pytest.skip("librccl could not be loaded / initialised on this box")
+            for K in g["Ks"]:
+                dists, ids = ix.search(g["queries"], int(K), id_base=0)
+                assert np.array_equal(ids, g["ids_K%d" % K]) and _eq_bits(dists, g["dists_K%d" % K]), K
+    finally:
+        rq.set_tuning("EXCHANGE_SELFTEST", 0)
