@@ -45,7 +45,11 @@ def shard_bounds(n_total, world):
 
 
 class ShardedIndex:
-    def __init__(self, codes_local, centers, id_offset, group=None, scan_fn=None, merge_fn=None, host_staging=False):
+    def __init__(self, codes_local, centers, id_offset, group=None, scan_fn=None, merge_fn=None, host_staging=False,
+                 always_exchange=False):
+        # always_exchange: take the all_to_all / gather path even at world size 1 (exercises the RCCL collectives
+        # on a one-GPU box; the product never sets it)
+        self.always_exchange = always_exchange
         # host_staging: run the collectives on CPU copies (debug aid: a gloo group over ranks that share one GPU)
         self.host_staging = host_staging
         self.codes = codes_local          # [n_local][m] uint8, resident on this rank's device
@@ -84,7 +88,7 @@ class ShardedIndex:
             raise ValueError("k=%d must be in [1, total rows = %d]" % (k, self.n_total))
         keys = self.local_keys(queries, k)
         per = (nq + W - 1) // W
-        if W == 1:
+        if W == 1 and not self.always_exchange:
             d, i = self.merge_fn(keys.view(nq, 1, k), k, id_base)
             return 0, nq, d, i
         if per * W != nq:  # equal splits for all_to_all_single: pad the query axis
@@ -112,7 +116,7 @@ class ShardedIndex:
         W = self.world
         nq = queries.shape[0]
         q_lo, q_hi, d, i = self.search_owned(queries, k, id_base)
-        if W == 1:
+        if W == 1 and not self.always_exchange:
             return d, i
         # rank 0 collects the owned blocks (nq/W * k * 8 bytes per rank) with a gather-to-root: W-1 point-to-
         # point transfers over W-1 DISTINCT xGMI links.  (An all_gather moves the same blocks to every rank and

@@ -169,3 +169,31 @@ def test_rccl_transport_selftest_on_one_gpu(rq):
                 assert np.array_equal(ids, g["ids_K%d" % K]) and _eq_bits(dists, g["dists_K%d" % K]), K
     finally:
         rq.set_tuning("EXCHANGE_SELFTEST", 0)
+
+
+def test_torch_distributed_rccl_collectives_at_world_size_one(rq):
+    """bench.py --gpus N runs rayuela.jl_amd/sharded.py over torch.distributed (backend nccl == RCCL).  A one-GPU box
+    cannot host two ranks (RCCL refuses a duplicate GPU), but the very collectives of the N-rank path --
+    all_reduce of the row count, all_to_all_single of int64 key lists, gather to rank 0 -- run here in a group of one."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from rayuela_jl_amd.sharded import ShardedIndex
+    from rayuela_jl_amd import device as rqd
+    g = golden("scan_sift_mini")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        codes = torch.from_numpy(g["codes"]).cuda()
+        centers = torch.from_numpy(g["centers"]).cuda()
+        Q = torch.from_numpy(g["queries"]).cuda()
+        ix = ShardedIndex(codes, centers, id_offset=0, always_exchange=True)
+        assert ix.n_total == g["codes"].shape[0]
+        for K in g["Ks"]:
+            d, i = ix.search(Q, int(K))
+            assert np.array_equal(i.cpu().numpy().view(np.uint32), g["ids_K%d" % K]), K
+            assert _eq_bits(d.cpu().numpy(), g["dists_K%d" % K]), K
+    finally:
+        dist.destroy_process_group()
