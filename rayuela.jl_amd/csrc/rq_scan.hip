@@ -314,13 +314,14 @@ __device__ __forceinline__ void emit_survivors(const float (&acc)[QG], const flo
 // some query are queued (row id, per wavefront) for the exact f32 evaluation above, 64 queued rows at a time.
 //
 //   entry  e_q[k][r] = min( floor( (T_q[k][r] - min_r T_q[k][.]) * inv_q ), CLAMP ),   CLAMP = 255 / M
-//   inv_q  a little BELOW  THR / (tau_q (1 + 2^-19) - sum_k min_k (1 - 2^-20))
+//   inv_q  a little BELOW  THR / (tau_q (1 + 2^-18) - sum_k min_k (1 - 2^-19))
 //   pass   sum_k e_q[k][b_k] <= THR            (byte sums cannot wrap: M * CLAMP <= 255)
 //
-// Soundness (every row with f32 distance d < tau passes): the real sum S of the 8 table entries is within
-// 7 * 2^-24 relative of the sequential f32 sum d (all entries >= 0), so S < tau (1 + 2^-21); the margins in
-// inv_q dominate every rounding of its own computation and of (T - min) * inv, so the computed entry never
-// exceeds the real (T - min) * THR / range, and the real sum of those is < THR.  Clamping only lowers entries.
+// Soundness (every row with f32 distance d < tau passes): the real sum S of the M <= 16 table entries is within
+// 15 * 2^-24 relative of the sequential f32 sum d (all entries >= 0), so S < tau (1 + 0.9e-6); the margins in
+// inv_q dominate every rounding of its own computation and of (T - min) * inv (accounting in build_qtab), so the
+// computed entry never exceeds the real (T - min) * THR / range with range >= S - sum_k min_k, the real sum of
+// those is <= THR, and the integer sum of their floors is <= THR.  Clamping only lowers entries.
 // The filter therefore passes a SUPERSET of {d < tau}; the exact evaluation decides, so results do not change.
 // ------------------------------------------------------------------------------------------
 // Byte accumulators hold the bounds of 8 sub-quantizers (8 * 31 <= 255).  M = 8: one accumulator set, compared
@@ -375,13 +376,17 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
     float base = 0.0f;
     for (int kk = 0; kk < M; ++kk) base = base + ctrl->fmin[kk][tid];
     const float tau = ctrl->tau[tid];
-    // margins: 2^-19 on tau, 2^-20 on the minima and on 1/step; the f32 sum of M <= 16 non-negative entries is
-    // within 15 * 2^-24 < 2^-20 relative of the real sum
-    const float range = tau * (1.0f + 1.9073486328125e-6f) - base * (1.0f - 9.5367431640625e-7f);
+    // Margins: 2^-18 on tau, 2^-19 on the minima and on 1/step.  What they have to cover (u = 2^-24): the sequential
+    // f32 sum of M <= 16 non-negative terms is within 15u/(1-15u) < 0.9e-6 of the real sum -- for the row's distance
+    // (so S < tau (1 + 0.9e-6) whenever d < tau) and for `base` against the real sum of the minima -- plus one rounding
+    // for each of the two products, the subtraction, the division, the reciprocal and its product (< 7u = 0.42e-6 in
+    // all).  2^-18 = 3.8e-6 and 2^-19 = 1.9e-6 leave a factor of two everywhere; their cost is nil (one filter step
+    // is range / THR, i.e. 1e-2 of the range).
+    const float range = tau * (1.0f + 3.814697265625e-6f) - base * (1.0f - 1.9073486328125e-6f);
     float inv = 0.0f;     // 0: every entry quantises to 0, i.e. the filter passes everything for this query
     if (tau < __uint_as_float(0x7f800000u) && range > 0.0f && base >= 0.0f) {
       const float step = range / THR;
-      const float cand = (1.0f / step) * (1.0f - 9.5367431640625e-7f);
+      const float cand = (1.0f / step) * (1.0f - 1.9073486328125e-6f);
       if (step > 0.0f && cand < __uint_as_float(0x7f800000u)) inv = cand;
     }
     ctrl->finv[tid] = inv;

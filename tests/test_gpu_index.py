@@ -197,3 +197,30 @@ def test_torch_distributed_rccl_collectives_at_world_size_one(rq):
             assert _eq_bits(d.cpu().numpy(), g["dists_K%d" % K]), K
     finally:
         dist.destroy_process_group()
+
+
+def test_row_ids_beyond_2_to_31_with_logical_shards(rq, oracle):
+    """2.2e9 rows (17.6 GB of synthetic codes) on ONE device as two logical shards: per-shard row counts stay below
+    2^31 (the kernels' limit), global ids are uint32 up to 4.29e9.  Size-independent check: every returned distance
+    is recomputed from the hash-generated code of the returned id; the lists must be ascending and cross 2^31."""
+    import torch
+    import rayuela_jl_amd.synth as synth
+    if torch.cuda.mem_get_info(0)[0] < 30 * (1 << 30):
+        pytest.skip("needs 30 GB of free device memory")
+    m, d, n, nq, k = 8, 32, 2_200_000_000, 8, 64
+    X = synth.sift_like(4000, d, seed=41)
+    C = synth.codebooks(X, m, 256, seed=42, iters=1, sample=4000)
+    Q = synth.sift_like(nq, d, seed=43)
+    with rq.Index(C, d, devices=[0, 0]) as ix:
+        ix.set_codes_synth(n, 777)
+        assert ix.info()["rows_per_shard"] == [n // 2, n // 2]
+        dists, ids = ix.search(Q, k, id_base=0)
+    assert (np.diff(dists, axis=1) >= 0).all() and ids.dtype == np.uint32
+    assert (ids >= 2 ** 31).any() and (ids < 2 ** 31).any() and int(ids.max()) < n
+    lut = np.stack([oracle.adc_lut(np.stack(C), Q[q]) for q in range(nq)])
+    e = ids.astype(np.uint64)[:, :, None] * np.uint64(m) + np.arange(m, dtype=np.uint64)[None, None, :]
+    cb = (synth.splitmix64(e ^ np.uint64(777)) >> np.uint64(56)).astype(np.int64)
+    acc = np.take_along_axis(lut[:, 0, :], cb[:, :, 0], axis=1)
+    for kk in range(1, m):
+        acc = acc + np.take_along_axis(lut[:, kk, :], cb[:, :, kk], axis=1)
+    assert _eq_bits(acc, dists)
