@@ -111,6 +111,7 @@ struct ScanCtrl {
   float fmin[16][QG];
   float finv[QG];
   uint32_t fpush;       // rows the pre-filter let through in the item's first block (it is switched off if too many)
+  int32_t base2[QG];    // after a second threshold estimate: (#candidates below the new tau) - (#candidates) at that moment
   SelState<QG> st;      // st.hist doubles as the per-wavefront queues of rows waiting for the exact evaluation
 };
 
@@ -134,6 +135,7 @@ struct ScanParams {
   uint32_t scratch_keys;    // LDS sort scratch capacity in keys
   uint32_t sample;          // rows sampled per slice to initialise tau (0 = off)
   uint32_t srank_mul;       // target survivors per slice = srank_mul * K (3; 0 forces the fallback, tests)
+  int retune_z;             // second threshold estimate after 1/8 of the rows: rank = mean + z sigma (6; 0 = off; < 0: tests)
   uint32_t *work_counter;
   float4 *gtab;               // [gridDim][GTAB_F4] L1-gathered part of the LUT
   unsigned long long *stats;  // optional [8]: cycles in lut, sample, stream, cuts, final cut, sort; #cuts; #fallbacks
@@ -468,9 +470,47 @@ __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, ui
   compact_leq<QG, TPG>(&ctrl->st, src, dst, cnt, tau_key, need, g, gi);
   if (need && gi == 0) {
     ctrl->cnt[g] = ctrl->st.newcnt[g];  // == K (keys are unique)
+    ctrl->base2[g] = 0;                 // the K kept keys are the K smallest so far: exact again
     ctrl->sel[g] = sel ^ 1u;
     atomicXor(&ctrl->selmask, 1u << g);
     ctrl->tau[g] = key_dist(tau_key);
+  }
+  __syncthreads();
+}
+
+// Second threshold estimate, once per item after the first `f` of the slice's rows: the candidates collected so far
+// are an exact sample of that fraction, so the number of them below the true K-th distance is Binomial(K, f); tau
+// becomes the distance of the candidate of rank  K f + z sqrt(K f (1 - f)) + 2  (z = 6), which lets ~K + z sqrt(K/f)
+// rows through the whole slice instead of the first estimate's 1.5-2.5 K: fewer exact re-evaluations, appends and
+// keys to cut at the end.  Nothing is discarded; candidates between the new and the old tau stay in the buffer, and
+// base2 = (#candidates below the new tau) - (#candidates) makes the end-of-slice check count only the former --
+// if fewer than K rows beat the tightened tau the slice is redone exactly, as after a failed first estimate.
+template <int M>
+__device__ __noinline__ void retune_tau(ScanCtrl<ScanCfg<M>::QG> *ctrl, const uint64_t *cand_wg, uint32_t cap, uint32_t r2) {
+  constexpr int QG = ScanCfg<M>::QG;
+  constexpr int TPG = SCAN_THREADS / QG;
+  const int g = threadIdx.x / TPG, gi = threadIdx.x % TPG;
+  const uint32_t cnt = ctrl->cnt[g];
+  const bool act = cnt > r2 && r2 >= 1;
+  const uint64_t *src = cand_wg + ((size_t)g * 2 + ctrl->sel[g]) * cap;
+  radix_select<QG, TPG>(&ctrl->st, src, cnt, r2, act, g, gi);
+  const uint32_t td = (uint32_t)(ctrl->st.prefix[g] >> 32);     // ordered bits of the r2-th smallest distance
+  if (gi == 0) ctrl->st.newcnt[g] = 0;
+  __syncthreads();
+  if (act) {
+    uint32_t c = 0;
+    for (uint32_t i = gi; i < cnt; i += TPG) c += (uint32_t)(src[i] >> 32) < td ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((gi & 63) == 0) atomicAdd(&ctrl->st.newcnt[g], c);
+  }
+  __syncthreads();
+  if (act && gi == 0) {
+    const float tau2 = ord2f(td);
+    if (tau2 < ctrl->tau[g]) {
+      ctrl->tau[g] = tau2;
+      ctrl->base2[g] = (int32_t)ctrl->st.newcnt[g] - (int32_t)cnt;
+    }
   }
   __syncthreads();
 }
@@ -612,6 +652,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
       ctrl->tau[tid] = __uint_as_float(0x7f800000u);  // +inf: everything passes until the first cut
       ctrl->cnt[tid] = 0;
       ctrl->sel[tid] = 0;
+      ctrl->base2[tid] = 0;
       if (tid == 0) { ctrl->selmask = 0; ctrl->fpush = 0; }
     }
     __syncthreads();
@@ -665,11 +706,40 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
         __syncthreads();
       }
     }
+    // second threshold estimate after ~1/8 of the rows (see retune_tau)
+    uint32_t retune_at = 0xffffffffu, retune_rank = 0;
+    if (attempt == 0 && p.retune_z != 0 && p.K >= 256 && rows >= 16u * (uint32_t)BLK) {
+      const uint32_t nb = max(1u, rows / (8u * (uint32_t)BLK));
+      retune_at = r_begin + nb * (uint32_t)BLK;
+      const float f = (float)(nb * (uint32_t)BLK) / (float)rows, mean = (float)p.K * f;
+      const float rk = mean + (float)p.retune_z * sqrtf(mean * (1.0f - f)) + 2.0f;
+      retune_rank = rk < 1.0f ? 1u : (uint32_t)ceilf(rk);
+    }
+    // wave-uniform values: keep them in SGPRs (as VGPRs they pushed the block's code words into scratch)
+    retune_at = __builtin_amdgcn_readfirstlane(retune_at);
+    retune_rank = __builtin_amdgcn_readfirstlane(retune_rank);
     t_ph = RQ_STAT_T();
 
     // ---- stream the slice -----------------------------------------------------------------------
 #pragma unroll 1
     for (uint32_t base = r_begin; base < r_end; base += BLK) {
+      if (base == retune_at) {
+        if (FILT && filt_on) {
+          while (qtail) {
+            const uint32_t take = min(qtail, 64u);
+            refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - take), take);
+            qtail -= take;
+          }
+        }
+        __syncthreads();       // every append of the first rows has landed, the queues are empty
+        retune_tau<M>(ctrl, cand_wg, p.cap, retune_rank);
+        if constexpr (FILT) {
+          if (filt_on) {
+            build_qtab<M>(ctrl, lut4, gtab, samp, tid);
+            __syncthreads();
+          }
+        }
+      }
       // ONE barrier per block.  Capacity invariant: cnt[q] + BLK <= cap for every q when a block starts.
       // The pre-barrier read of cnt may miss what slower wavefronts are still appending for the
       // previous block (at most BLK keys), hence cap = trigger + 2*BLK; behind the barrier cnt is exact.
@@ -854,7 +924,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     // ---- finish the item: cut to K, sort, write ----------------------------------------------
     if (attempt == 0) {
       // the sampled tau must have let at least min(K, rows) rows through for EVERY query
-      const bool shortfall = ctrl->cnt[g] < min((uint32_t)p.K, rows);
+      // (after a second estimate only the candidates below the tightened tau count: cnt + base2)
+      const bool shortfall = (int32_t)ctrl->cnt[g] + ctrl->base2[g] < (int32_t)min((uint32_t)p.K, rows);
       if (__syncthreads_or(shortfall)) continue;  // exact fallback: redo the slice from tau = +inf
     }
     if (!p.bigk) {
@@ -1201,6 +1272,7 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.cap = pl.cap; p.trigger = pl.trigger; p.p2 = pl.p2; p.scratch_keys = pl.scratch_keys;
   p.sample = pl.sample;
   p.srank_mul = (uint32_t)tuning("SCAN_SRANK_MUL", 2);
+  p.retune_z = tuning("SCAN_RETUNE_Z", 6);
   p.work_counter = work_counter; p.cand = cand;
   p.gtab = reinterpret_cast<float4 *>(reinterpret_cast<char *>(cand) + pl.gtab_off);
   p.bkt = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(cand) + pl.bkt_off);

@@ -319,3 +319,24 @@ def test_full_size_sift1m_properties(rq, oracle):
     d0, i0 = oracle.linscan_aqd_query(codes, centers, queries[sel], K)
     assert np.array_equal(ids.cpu().numpy().view(np.uint32)[sel], i0)
     assert _eq_bits(dists.cpu().numpy()[sel], d0)
+
+
+@pytest.mark.parametrize("z", [6, 1, -2, -8])
+def test_second_threshold_estimate_and_its_fallback(rq, oracle, z):
+    """After 1/8 of a slice the threshold is re-estimated from the candidates collected so far (rank K f + z sigma).
+    z = 6 is the shipped setting; smaller and negative z make the new threshold too tight on purpose, so that the
+    "fewer than K rows beat it" check must redo the slice exactly.  The answer never changes."""
+    import rayuela_jl_amd.synth as synth
+    rng = np.random.default_rng(12)
+    m, sub, n, nq = 8, 4, 400_000, 24
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=9)
+    rq.set_tuning("SCAN_RETUNE_Z", z)
+    try:
+        for K in (300, 1000, 3000):
+            d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+            d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+            assert np.array_equal(i0, i1) and _eq_bits(d0, d1), (z, K)
+    finally:
+        rq.set_tuning("SCAN_RETUNE_Z", 6)
