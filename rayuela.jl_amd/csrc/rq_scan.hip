@@ -134,8 +134,11 @@ struct ScanParams {
   uint32_t p2;              // next_pow2(K)
   uint32_t scratch_keys;    // LDS sort scratch capacity in keys
   uint32_t sample;          // rows sampled per slice to initialise tau (0 = off)
+  uint32_t sample_rt;       // ... for slices that get the second estimate (a looser first tau only rules 1/8 of the rows)
   uint32_t srank_mul;       // target survivors per slice = srank_mul * K (3; 0 forces the fallback, tests)
   int retune_z;             // second threshold estimate after 1/8 of the rows: rank = mean + z sigma (6; 0 = off; < 0: tests)
+  int retune_min_k;         // ... only for K >= this
+  int retune_div;           // ... after rows / retune_div rows (8)
   uint32_t *work_counter;
   float4 *gtab;               // [gridDim][GTAB_F4] L1-gathered part of the LUT
   unsigned long long *stats;  // optional [8]: cycles in lut, sample, stream, cuts, final cut, sort; #cuts; #fallbacks
@@ -625,7 +628,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     // The sample statistic is the per-thread MINIMUM of gsz rows, so the fraction of threads whose
     // minimum beats the q-quantile is 1-(1-q)^gsz (~ q*gsz only while that is small); gsz shrinks
     // for large K so that the selected rank stays in the well-conditioned middle of the 512 minima.
-    uint32_t S = p.sample;
+    // slices long enough for the second estimate (retune_tau) start from a smaller sample
+    const bool will_retune = p.retune_z != 0 && p.K >= p.retune_min_k && rows >= 16u * (uint32_t)BLK;
+    uint32_t S = will_retune ? p.sample_rt : p.sample;
     uint32_t srank = 0;
     bool sampled = false;
     const uint32_t Ks = max((uint32_t)p.K, 8u);   // k < 8 aims at the 8th neighbour: same machinery, still exact
@@ -708,8 +713,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     }
     // second threshold estimate after ~1/8 of the rows (see retune_tau)
     uint32_t retune_at = 0xffffffffu, retune_rank = 0;
-    if (attempt == 0 && p.retune_z != 0 && p.K >= 256 && rows >= 16u * (uint32_t)BLK) {
-      const uint32_t nb = max(1u, rows / (8u * (uint32_t)BLK));
+    if (attempt == 0 && will_retune) {
+      const uint32_t nb = max(1u, rows / ((uint32_t)p.retune_div * (uint32_t)BLK));
       retune_at = r_begin + nb * (uint32_t)BLK;
       const float f = (float)(nb * (uint32_t)BLK) / (float)rows, mean = (float)p.K * f;
       const float rk = mean + (float)p.retune_z * sqrtf(mean * (1.0f - f)) + 2.0f;
@@ -822,6 +827,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
       if (filt_on) {
         filtered = true;
         uint32_t npush = 0;      // wave-uniform: rows this wavefront queued in this block
+        asm volatile("; RQ_FILTER_LOOP_BEGIN" ::: "memory");     // markers for tests/test_isa.py (no instructions)
         // ---- pre-filter: byte lower bounds for the 8 queries, 8 bytes per gather; rows that may still beat a
         // threshold are queued for the exact evaluation, which runs 64 queued rows at a time
 #pragma unroll
@@ -887,6 +893,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
             } while (qtail >= 64u);
           }
         }
+        asm volatile("; RQ_FILTER_LOOP_END" ::: "memory");
         if (base == r_begin && lane == 0) atomicAdd(&ctrl->fpush, npush);
       }
       }
@@ -1271,8 +1278,12 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.nslices = pl.nslices; p.rows_per_slice = pl.rows_per_slice; p.ngroups = pl.ngroups; p.whole = pl.whole;
   p.cap = pl.cap; p.trigger = pl.trigger; p.p2 = pl.p2; p.scratch_keys = pl.scratch_keys;
   p.sample = pl.sample;
+  p.sample_rt = (uint32_t)tuning("SCAN_SAMPLE_RT", 4096);
+  if (tuning("SCAN_SAMPLE", 0) > 0) p.sample_rt = pl.sample;      // an explicit SCAN_SAMPLE rules both
   p.srank_mul = (uint32_t)tuning("SCAN_SRANK_MUL", 2);
   p.retune_z = tuning("SCAN_RETUNE_Z", 6);
+  p.retune_min_k = tuning("SCAN_RETUNE_MIN_K", 1);
+  p.retune_div = std::max(2, tuning("SCAN_RETUNE_DIV", 8));
   p.work_counter = work_counter; p.cand = cand;
   p.gtab = reinterpret_cast<float4 *>(reinterpret_cast<char *>(cand) + pl.gtab_off);
   p.bkt = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(cand) + pl.bkt_off);
