@@ -335,6 +335,29 @@ constexpr uint32_t FILT_CLAMP = 31;
 constexpr uint32_t FILT_THR8 = 95;
 constexpr uint32_t FILT_THR16 = 159;
 
+// (byte k of w) << SH in ONE VALU instruction (SDWA operand select; the compiler emits v_bfe_u32 + v_lshl_add_u32)
+template <int K, int SH>
+__device__ __forceinline__ uint32_t byte_shl(uint32_t w, uint32_t sh_reg) {
+  uint32_t r;
+  if constexpr (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(sh_reg), "v"(w));
+  else if constexpr (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(sh_reg), "v"(w));
+  else if constexpr (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(sh_reg), "v"(w));
+  else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(sh_reg), "v"(w));
+  return r;
+}
+
+// load from an ABSOLUTE LDS byte address (no symbol involved: constant parts fold into the instruction's offset field)
+template <class T> __device__ __forceinline__ T lds_abs_load(uint32_t addr);
+template <> __device__ __forceinline__ uint2 lds_abs_load<uint2>(uint32_t addr) {
+  typedef const unsigned long long __attribute__((address_space(3))) lds_u64_t;
+  const unsigned long long v = *(lds_u64_t *)(uintptr_t)addr;
+  return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+template <> __device__ __forceinline__ uint32_t lds_abs_load<uint32_t>(uint32_t addr) {
+  typedef const uint32_t __attribute__((address_space(3))) lds_u32_t;
+  return *(lds_u32_t *)(uintptr_t)addr;
+}
+
 template <int M> struct FiltVec;               // table entry: one byte per query of the group
 template <> struct FiltVec<8> { using type = uint2; };      // QG = 8: ds_read_b64
 template <> struct FiltVec<16> { using type = uint32_t; };  // QG = 4: ds_read_b32
@@ -461,14 +484,14 @@ __device__ __noinline__ void refine_rows(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_
 // Cut the candidate buffers of the flagged queries back to exactly K keys and refresh tau.
 template <int M>
 __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg,
-                                              const ScanParams &p, bool need, int g, int gi) {
+                                              const ScanParams &p, bool need, int g, int gi, uint32_t &vseq) {
   constexpr int QG = ScanCfg<M>::QG;
   constexpr int TPG = SCAN_THREADS / QG;
   const uint32_t cnt = ctrl->cnt[g];
   const uint32_t sel = ctrl->sel[g];
   const uint64_t *src = cand_wg + ((size_t)g * 2 + sel) * p.cap;
   uint64_t *dst = cand_wg + ((size_t)g * 2 + (sel ^ 1u)) * p.cap;
-  radix_select<QG, TPG>(&ctrl->st, src, cnt, (uint32_t)p.K, need, g, gi);
+  radix_select<QG, TPG>(&ctrl->st, src, cnt, (uint32_t)p.K, need, g, gi, vseq);
   const uint64_t tau_key = ctrl->st.prefix[g];
   compact_leq<QG, TPG>(&ctrl->st, src, dst, cnt, tau_key, need, g, gi);
   if (need && gi == 0) {
@@ -489,14 +512,15 @@ __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, ui
 // base2 = (#candidates below the new tau) - (#candidates) makes the end-of-slice check count only the former --
 // if fewer than K rows beat the tightened tau the slice is redone exactly, as after a failed first estimate.
 template <int M>
-__device__ __noinline__ void retune_tau(ScanCtrl<ScanCfg<M>::QG> *ctrl, const uint64_t *cand_wg, uint32_t cap, uint32_t r2) {
+__device__ __noinline__ uint32_t retune_tau(ScanCtrl<ScanCfg<M>::QG> *ctrl, const uint64_t *cand_wg, uint32_t cap, uint32_t r2,
+                                            uint32_t vseq) {
   constexpr int QG = ScanCfg<M>::QG;
   constexpr int TPG = SCAN_THREADS / QG;
   const int g = threadIdx.x / TPG, gi = threadIdx.x % TPG;
   const uint32_t cnt = ctrl->cnt[g];
   const bool act = cnt > r2 && r2 >= 1;
   const uint64_t *src = cand_wg + ((size_t)g * 2 + ctrl->sel[g]) * cap;
-  radix_select<QG, TPG>(&ctrl->st, src, cnt, r2, act, g, gi);
+  radix_select<QG, TPG>(&ctrl->st, src, cnt, r2, act, g, gi, vseq);
   const uint32_t td = (uint32_t)(ctrl->st.prefix[g] >> 32);     // ordered bits of the r2-th smallest distance
   if (gi == 0) ctrl->st.newcnt[g] = 0;
   __syncthreads();
@@ -516,6 +540,7 @@ __device__ __noinline__ void retune_tau(ScanCtrl<ScanCfg<M>::QG> *ctrl, const ui
     }
   }
   __syncthreads();
+  return vseq;
 }
 
 // phase accounting (diagnostics only; p.stats == nullptr in normal runs)
@@ -561,9 +586,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
   constexpr int CTRL_BYTES = (sizeof(ScanCtrl<QG>) + 15) & ~15;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   ScanCtrl<QG> *ctrl = reinterpret_cast<ScanCtrl<QG> *>(smem);
-  float *lut = reinterpret_cast<float *>(smem + CTRL_BYTES);
+  // LDS: [ctrl][aux: sample minima, later the byte tables][f32 tables][staged queries].  The byte tables sit
+  // right behind ctrl so that their addresses are byte * 8 + a COMPILE-TIME offset below 64 KiB: the hot loop's
+  // address is then one SDWA shift and the offset rides in the ds_read instruction.
+  uint32_t *samp = reinterpret_cast<uint32_t *>(smem + CTRL_BYTES);   // [QG][SCAN_THREADS] sample minima / qtab
+  float *lut = reinterpret_cast<float *>(smem + CTRL_BYTES + Cfg::AUX_BYTES);
   float *qstage = lut + Cfg::LUT_LDS_BYTES / 4;
-  uint32_t *samp = reinterpret_cast<uint32_t *>(qstage + QG * p.d);   // [QG][SCAN_THREADS] sample minima
   uint64_t *scratch = reinterpret_cast<uint64_t *>(smem + CTRL_BYTES);  // aliases lut (dead by then)
 
   const int tid = threadIdx.x;
@@ -573,6 +601,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
   float4 *gtab = p.gtab + (size_t)blockIdx.x * (Cfg::GTAB_F4 > 0 ? Cfg::GTAB_F4 : 1);
   const uint32_t tail_groups = p.ngroups - p.whole;
   const uint32_t nitems = p.whole + tail_groups * p.nslices;
+  uint32_t vseq = 0;                         // block_any() call counter (workgroup-uniform)
+  if (tid < 2) ctrl->st.vote[tid] = 0;
 
   for (;;) {
     __syncthreads();
@@ -697,7 +727,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
       RQ_STAT_ADD(1, t_ph);
     }
     // ---- pre-filter tables for this threshold (they live where the sample minima were) ---------------------
-    bool filt_on = FILT && p.filter && attempt == 0 && (uint64_t)rows >= 64ull * (uint64_t)Ks;
+    // (__builtin_amdgcn_groupstaticsize() == 0: the byte tables are addressed absolutely, see the hot loop)
+    bool filt_on = FILT && p.filter && attempt == 0 && (uint64_t)rows >= 64ull * (uint64_t)Ks &&
+                   __builtin_amdgcn_groupstaticsize() == 0;
     constexpr uint32_t FILT_QCAP = QG * 256 / (SCAN_THREADS / 64);   // queue entries per wavefront: st.hist split over the waves
     static_assert(!FILT || FILT_QCAP >= 128, "a wavefront's queue holds 64 waiting rows + one row-step of pushes");
     const uint32_t *qtab = samp;
@@ -737,7 +769,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
           }
         }
         __syncthreads();       // every append of the first rows has landed, the queues are empty
-        retune_tau<M>(ctrl, cand_wg, p.cap, retune_rank);
+        vseq = retune_tau<M>(ctrl, cand_wg, p.cap, retune_rank, vseq);
         if constexpr (FILT) {
           if (filt_on) {
             build_qtab<M>(ctrl, lut4, gtab, samp, tid);
@@ -749,7 +781,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
       // The pre-barrier read of cnt may miss what slower wavefronts are still appending for the
       // previous block (at most BLK keys), hence cap = trigger + 2*BLK; behind the barrier cnt is exact.
       const bool maybe = ctrl->cnt[g] > p.trigger;
-      if (__syncthreads_or(maybe)) {
+      if (block_any(maybe, ctrl->st.vote, vseq)) {
         const unsigned long long t_c = RQ_STAT_T();
         if (FILT && filt_on) {
           // the cut uses st.hist: every wavefront first runs its queued rows through the exact evaluation
@@ -761,7 +793,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
           __syncthreads();
         }
         const bool need = ctrl->cnt[g] > p.trigger;
-        compact_group<M>(ctrl, cand_wg, p, need, g, gi);
+        compact_group<M>(ctrl, cand_wg, p, need, g, gi, vseq);
         RQ_STAT_ADD(3, t_c);
         RQ_STAT_INC(6);
       }
@@ -837,6 +869,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
           // all RPT * M gathers of the sub-step are issued before the first sum (16 x ds_read_b64 / 32 x ds_read_b32)
           using FV = typename FiltVec<M>::type;
           const FV *qt = reinterpret_cast<const FV *>(qtab);
+          const uint32_t shreg = sizeof(FV) == 8 ? 3u : 2u;
           // gathers in flight together: 16 (M = 8: both rows of the sub-step; M = 16: one row -- 32 of them with
           // their 32 addresses spill registers in this loop)
           constexpr int RB = (RPT * M > 16) ? 1 : RPT;      // rows per gather batch
@@ -847,8 +880,20 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
           for (int r = rb; r < rb + RB; ++r) {
 #pragma unroll
             for (int k = 0; k < M; ++k) {
-              const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
-              e[r][k] = qt[k * 256 + byte];
+              // address = byte * sizeof(FV) (one SDWA shift) + compile-time offset of table k (in the instruction)
+              constexpr int SH = sizeof(FV) == 8 ? 3 : 2;
+              const uint32_t w32 = w[(r * M + k) >> 2];
+              uint32_t boff;
+              switch ((r * M + k) & 3) {
+                case 0: boff = byte_shl<0, SH>(w32, shreg); break;
+                case 1: boff = byte_shl<1, SH>(w32, shreg); break;
+                case 2: boff = byte_shl<2, SH>(w32, shreg); break;
+                default: boff = byte_shl<3, SH>(w32, shreg); break;
+              }
+              // absolute LDS address = CTRL_BYTES + k * table + byte * entry: the kernel has no static LDS (its dynamic
+              // segment starts at 0, checked once per launch through filt_on), so the constant part folds into the
+              // ds_read offset field and the whole address costs the one SDWA shift above
+              e[r][k] = lds_abs_load<FV>(boff + (uint32_t)(CTRL_BYTES + k * 256 * sizeof(FV)));
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -933,11 +978,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
       // the sampled tau must have let at least min(K, rows) rows through for EVERY query
       // (after a second estimate only the candidates below the tightened tau count: cnt + base2)
       const bool shortfall = (int32_t)ctrl->cnt[g] + ctrl->base2[g] < (int32_t)min((uint32_t)p.K, rows);
-      if (__syncthreads_or(shortfall)) continue;  // exact fallback: redo the slice from tau = +inf
+      if (block_any(shortfall, ctrl->st.vote, vseq)) continue;  // exact fallback: redo the slice from tau = +inf
     }
     if (!p.bigk) {
       bool need = ctrl->cnt[g] > (uint32_t)p.K;
-      if (__syncthreads_or(need)) compact_group<M>(ctrl, cand_wg, p, need, g, gi);
+      if (block_any(need, ctrl->st.vote, vseq)) compact_group<M>(ctrl, cand_wg, p, need, g, gi, vseq);
     }
     break;
     }  // attempts
@@ -1027,7 +1072,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_topk_kernel(MergeParams p
   const uint64_t *src = p.keys_in + (size_t)q * p.P * p.K;
   const uint32_t cnt = p.P * (uint32_t)p.K;
   for (uint32_t i = tid; i < p.p2; i += MERGE_THREADS) a[i] = KEY_MAX;
-  radix_select<1, MERGE_THREADS>(&ctrl->st, src, cnt, (uint32_t)p.K, true, 0, tid);
+  uint32_t vseq = 0;
+  if (tid < 2) ctrl->st.vote[tid] = 0;
+  __syncthreads();
+  radix_select<1, MERGE_THREADS>(&ctrl->st, src, cnt, (uint32_t)p.K, true, 0, tid, vseq);
   const uint64_t tau = ctrl->st.prefix[0];
   // survivors straight into LDS (padding keys equal to KEY_MAX never survive unless tau is one)
   if (tid == 0) ctrl->st.newcnt[0] = 0;

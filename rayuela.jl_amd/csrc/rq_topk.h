@@ -45,8 +45,23 @@ struct SelState {
   uint32_t krem[G];     // rank still to resolve inside the current bucket (1-based)
   uint32_t newcnt[G];   // compaction cursor
   uint32_t bcnt[G];     // population of the bucket chosen in the last pass
+  uint32_t vote[2];     // block_any() words (zeroed once per kernel)
   uint32_t hist[G][256];
 };
+
+// Workgroup-wide "does any thread have pred?" with ONE barrier and no static LDS.  HIP's __syncthreads_or/_and
+// reserve 256 bytes of static LDS, which moves the dynamic LDS base off zero and keeps the compiler from folding
+// LDS table offsets into the ds_read instructions of the scan's hot loop.  vote[2] lives in (dynamic) LDS and is
+// zeroed at kernel start; `seq` is a per-thread, workgroup-uniform call counter (every thread makes the same
+// calls).  Calls alternate between the two words, so a fast wavefront's next vote cannot overwrite the word a
+// slow one is still reading; sequence numbers replace resets.  All threads of the workgroup must call it.
+__device__ __forceinline__ bool block_any(bool pred, uint32_t *vote, uint32_t &seq) {
+  ++seq;
+  uint32_t *w = vote + (seq & 1u);
+  if (__ballot(pred) != 0 && (threadIdx.x & 63) == 0) atomicMax(w, seq);
+  __syncthreads();
+  return *w == seq;
+}
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
@@ -80,7 +95,7 @@ __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t digit, bool on
 template <int G, int TPG, int NPASS = 8>
 __device__ __forceinline__ void radix_select(SelState<G> *st, const uint64_t *__restrict__ src,
                                              uint32_t cnt, uint32_t k, bool active, int g,
-                                             int gi) {
+                                             int gi, uint32_t &vseq) {
   static_assert(TPG >= 64 && TPG % 64 == 0, "a query-lane is a whole number of wavefronts");
   if (gi == 0 && active) {
     st->prefix[g] = 0;
@@ -133,7 +148,7 @@ __device__ __forceinline__ void radix_select(SelState<G> *st, const uint64_t *__
       // its population -- always the case without distance ties) the answer is "all ids of this distance":
       // the id half needs no passes.  Uniform over the workgroup: all query-lanes must agree to stop.
       const bool done = !active || st->bcnt[g] == st->krem[g];
-      if (__syncthreads_and(done)) {
+      if (!block_any(!done, st->vote, vseq)) {
         if (gi == 0 && active) st->prefix[g] |= 0xFFFFFFFFull;
         __syncthreads();
         return;
