@@ -21,6 +21,7 @@ from .Linscan import (linscan_pq, linscan_opq, linscan_lsq, linscan_cq, linscan_
 
 from .index import Index, Dataset  # noqa: F401,E402
 from . import h5results  # noqa: F401,E402  (libhdf5 is looked up lazily, on first use)
+from . import datasets  # noqa: F401,E402
 
 __all__ = ["quantize_pq", "quantize_opq", "linscan_pq", "linscan_opq", "linscan_lsq", "linscan_cq",
            "eval_recall", "splitarray"]
