@@ -86,32 +86,38 @@ static bool rccl_load() {
   } while (0)
 
 // ---- [P][nq][k] -> [nq][P][k] ---------------------------------------------------------------------
+// pstride = keys between the blocks of two shards (nq_total * k when only a chunk of the queries is interleaved)
 __global__ void interleave_keys_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ src, size_t nq, uint32_t P,
-                                       uint32_t k) {
+                                       uint32_t k, size_t pstride) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t per_q = (size_t)P * k;
   if (i >= nq * per_q) return;
   const size_t q = i / per_q;
   const uint32_t rem = (uint32_t)(i - q * per_q);
   const uint32_t p = rem / k, j = rem - p * k;
-  dst[i] = src[((size_t)p * nq + q) * k + j];
+  dst[i] = src[(size_t)p * pstride + q * k + j];
 }
 
-int interleave_keys_launch(uint64_t *dst, const uint64_t *src, int64_t nq, int P, int k, hipStream_t stream) {
+int interleave_keys_launch(uint64_t *dst, const uint64_t *src, int64_t nq, int P, int k, size_t pstride, hipStream_t stream) {
   const size_t total = (size_t)nq * P * k;
   if (!total) return RQ_OK;
   hipLaunchKernelGGL(interleave_keys_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, dst, src,
-                     (size_t)nq, (uint32_t)P, (uint32_t)k);
+                     (size_t)nq, (uint32_t)P, (uint32_t)k, pstride);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
 }
 
 // ---- the handle -------------------------------------------------------------------------------------
+constexpr int IX_MAX_CHUNKS = 8;
+
 struct IxDev {          // one per DISTINCT device of the index
   int device = 0;
   int num_cu = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t done = nullptr;
+  hipStream_t stream = nullptr;     // uploads, rotation, scans
+  hipStream_t xstream = nullptr;    // top-k lists towards the root (SDMA peer copies / RCCL send, recv)
+  hipStream_t mstream = nullptr;    // root only: interleave + merge of a query chunk
+  hipEvent_t ev_scan[IX_MAX_CHUNKS] = {nullptr};   // this device's lists of chunk c are complete
+  hipEvent_t ev_xfer[IX_MAX_CHUNKS] = {nullptr};   // ... and have arrived on the root
   float *centers = nullptr;
   float *queries = nullptr, *queries_rot = nullptr, *R = nullptr;
   size_t q_cap = 0;
@@ -166,6 +172,7 @@ struct rq_index {
   // exchange
   ncclComm_t comms[16] = {nullptr};
   int exchange = 0;     // 0 none (one device), 1 peer copies, 2 RCCL
+  bool peer_ok = false;    // every device has a direct path to the root (hipDeviceCanAccessPeer)
   bool selftest = false;   // tuning EXCHANGE_SELFTEST on ONE device: logical shards 1.. travel through RCCL send/recv to self
   std::mutex mu;
 };
@@ -197,7 +204,12 @@ static void index_free(rq_index *ix) {
     if (dv.queries) (void)hipFree(dv.queries);
     if (dv.queries_rot) (void)hipFree(dv.queries_rot);
     if (dv.R) (void)hipFree(dv.R);
-    if (dv.done) (void)hipEventDestroy(dv.done);
+    for (int c = 0; c < IX_MAX_CHUNKS; ++c) {
+      if (dv.ev_scan[c]) (void)hipEventDestroy(dv.ev_scan[c]);
+      if (dv.ev_xfer[c]) (void)hipEventDestroy(dv.ev_xfer[c]);
+    }
+    if (dv.xstream) (void)hipStreamDestroy(dv.xstream);
+    if (dv.mstream) { (void)release_stream_workspace(dv.mstream); (void)hipStreamDestroy(dv.mstream); }
     if (dv.stream) { (void)release_stream_workspace(dv.stream); (void)hipStreamDestroy(dv.stream); }
   }
   (void)hipGetLastError();
@@ -228,7 +240,12 @@ static int index_build(rq_index *ix, int m, int d, const float *centers_host, co
       di = (int)ix->devs.size() - 1;
       IxDev &r = ix->devs[di];
       RQ_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
-      RQ_HIP(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+      RQ_HIP(hipStreamCreateWithFlags(&r.xstream, hipStreamNonBlocking));
+      if (di == 0) RQ_HIP(hipStreamCreateWithFlags(&r.mstream, hipStreamNonBlocking));
+      for (int c = 0; c < IX_MAX_CHUNKS; ++c) {
+        RQ_HIP(hipEventCreateWithFlags(&r.ev_scan[c], hipEventDisableTiming));
+        RQ_HIP(hipEventCreateWithFlags(&r.ev_xfer[c], hipEventDisableTiming));
+      }
       RQ_HIP(hipMalloc((void **)&r.centers, ce));
       RQ_HIP(hipMemcpy(r.centers, centers_host, ce, hipMemcpyHostToDevice));
     }
@@ -246,9 +263,11 @@ static int index_build(rq_index *ix, int m, int d, const float *centers_host, co
   if (nd > 1) {
     // direct xGMI paths root <-> every other device (a failure only means staged copies)
     const int root = ix->devs[0].device;
+    ix->peer_ok = true;
     for (int i = 1; i < nd; ++i) {
       int can = 0;
-      if (hipDeviceCanAccessPeer(&can, root, ix->devs[i].device) == hipSuccess && can) {
+      if (hipDeviceCanAccessPeer(&can, root, ix->devs[i].device) != hipSuccess || !can) ix->peer_ok = false;
+      if (can) {
         (void)hipSetDevice(root);
         (void)hipDeviceEnablePeerAccess(ix->devs[i].device, 0);
         (void)hipSetDevice(ix->devs[i].device);
@@ -357,64 +376,107 @@ int index_search(rq_index *ix, float *dists, uint32_t *ids, const float *queries
   } else {
     RQ_TRY(grow((void **)&ix->gathered, &ix->gathered_cap, (size_t)P * cnt * 8));
     RQ_TRY(grow((void **)&ix->inter, &ix->inter_cap, (size_t)P * cnt * 8));
-    // ---- local scans: every device works through its shards on its own stream ------------------------
+    // Query chunks: with several devices and long lists (k x nq x 8 B per shard: 80 MB at SIFT1M shape with k = 1000,
+    // 800 MB with the reference's default k = 10000) the exchange is as long as a device's scan of its 1/8 of the rows.
+    // The queries are then cut into C chunks and pipelined: scan of chunk c+1 on `stream` | lists of chunk c towards
+    // the root on `xstream` | merge of chunk c-1 on the root's `mstream`.  In that mode the lists travel as SDMA peer
+    // copies: the persistent scan grid holds every CU and all of the LDS, an RCCL kernel would wait for the scan to
+    // drain, the copy engines do not need a CU.  Every extra chunk costs a shard ~0.17 ms of fixed scan overhead
+    // (tools/chunk_cost.py: tables, threshold sample, launch tails), an xGMI link moves 64 MB in ~0.42 ms, so a
+    // chunk is at least 64 MB.  Unchunked (BASELINE config 5: 0.8 MB per device) the exchange is one RCCL group.
+    int C = tuning("IDX_QCHUNKS", 0);
+    if (C <= 0) C = (ix->devs.size() > 1) ? (int)std::min<size_t>(cnt * 8 / ((size_t)64 << 20), 4) : 1;
+    C = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(C, IX_MAX_CHUNKS), nq));
+    const bool use_rccl = ix->exchange == 2 && (C == 1 || ix->selftest || !ix->peer_ok || tuning("EXCHANGE_CHUNK_RCCL", 0));
+    auto remote = [&](int si) { return ix->shards[si].dev != 0 || (ix->selftest && si > 0); };
+
+    // ---- buffers first (growing one may synchronise the device) -----------------------------------------
     for (int si = 0; si < P; ++si) {
       IxShard &s = ix->shards[si];
       IxDev &dv = ix->devs[s.dev];
       RQ_HIP(hipSetDevice(dv.device));
-      uint64_t *out = ix->gathered + (size_t)si * cnt;       // shards of the root device write in place
-      if (s.dev != 0 || (ix->selftest && si > 0)) {
-        RQ_TRY(grow((void **)&s.keys, &s.keys_cap, cnt * 8));
-        out = s.keys;
-      }
+      if (remote(si)) RQ_TRY(grow((void **)&s.keys, &s.keys_cap, cnt * 8));
       const int k_local = (int)std::min<int64_t>(k, s.n);
-      if (k_local < k) RQ_HIP(hipMemsetAsync(out, 0xFF, cnt * 8, dv.stream));   // KEY_MAX padding: the shard has < k rows
-      if (k_local == 0) continue;
-      uint64_t *dst = out;
-      if (k_local < k) {
-        RQ_TRY(grow((void **)&s.tmp, &s.tmp_cap, (size_t)nq * k_local * 8));
-        dst = s.tmp;
-      }
-      RQ_TRY(dev_linscan(nullptr, nullptr, dst, s.codes, dv.centers, R_host ? dv.queries_rot : dv.queries, s.n, nq, m, d,
-                         k_local, (uint32_t)(ix->id_offset + (uint64_t)s.row0), 0, dv.stream));
-      if (k_local < k)
-        RQ_HIP(hipMemcpy2DAsync(out, (size_t)k * 8, s.tmp, (size_t)k_local * 8, (size_t)k_local * 8, (size_t)nq,
-                                hipMemcpyDeviceToDevice, dv.stream));
+      if (k_local < k && k_local > 0) RQ_TRY(grow((void **)&s.tmp, &s.tmp_cap, (size_t)nq * k_local * 8));
+      if (k_local < k)      // KEY_MAX padding: the shard has < k rows
+        RQ_HIP(hipMemsetAsync(remote(si) ? s.keys : ix->gathered + (size_t)si * cnt, 0xFF, cnt * 8, dv.stream));
     }
-    // ---- gather the lists of the other devices to the root -------------------------------------------
-    if (ix->exchange == 2) {
-      RQ_NCCL(g_rccl.GroupStart());
+    for (int c = 0; c < C; ++c) {
+      const int64_t q0 = nq * c / C, nqc = nq * (c + 1) / C - q0;
+      // ---- local scans of this chunk: every device works through its shards on its own stream ------------
       for (int si = 0; si < P; ++si) {
         IxShard &s = ix->shards[si];
-        if (s.dev == 0 && !(ix->selftest && si > 0)) continue;
         IxDev &dv = ix->devs[s.dev];
-        RQ_NCCL(g_rccl.Send(s.keys, cnt, ncclUint64, 0, ix->comms[s.dev], dv.stream));
-        RQ_NCCL(g_rccl.Recv(ix->gathered + (size_t)si * cnt, cnt, ncclUint64, s.dev, ix->comms[0], root.stream));
-      }
-      RQ_NCCL(g_rccl.GroupEnd());
-    } else {
-      for (int si = 0; si < P; ++si) {
-        IxShard &s = ix->shards[si];
-        if (s.dev == 0) continue;
-        IxDev &dv = ix->devs[s.dev];
+        const int k_local = (int)std::min<int64_t>(k, s.n);
+        if (k_local == 0) continue;
         RQ_HIP(hipSetDevice(dv.device));
-        RQ_HIP(hipMemcpyPeerAsync(ix->gathered + (size_t)si * cnt, root.device, s.keys, dv.device, cnt * 8, dv.stream));
+        uint64_t *out = (remote(si) ? s.keys : ix->gathered + (size_t)si * cnt) + (size_t)q0 * k;   // root shards: in place
+        uint64_t *dst = k_local < k ? s.tmp + (size_t)q0 * k_local : out;
+        const float *qs = (R_host ? dv.queries_rot : dv.queries) + (size_t)q0 * d;
+        RQ_TRY(dev_linscan(nullptr, nullptr, dst, s.codes, dv.centers, qs, s.n, nqc, m, d, k_local,
+                           (uint32_t)(ix->id_offset + (uint64_t)s.row0), 0, dv.stream));
+        if (k_local < k)
+          RQ_HIP(hipMemcpy2DAsync(out, (size_t)k * 8, dst, (size_t)k_local * 8, (size_t)k_local * 8, (size_t)nqc,
+                                  hipMemcpyDeviceToDevice, dv.stream));
       }
-      for (size_t i = 1; i < ix->devs.size(); ++i) {
-        IxDev &dv = ix->devs[i];
+      for (auto &dv : ix->devs) {
         RQ_HIP(hipSetDevice(dv.device));
-        RQ_HIP(hipEventRecord(dv.done, dv.stream));
-        RQ_HIP(hipStreamWaitEvent(root.stream, dv.done, 0));
+        RQ_HIP(hipEventRecord(dv.ev_scan[c], dv.stream));
       }
+      // ---- the lists of the other devices travel to the root ---------------------------------------------
+      RQ_HIP(hipSetDevice(root.device));
+      RQ_HIP(hipStreamWaitEvent(root.mstream, root.ev_scan[c], 0));
+      if (use_rccl) {
+        bool any = false;
+        for (size_t i = 0; i < ix->devs.size(); ++i) {
+          IxDev &dv = ix->devs[i];
+          RQ_HIP(hipSetDevice(dv.device));
+          RQ_HIP(hipStreamWaitEvent(dv.xstream, dv.ev_scan[c], 0));
+        }
+        RQ_NCCL(g_rccl.GroupStart());
+        for (int si = 0; si < P; ++si) {
+          if (!remote(si)) continue;
+          IxShard &s = ix->shards[si];
+          IxDev &dv = ix->devs[s.dev];
+          any = true;
+          RQ_NCCL(g_rccl.Send(s.keys + (size_t)q0 * k, (size_t)nqc * k, ncclUint64, 0, ix->comms[s.dev], dv.xstream));
+          RQ_NCCL(g_rccl.Recv(ix->gathered + (size_t)si * cnt + (size_t)q0 * k, (size_t)nqc * k, ncclUint64, s.dev,
+                              ix->comms[0], root.xstream));
+        }
+        RQ_NCCL(g_rccl.GroupEnd());
+        if (any) {
+          RQ_HIP(hipSetDevice(root.device));
+          RQ_HIP(hipEventRecord(root.ev_xfer[c], root.xstream));
+          RQ_HIP(hipStreamWaitEvent(root.mstream, root.ev_xfer[c], 0));
+        }
+      } else {
+        for (size_t i = 1; i < ix->devs.size(); ++i) {
+          IxDev &dv = ix->devs[i];
+          RQ_HIP(hipSetDevice(dv.device));
+          RQ_HIP(hipStreamWaitEvent(dv.xstream, dv.ev_scan[c], 0));
+          for (int si = 0; si < P; ++si) {
+            IxShard &s = ix->shards[si];
+            if (s.dev != (int)i) continue;
+            RQ_HIP(hipMemcpyPeerAsync(ix->gathered + (size_t)si * cnt + (size_t)q0 * k, root.device,
+                                      s.keys + (size_t)q0 * k, dv.device, (size_t)nqc * k * 8, dv.xstream));
+          }
+          RQ_HIP(hipEventRecord(dv.ev_xfer[c], dv.xstream));
+          RQ_HIP(hipStreamWaitEvent(root.mstream, dv.ev_xfer[c], 0));
+        }
+      }
+      // ---- merge of the chunk on the root ------------------------------------------------------------------
+      RQ_HIP(hipSetDevice(root.device));
+      uint64_t *inter = ix->inter + (size_t)q0 * P * k;
+      RQ_TRY(interleave_keys_launch(inter, ix->gathered + (size_t)q0 * k, nqc, P, k, cnt, root.mstream));
+      RQ_TRY(merge_launch(ix->dd + (size_t)q0 * k, ix->di + (size_t)q0 * k, nullptr, inter, nqc, P, k, id_base, root.mstream));
     }
-    // ---- merge on the root --------------------------------------------------------------------------------
-    RQ_HIP(hipSetDevice(root.device));
-    RQ_TRY(interleave_keys_launch(ix->inter, ix->gathered, nq, P, k, root.stream));
-    RQ_TRY(merge_launch(ix->dd, ix->di, nullptr, ix->inter, nq, P, k, id_base, root.stream));
   }
-  for (size_t i = ix->devs.size(); i-- > 0;) {     // the root last: its stream ends with the merge
-    RQ_HIP(hipSetDevice(ix->devs[i].device));
-    RQ_HIP(hipStreamSynchronize(ix->devs[i].stream));
+  for (size_t i = ix->devs.size(); i-- > 0;) {
+    IxDev &dv = ix->devs[i];
+    RQ_HIP(hipSetDevice(dv.device));
+    RQ_HIP(hipStreamSynchronize(dv.stream));
+    RQ_HIP(hipStreamSynchronize(dv.xstream));
+    if (dv.mstream) RQ_HIP(hipStreamSynchronize(dv.mstream));
   }
   const double kernel_ms = t2.ms();
   Clock t3;

@@ -77,7 +77,7 @@ int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *code
                 const float *queries, int64_t n, int64_t nq, int m, int d, int k, uint32_t id_offset,
                 int id_base, hipStream_t stream, int lut_mode = LUT_PQ, const float *row_bias = nullptr);
 // [P][nq][k] -> [nq][P][k] (lists gathered shard-major, merged query-major)
-int interleave_keys_launch(uint64_t *dst, const uint64_t *src, int64_t nq, int P, int k, hipStream_t stream);
+int interleave_keys_launch(uint64_t *dst, const uint64_t *src, int64_t nq, int P, int k, size_t pstride, hipStream_t stream);
 int scan_padded_m(int m);   // smallest tiled row width >= m (2,4,8,16,32,64) or -1
 int pad_codes_launch(uint8_t *dst, const uint8_t *src, int64_t n, int m, int mp, hipStream_t stream);
 int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t *keys_in, int64_t nq,

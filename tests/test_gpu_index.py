@@ -171,6 +171,38 @@ def test_rccl_transport_selftest_on_one_gpu(rq):
         rq.set_tuning("EXCHANGE_SELFTEST", 0)
 
 
+@pytest.mark.parametrize("selftest", [0, 1])
+@pytest.mark.parametrize("chunks", [2, 3, 8])
+def test_query_chunk_pipeline(rq, chunks, selftest):
+    """Long top-k lists are exchanged in query chunks (scan of chunk c+1 | transfer of chunk c | merge of chunk c-1 on
+    three streams); IDX_QCHUNKS forces the chunk count, with EXCHANGE_SELFTEST the chunks travel through RCCL."""
+    g = golden("scan_sift_mini")
+    m = g["codes"].shape[1]
+    d = g["queries"].shape[1]
+    C = [g["centers"][i] for i in range(m)]
+    rq.set_tuning("IDX_QCHUNKS", chunks)
+    rq.set_tuning("EXCHANGE_SELFTEST", selftest)
+    try:
+        with rq.Index(C, d, devices=[0, 0, 0]) as ix:
+            ix.set_codes(g["codes"])
+            if selftest and ix.info()["exchange"] != "rccl":
+                pytest.skip("librccl could not be loaded / initialised on this box")
+            for rep in range(2):
+                for K in g["Ks"]:
+                    dists, ids = ix.search(g["queries"], int(K), id_base=0)
+                    assert np.array_equal(ids, g["ids_K%d" % K]) and _eq_bits(dists, g["dists_K%d" % K]), K
+        # a shard shorter than k (KEY_MAX padding) inside a chunked search
+        n_small = 40
+        with rq.Index(C, d, devices=[0] * 7) as ix:
+            ix.set_codes(g["codes"][:n_small])
+            dists, ids = ix.search(g["queries"], 20, id_base=0)
+            d1, i1 = rq.linscan_aqd_query(g["codes"][:n_small], g["centers"], g["queries"], 20)
+            assert np.array_equal(ids, i1) and _eq_bits(dists, d1)
+    finally:
+        rq.set_tuning("IDX_QCHUNKS", 0)
+        rq.set_tuning("EXCHANGE_SELFTEST", 0)
+
+
 def test_torch_distributed_rccl_collectives_at_world_size_one(rq):
     """bench.py --gpus N runs rayuela.jl_amd/sharded.py over torch.distributed (backend nccl == RCCL).  A one-GPU box
     cannot host two ranks (RCCL refuses a duplicate GPU), but the very collectives of the N-rank path --
