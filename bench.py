@@ -259,6 +259,9 @@ def main():
         def scan():
             res["r"] = ix.search(Qs, K)
     scan_ms, scan_wall = timed(scan, a.steps, a.warmup, barrier)
+    if os.environ.get("RQ_SCAN_STATS") and rank == 0:      # development aid: the scan kernel's phase / filter counters
+        from rayuela_jl_amd import _lib
+        sys.stderr.write("scan_stats %s\n" % json.dumps(_lib.scan_stats()))
     if a.inproc:
         scan_ms = scan_wall      # the library's own streams do the work: host wall clock is the step time
 

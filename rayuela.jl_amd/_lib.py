@@ -123,7 +123,7 @@ def scan_plan(n, nq, m, d, k, num_cu=256):
 def scan_stats():
     out = (C.c_uint64 * 16)()
     check(lib().rq_scan_stats(C.cast(out, C.c_void_p)))
-    names = ["lut", "sample", "stream", "cuts", "final_cut", "sort_write", "n_cuts", "n_fallbacks", "sample_rows", "sort_load", "sort_stages", "sort_out", "refine", "n_refine_calls", "x14", "x15"]
+    names = ["lut", "sample", "stream", "cuts", "final_cut", "sort_write", "n_cuts", "n_fallbacks", "sample_rows", "sort_load", "sort_stages", "sort_out", "n_items", "n_items_filtered", "first_block_pushed", "first_block_rows"]
     return dict(zip(names, [int(x) for x in out]))
 
 

@@ -60,12 +60,15 @@ template <> struct LutVec<2> {
   static __device__ __forceinline__ float get(const type &v, int i) { return i == 0 ? v.x : v.y; }
 };
 
+#ifndef RQ_SCAN_QG8_MAX_M
+#define RQ_SCAN_QG8_MAX_M 8
+#endif
 template <int M>
 struct ScanCfg {
   // queries per LDS gather: a float4 entry (ds_read_b128) up to m = 32; m = 64 only fits the 160 KiB of
   // LDS with float2 entries (ds_read_b64, 2 queries per gather)
   static constexpr int QPG = (M <= 32) ? 4 : 2;
-  static constexpr int QG = (M <= 8) ? 8 : (M <= 32) ? 4 : 2;   // queries per group
+  static constexpr int QG = (M <= RQ_SCAN_QG8_MAX_M) ? 8 : (M <= 32) ? 4 : 2;   // queries per group
   static constexpr int NQUAD = QG / QPG;                         // gathers per code byte
   static constexpr int RPT = (32 / (M * NQUAD)) > 0 ? 32 / (M * NQUAD) : 1;   // rows per thread per sub-step
   static constexpr int SUB = SCAN_THREADS * RPT;    // rows per sub-step (one 16/32-byte load per lane)
@@ -360,7 +363,7 @@ template <> __device__ __forceinline__ uint32_t lds_abs_load<uint32_t>(uint32_t 
 
 template <int M> struct FiltVec;               // table entry: one byte per query of the group
 template <> struct FiltVec<8> { using type = uint2; };      // QG = 8: ds_read_b64
-template <> struct FiltVec<16> { using type = uint32_t; };  // QG = 4: ds_read_b32
+template <> struct FiltVec<16> { using type = std::conditional<ScanCfg<16>::QG == 8, uint2, uint32_t>::type; };
 
 template <int M>
 __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const float4 *lut4, const float4 *gtab4,
@@ -448,6 +451,15 @@ __device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC 
   if constexpr (M == 8) {
     constexpr uint32_t H = 0x80808080u, TC = (FILT_THR8 + 1u) * 0x01010101u;
     const uint32_t g0 = ((a[0] | H) - TC) | a[0], g1 = ((a[1] | H) - TC) | a[1];
+    return (g0 & g1 & H) != H;
+  } else if constexpr (ScanCfg<M>::NQUAD == 2) {
+    // two sets (k < 8, k >= 8) of 8 byte sums, each <= 248: A + B <= THR  <=>  floor((A + B) / 2) <= (THR - 1) / 2 for
+    // odd THR, and the per-byte average needs no wider fields: (A & B) + (((A ^ B) >> 1) & 0x7f..)
+    static_assert(FILT_THR16 % 2 == 1 && (FILT_THR16 - 1) / 2 < 128, "average trick");
+    constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR16 - 1u) / 2u + 1u) * 0x01010101u;
+    const uint32_t v0 = (a[0] & a[2]) + (((a[0] ^ a[2]) >> 1) & 0x7f7f7f7fu);
+    const uint32_t v1 = (a[1] & a[3]) + (((a[1] ^ a[3]) >> 1) & 0x7f7f7f7fu);
+    const uint32_t g0 = ((v0 | H) - TC) | v0, g1 = ((v1 | H) - TC) | v1;
     return (g0 & g1 & H) != H;
   } else {
     constexpr uint32_t H = 0x80008000u, F = 0x00ff00ffu, TC = (FILT_THR16 + 1u) * 0x00010001u;
@@ -972,6 +984,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     __syncthreads();   // every append of the slice has landed
 
     RQ_STAT_ADD(2, t_ph);
+    if (p.stats && tid == 0) {       // filter bookkeeping: items, items that kept the filter, first-block pushes, rows
+      atomicAdd(&p.stats[12], 1ull);
+      if (FILT && filt_on) atomicAdd(&p.stats[13], 1ull);
+      atomicAdd(&p.stats[14], (unsigned long long)ctrl->fpush);
+      atomicAdd(&p.stats[15], (unsigned long long)min(rows, (uint32_t)BLK));
+    }
     t_ph = RQ_STAT_T();
     // ---- finish the item: cut to K, sort, write ----------------------------------------------
     if (attempt == 0) {

@@ -50,7 +50,7 @@ if "scan" in a.what:
             from rayuela_jl_amd import _lib
             st = _lib.scan_stats()
             tot = sum(st[k] for k in ("lut", "sample", "stream", "final_cut", "sort_write")) or 1
-            print("   phases(%%): " + " ".join("%s=%.1f" % (k, 100.0 * st[k] / tot) for k in ("lut", "sample", "stream", "cuts", "final_cut", "sort_write")) + " n_cuts=%d n_fallbacks=%d sample_rows=%.1f%% sort_load=%.1f%% sort_stages=%.1f%% sort_out=%.1f%% refine=%.1f%% refine_calls=%d" % (st["n_cuts"], st["n_fallbacks"], 100.0 * st["sample_rows"] / tot, 100.0 * st["sort_load"] / tot, 100.0 * st["sort_stages"] / tot, 100.0 * st["sort_out"] / tot, 100.0 * st["refine"] / tot, st["n_refine_calls"]))
+            print("   phases(%%): " + " ".join("%s=%.1f" % (k, 100.0 * st[k] / tot) for k in ("lut", "sample", "stream", "cuts", "final_cut", "sort_write")) + " n_cuts=%d n_fallbacks=%d sample_rows=%.1f%% sort_load=%.1f%% sort_stages=%.1f%% sort_out=%.1f%% items=%d filtered=%d first_block_alive=%.2f%%" % (st["n_cuts"], st["n_fallbacks"], 100.0 * st["sample_rows"] / tot, 100.0 * st["sort_load"] / tot, 100.0 * st["sort_stages"] / tot, 100.0 * st["sort_out"] / tot, st["n_items"], st["n_items_filtered"], 100.0 * st["first_block_pushed"] / max(1, st["first_block_rows"])))
         print("scan   n=%d nq=%d m=%d K=%-5d %8.3f ms  %10.0f q/s  %7.1f GB/s-alg" % (n, nq, m, K, ms, nq / ms * 1e3, nq * n * m / ms / 1e6))
 if "aq" in a.what:   # linscan_lsq / linscan_cq: full-dimensional codebooks, LSQ adds the row norms
     codes = rqd.synth_codes(n, m, seed=1234)
