@@ -71,6 +71,11 @@ struct DevCtx {
   StreamWs sw[MAX_STREAM_WS];
   std::recursive_mutex launch_mu;
   hipStream_t aux[2] = {nullptr, nullptr};   // compute / transfer streams of the host-pointer calls
+  // device buffers of finished host-pointer calls, kept for the next one (hipMalloc + hipFree of the 170 MB a
+  // linscan_pq call stages cost 1.5-2.5 ms, a third of the call); rq_release_workspaces frees them
+  struct Cached { void *p; size_t bytes; };
+  std::vector<Cached> pool;
+  size_t pool_bytes = 0;
 };
 static DevCtx g_dev[16];
 
@@ -181,15 +186,57 @@ int release_workspaces() {
     c.sw[i].used = false;
     c.sw[i].stream = nullptr;
   }
+  for (auto &b : c.pool) (void)hipFree(b.p);
+  c.pool.clear();
+  c.pool_bytes = 0;
   return RQ_OK;
 }
 
-// RAII device buffer for the host-pointer entry points
+// RAII device buffer for the host-pointer entry points.  Buffers up to HOST_CACHE_MAX_MB (256) each go back to a
+// per-device pool of at most HOST_CACHE_MB (2048) instead of hipFree: every host-pointer call synchronises before it
+// returns, so a pooled buffer is idle.
 struct DevBuf {
   void *p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  int alloc(size_t bytes) {
-    RQ_HIP(hipMalloc(&p, bytes ? bytes : 16));
+  size_t bytes = 0;
+  int dev = -1;
+  ~DevBuf() {
+    if (!p) return;
+    const size_t each = (size_t)std::max(0, tuning("HOST_CACHE_MAX_MB", 256)) << 20;
+    const size_t total = (size_t)std::max(0, tuning("HOST_CACHE_MB", 2048)) << 20;
+    if (dev >= 0 && dev < 16 && bytes <= each) {
+      std::lock_guard<std::mutex> lk(g_mu);
+      DevCtx &c = g_dev[dev];
+      if (c.pool_bytes + bytes <= total && c.pool.size() < 64) {
+        c.pool.push_back({p, bytes});
+        c.pool_bytes += bytes;
+        return;
+      }
+    }
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != dev && dev >= 0) (void)hipSetDevice(dev);
+    (void)hipFree(p);
+    if (cur >= 0 && cur != dev) (void)hipSetDevice(cur);
+  }
+  int alloc(size_t want) {
+    want = ((want ? want : 16) + 255) & ~(size_t)255;
+    RQ_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 16) {
+      std::lock_guard<std::mutex> lk(g_mu);
+      DevCtx &c = g_dev[dev];
+      int best = -1;       // smallest pooled buffer that fits and is not more than twice too large
+      for (size_t i = 0; i < c.pool.size(); ++i)
+        if (c.pool[i].bytes >= want && c.pool[i].bytes <= 2 * want + (1u << 20) &&
+            (best < 0 || c.pool[i].bytes < c.pool[best].bytes)) best = (int)i;
+      if (best >= 0) {
+        p = c.pool[best].p;
+        bytes = c.pool[best].bytes;
+        c.pool_bytes -= bytes;
+        c.pool.erase(c.pool.begin() + best);
+        return RQ_OK;
+      }
+    }
+    RQ_HIP(hipMalloc(&p, want));
+    bytes = want;
     return RQ_OK;
   }
   template <class T> T *as() { return reinterpret_cast<T *>(p); }
