@@ -209,7 +209,9 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
  *                            (RCCL send/recv on a single-process ncclCommInitAll clique, or
  *                            hipMemcpyPeerAsync when tuning EXCHANGE_PEER=1 / librccl is absent) and merged
  *                            there.  (dist, id) keys are totally ordered and ids are global, so the result
- *                            is bit-identical to one scan of the whole base.
+ *                            is bit-identical to one scan of the whole base.  Lists of 128 MB or more per device
+ *                            (k x nq x 8 B) travel in up to 4 query chunks -- scan of chunk c+1 | copy of chunk c |
+ *                            merge of chunk c-1 on three streams; tuning IDX_QCHUNKS forces the chunk count.
  *   rq_index_set_codes       rows are split into contiguous shards whose sizes differ by at most one;
  *                            ids returned by searches are id_offset + row (+ id_base)
  *   rq_index_set_codes_synth SIFT1B-shape synthetic base generated on the devices:
@@ -236,7 +238,9 @@ void rq_index_destroy(rq_index *ix);
 /* Threading: every entry point may be called from any host thread.  Library scratch is keyed by
  * (device, stream) and the launch sequences of one device are serialised internally, so concurrent
  * calls on different streams or devices do not interfere; at most 8 distinct streams per device may
- * use the rq_dev_* calls before rq_release_workspaces() (which frees the current device's scratch). */
+ * use the rq_dev_* calls before rq_release_workspaces() (which frees the current device's scratch and the
+ * pool of staging buffers the host-pointer calls keep between calls: at most HOST_CACHE_MB = 2048 MB per device,
+ * buffers of up to HOST_CACHE_MAX_MB = 256 MB each; HOST_CACHE_MB=0 restores hipMalloc / hipFree per call). */
 int rq_release_workspaces(void);
 
 /* Diagnostic knob used by tests and tuning runs (same effect as env RQ_<KEY>):
@@ -248,8 +252,8 @@ int rq_set_tuning(const char *key, int value);
 /* Diagnostics: with tuning SCAN_STATS=1, summed shader-clock cycles (thread 0 of every workgroup) of the
  * last scan: [0] LUT build [1] threshold sample [2] streaming [3] in-stream cuts [4] final cut [5] sort+write,
  * [6] number of in-stream cuts, [7] number of exact fallbacks, [8] the row part of [1], [9..11] sort load / stages /
- * write-out, [12] cycles in the exact re-evaluation of pre-filtered rows (part of [2]), [13] its calls (64 rows each);
- * out has 16 slots. */
+ * write-out, [12] work items, [13] items that kept the integer pre-filter to their end, [14] rows the pre-filter let
+ * through in the items' first blocks, [15] rows of those blocks; out has 16 slots. */
 int rq_scan_stats(unsigned long long *out16);
 
 /* Diagnostics (pure host code, no device needed): the scan planner's decision for a shard of n rows, nq queries,
