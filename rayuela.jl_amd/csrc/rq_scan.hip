@@ -514,6 +514,123 @@ __device__ __noinline__ void refine_rows(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_
   emit_survivors<QG>(acc, tau, valid, row + id_offset, selmask, ctrl, cand_wg, cap, lane);
 }
 
+// The same queue, evaluated per (row, query) PAIR: of the QG queries of an alive row typically one or two passed the
+// byte bound (the bound is per query, so only those can beat their tau).  Lane i recomputes the byte sums of its row
+// (M gathers from the byte tables, the filter's own arithmetic), and the wavefront then walks the alive queries in
+// rounds: in round j every lane that still has one takes its next alive query q, gathers the M f32 entries
+// T_q[k][b_k] (4-byte gathers), sums them in the reference's order and appends the key if it beats tau_q (one LDS
+// atomic per survivor).  Against refine_rows (M * QG / 4 16-byte gathers per row, QG compares and ballots) this is
+// ~M 4-byte gathers per alive pair.  Soundness: a pair the bound rules out has d >= tau_q (build_qtab), so skipping
+// it cannot change the candidate set below tau.
+#ifndef RQ_REFINE_PAIRS
+#define RQ_REFINE_PAIRS 1
+#endif
+__device__ __forceinline__ uint32_t high_bits4(uint32_t x) {   // bits 7, 15, 23, 31 of x -> bits 0..3
+  return (((x >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xfu;
+}
+
+template <int M>
+__device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<M>::NACC * ScanCfg<M>::NQUAD]) {
+  using Cfg = ScanCfg<M>;
+  if constexpr (M == 8 && Cfg::NACC == 2) {
+    constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR8 - 1u) / 2u + 1u) * 0x01010101u;
+    const uint32_t v0 = (a[0] & a[2]) + (((a[0] ^ a[2]) >> 1) & 0x7f7f7f7fu);
+    const uint32_t v1 = (a[1] & a[3]) + (((a[1] ^ a[3]) >> 1) & 0x7f7f7f7fu);
+    const uint32_t g0 = ((v0 | H) - TC) | v0, g1 = ((v1 | H) - TC) | v1;
+    return (high_bits4(~g0) | (high_bits4(~g1) << 4));
+  } else if constexpr (M == 8) {
+    constexpr uint32_t H = 0x80808080u, TC = (FILT_THR8 + 1u) * 0x01010101u;
+    const uint32_t g0 = ((a[0] | H) - TC) | a[0], g1 = ((a[1] | H) - TC) | a[1];
+    return (high_bits4(~g0) | (high_bits4(~g1) << 4));
+  } else if constexpr (Cfg::NQUAD == 2) {
+    constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR16 - 1u) / 2u + 1u) * 0x01010101u;
+    const uint32_t v0 = (a[0] & a[2]) + (((a[0] ^ a[2]) >> 1) & 0x7f7f7f7fu);
+    const uint32_t v1 = (a[1] & a[3]) + (((a[1] ^ a[3]) >> 1) & 0x7f7f7f7fu);
+    const uint32_t g0 = ((v0 | H) - TC) | v0, g1 = ((v1 | H) - TC) | v1;
+    return (high_bits4(~g0) | (high_bits4(~g1) << 4));
+  } else {
+    // 16-bit fields: lo = queries 0 (bits 0-15) and 2 (16-31), hi = queries 1 and 3; bit 15 of (x | H) - TC set = dead
+    constexpr uint32_t H = 0x80008000u, F = 0x00ff00ffu, TC = (FILT_THR16 + 1u) * 0x00010001u;
+    const uint32_t lo = (a[0] & F) + (a[1] & F), hi = ((a[0] >> 8) & F) + ((a[1] >> 8) & F);
+    const uint32_t fl = ~((lo | H) - TC), fh = ~((hi | H) - TC);
+    return ((fl >> 15) & 1u) | (((fh >> 15) & 1u) << 1) | (((fl >> 31) & 1u) << 2) | (((fh >> 31) & 1u) << 3);
+  }
+}
+
+template <int M, bool BIAS>
+__device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, const uint8_t *codes,
+                                          const float *row_bias, uint32_t id_offset, uint32_t cap, const float4 *lut4,
+                                          const float4 *gtab, const uint32_t *qtab, const uint32_t *queue, uint32_t count) {
+  using Cfg = ScanCfg<M>;
+  constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD, KL = Cfg::KL;
+  static_assert(Cfg::QPG == 4, "pair refinement: float4 table entries");
+  using FV = typename FiltVec<M>::type;
+  const int lane = threadIdx.x & 63;
+  const bool valid = (uint32_t)lane < count;
+  const uint32_t row = queue[valid ? lane : 0];
+  uint32_t w1[(M + 3) / 4];
+  load_row<M>(w1, codes, row);
+  // byte sums of the row, exactly as the hot loop forms them
+  uint32_t a[Cfg::NACC * NQUAD];
+#pragma unroll
+  for (int i = 0; i < Cfg::NACC * NQUAD; ++i) a[i] = 0;
+  const FV *qt = reinterpret_cast<const FV *>(qtab);
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    const uint32_t byte = (w1[k >> 2] >> (8 * (k & 3))) & 0xffu;
+    const FV e = qt[k * 256 + byte];
+    if constexpr (NQUAD == 2) {
+      const uint2 v = *reinterpret_cast<const uint2 *>(&e);
+      a[(k / Cfg::KPA) * 2 + 0] += v.x;
+      a[(k / Cfg::KPA) * 2 + 1] += v.y;
+    } else {
+      a[k >> 3] += *reinterpret_cast<const uint32_t *>(&e);
+    }
+  }
+  uint32_t alive = valid ? filt_alive_bits<M>(a) : 0u;
+  const uint32_t selmask = __builtin_amdgcn_readfirstlane(ctrl->selmask);
+  const float bias = BIAS ? row_bias[row] : 0.0f;
+  const float *lutf = reinterpret_cast<const float *>(lut4);
+  const float *__restrict__ gtf = reinterpret_cast<const float *>(gtab);
+  while (__ballot(alive != 0u)) {
+    if (alive != 0u) {
+      const uint32_t q = (uint32_t)__builtin_ctz(alive);
+      alive &= alive - 1u;
+      const uint32_t qoff = (q >> 2) * 1024u + (q & 3u);       // float index of (quad, component) inside a k block
+      float tg[Cfg::KG > 0 ? Cfg::KG : 1];
+#pragma unroll
+      for (int k = KL; k < M; ++k) {
+        const uint32_t byte = (w1[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        tg[k - KL] = gtf[(uint32_t)(k - KL) * NQUAD * 1024u + qoff + byte * 4u];
+      }
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        const uint32_t byte = (w1[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        const float t = k < KL ? lutf[(uint32_t)k * NQUAD * 1024u + qoff + byte * 4u] : tg[k - KL];
+        acc = (k == 0) ? t : acc + t;        // deps/src/linscan_aqd.cpp:85-87, sequential f32
+      }
+      if (BIAS) acc = acc + bias;
+      if (acc < ctrl->tau[q]) {
+        const uint32_t pos = atomicAdd(&ctrl->cnt[q], 1u);
+        uint64_t *buf = cand_wg + ((size_t)q * 2 + ((selmask >> q) & 1u)) * cap;
+        buf[pos] = make_key(acc, row + id_offset);
+      }
+    }
+  }
+}
+
+template <int M, bool BIAS, bool FILT, class... A>
+__device__ __forceinline__ void refine_queue(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, const uint8_t *codes,
+                                             const float *row_bias, uint32_t id_offset, uint32_t cap, const float4 *lut4,
+                                             const float4 *gtab, const uint32_t *qtab, const uint32_t *queue, uint32_t count) {
+  if constexpr (FILT && ScanCfg<M>::HAS_FILT && RQ_REFINE_PAIRS)
+    refine_pairs<M, BIAS>(ctrl, cand_wg, codes, row_bias, id_offset, cap, lut4, gtab, qtab, queue, count);
+  else
+    refine_rows<M, BIAS>(ctrl, cand_wg, codes, row_bias, id_offset, cap, lut4, gtab, queue, count);
+}
+#define RQ_REFINE(c, cw, cd, rb, io, cp, l4, gt, qu, n) refine_queue<M, BIAS, FILT>(c, cw, cd, rb, io, cp, l4, gt, qtab, qu, n)
+
 // Cut the candidate buffers of the flagged queries back to exactly K keys and refresh tau.
 template <int M>
 __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg,
@@ -797,7 +914,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
         if (FILT && filt_on) {
           while (qtail) {
             const uint32_t take = min(qtail, 64u);
-            refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - take), take);
+            RQ_REFINE(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - take), take);
             qtail -= take;
           }
         }
@@ -820,7 +937,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
           // the cut uses st.hist: every wavefront first runs its queued rows through the exact evaluation
           while (qtail) {
             const uint32_t take = min(qtail, 64u);
-            refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - take), take);
+            RQ_REFINE(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - take), take);
             qtail -= take;
           }
           __syncthreads();
@@ -839,7 +956,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
           if (__builtin_amdgcn_readfirstlane(ctrl->fpush) * 100u > (uint32_t)BLK * MAX_SHARE_PCT) {
             while (qtail) {
               const uint32_t take = min(qtail, 64u);
-              refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - take), take);
+              RQ_REFINE(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - take), take);
               qtail -= take;
             }
             filt_on = false;
@@ -954,7 +1071,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
             }
             if constexpr (FILT_QCAP < 64u * (RPT + 1)) {     // small queue: make room after every row
               while (qtail >= 64u) {
-                refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - 64u), 64u);
+                RQ_REFINE(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - 64u), 64u);
                 qtail -= 64u;
               }
             }
@@ -966,7 +1083,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
             // bytes -> table gathers -- but the larger callee makes every call save more registers: 3.64 -> 4.16 ms)
             // (timing this call with clock64 costs two live VGPRs here, which spilled the code words of the block)
             do {
-              refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - 64u), 64u);
+              RQ_REFINE(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - 64u), 64u);
               qtail -= 64u;
             } while (qtail >= 64u);
           }
@@ -998,7 +1115,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     if (FILT && filt_on) {
       while (qtail) {          // slice end: the rest of the queue
         const uint32_t take = min(qtail, 64u);
-        refine_rows<M, BIAS>(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - take), take);
+        RQ_REFINE(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - take), take);
         qtail -= take;
       }
     }
