@@ -95,12 +95,9 @@ struct ScanCfg {
   static constexpr int LUT_LDS_BYTES = KL * QG * 1024;
   // integer pre-filter (see build_qtab): one byte per (sub-quantizer, code, query); tiled for M = 8 and 16
   static constexpr bool HAS_FILT = (M == 8 || M == 16) && SCAN_THREADS == 512;
-#ifndef RQ_FILT8_FINE
-#define RQ_FILT8_FINE 1
-#endif
-  // byte accumulators: 8 sub-quantizers each (RQ_FILT8_FINE, m = 8: two sets of 4 with 6-bit entries, half the step)
-  static constexpr int KPA = (M == 8 && RQ_FILT8_FINE) ? 4 : 8;
-  static constexpr int NACC = HAS_FILT ? M / KPA : 1;
+  // byte accumulator sets: 8 sub-quantizers each; m = 8 in FINE mode: two sets of 4 with 6-bit entries (half the step)
+  static constexpr int NACC = HAS_FILT ? (M == 8 ? 2 : M / 8) : 1;
+  static constexpr int kpa(bool fine) { return (M == 8 && fine) ? 4 : 8; }   // sub-quantizers per accumulator set
   static constexpr int QTAB_BYTES = HAS_FILT ? M * 256 * QG : 0;
   // scratch behind the staged queries: the threshold sample's [QG][SCAN_THREADS] minima, later the filter table
   static constexpr int AUX_BYTES = (QG * SCAN_THREADS * 4 > QTAB_BYTES) ? QG * SCAN_THREADS * 4 : QTAB_BYTES;
@@ -337,7 +334,7 @@ __device__ __forceinline__ void emit_survivors(const float (&acc)[QG], const flo
 // those is <= THR, and the integer sum of their floors is <= THR.  Clamping only lowers entries.
 // The filter therefore passes a SUPERSET of {d < tau}; the exact evaluation decides, so results do not change.
 // ------------------------------------------------------------------------------------------
-// Byte accumulators.  M = 8 (RQ_FILT8_FINE, default): TWO sets of 4 sub-quantizers with 6-bit entries (4 * 63 <= 255) and
+// Byte accumulators.  M = 8, FINE kernels (chosen for k >= 8192): TWO sets of 4 sub-quantizers with 6-bit entries (4 * 63 <= 255) and
 // THR8 = 191 -- half the quantisation step of one set of 8 with 5-bit entries and THR 95, same relative clamp (1/3 of
 // the range): 27 % fewer rows reach the exact evaluation (first block at SIFT1M shape: 7.0 -> 5.1 % of the rows at
 // K = 1000, 25.8 -> 19.9 % at K = 10000; K = 10000 7.38 -> 6.79 ms, K <= 1000 within 1 %; THR 159 / 223 / 255 are level
@@ -345,11 +342,8 @@ __device__ __forceinline__ void emit_survivors(const float (&acc)[QG], const flo
 // fields: floor((A + B) / 2) = (A & B) + (((A ^ B) >> 1) & 0x7f..) <= (THR - 1) / 2 for odd THR.
 // M = 16: two sets of 8 (8 * 31 <= 255), widened to 16-bit fields and compared against THR16.
 constexpr uint32_t FILT_CLAMP = 31;
-#ifndef RQ_FILT8_THR
-#define RQ_FILT8_THR (RQ_FILT8_FINE ? 191 : 95)
-#endif
-constexpr uint32_t FILT_THR8 = RQ_FILT8_THR;
-constexpr uint32_t FILT_CLAMP8 = RQ_FILT8_FINE ? 63 : 31;
+constexpr uint32_t filt_thr8(bool fine) { return fine ? 191u : 95u; }
+constexpr uint32_t filt_clamp8(bool fine) { return fine ? 63u : 31u; }
 constexpr uint32_t FILT_THR16 = 159;
 
 // (byte k of w) << SH in ONE VALU instruction (SDWA operand select; the compiler emits v_bfe_u32 + v_lshl_add_u32)
@@ -379,13 +373,13 @@ template <int M> struct FiltVec;               // table entry: one byte per quer
 template <> struct FiltVec<8> { using type = uint2; };      // QG = 8: ds_read_b64
 template <> struct FiltVec<16> { using type = std::conditional<ScanCfg<16>::QG == 8, uint2, uint32_t>::type; };
 
-template <int M>
+template <int M, bool FINE>
 __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const float4 *lut4, const float4 *gtab4,
                                            uint32_t *qtab, int tid) {
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD, KL = Cfg::KL;
   static_assert(Cfg::QPG == 4, "pre-filter tiling: float4 table entries");
-  constexpr float THR = (float)(M == 8 ? FILT_THR8 : FILT_THR16);
+  constexpr float THR = (float)(M == 8 ? filt_thr8(FINE) : FILT_THR16);
   const int wave = tid >> 6, lane = tid & 63;
   auto entry = [&](int kk, int quad, int r) -> float4 {
     return kk < KL ? lut4[(kk * NQUAD + quad) * 256 + r] : gtab4[((kk - KL) * NQUAD + quad) * 256 + r];
@@ -449,7 +443,7 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
       for (int c = 0; c < 4; ++c) {
         const float diff = t[c] - ctrl->fmin[kk][quad * 4 + c];
         const float x = diff * ctrl->finv[quad * 4 + c];
-        w |= (uint32_t)fminf(fmaxf(x, 0.0f), (float)(M == 8 ? FILT_CLAMP8 : FILT_CLAMP)) << (8 * c);   // float -> uint truncates = floor (x >= 0)
+        w |= (uint32_t)fminf(fmaxf(x, 0.0f), (float)(M == 8 ? filt_clamp8(FINE) : FILT_CLAMP)) << (8 * c);   // float -> uint truncates = floor (x >= 0)
       }
       qtab[e * NQUAD + quad] = w;
     }
@@ -461,16 +455,16 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
 //           sums s <= 252.  ((s | 0x80) - (T+1)) has bit 7 set iff (s & 0x7f) > T, and any s >= 0x80 is > T as well; no
 //           borrow crosses a byte because (s | 0x80) >= T + 1.
 //   M = 16: two sets of 4 byte sums; per query sum = A + B <= 496, widened to 16-bit fields, same trick with bit 15.
-template <int M>
+template <int M, bool FINE>
 __device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC * ScanCfg<M>::NQUAD]) {
-  if constexpr (M == 8 && ScanCfg<M>::NACC == 2) {
-    constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR8 - 1u) / 2u + 1u) * 0x01010101u;
+  if constexpr (M == 8 && FINE) {
+    constexpr uint32_t H = 0x80808080u, TC = ((filt_thr8(true) - 1u) / 2u + 1u) * 0x01010101u;
     const uint32_t v0 = (a[0] & a[2]) + (((a[0] ^ a[2]) >> 1) & 0x7f7f7f7fu);
     const uint32_t v1 = (a[1] & a[3]) + (((a[1] ^ a[3]) >> 1) & 0x7f7f7f7fu);
     const uint32_t g0 = ((v0 | H) - TC) | v0, g1 = ((v1 | H) - TC) | v1;
     return (g0 & g1 & H) != H;
   } else if constexpr (M == 8) {
-    constexpr uint32_t H = 0x80808080u, TC = (FILT_THR8 + 1u) * 0x01010101u;
+    constexpr uint32_t H = 0x80808080u, TC = (filt_thr8(false) + 1u) * 0x01010101u;
     const uint32_t g0 = ((a[0] | H) - TC) | a[0], g1 = ((a[1] | H) - TC) | a[1];
     return (g0 & g1 & H) != H;
   } else if constexpr (ScanCfg<M>::NQUAD == 2) {
@@ -529,17 +523,17 @@ __device__ __forceinline__ uint32_t high_bits4(uint32_t x) {   // bits 7, 15, 23
   return (((x >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xfu;
 }
 
-template <int M>
+template <int M, bool FINE>
 __device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<M>::NACC * ScanCfg<M>::NQUAD]) {
   using Cfg = ScanCfg<M>;
-  if constexpr (M == 8 && Cfg::NACC == 2) {
-    constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR8 - 1u) / 2u + 1u) * 0x01010101u;
+  if constexpr (M == 8 && FINE) {
+    constexpr uint32_t H = 0x80808080u, TC = ((filt_thr8(true) - 1u) / 2u + 1u) * 0x01010101u;
     const uint32_t v0 = (a[0] & a[2]) + (((a[0] ^ a[2]) >> 1) & 0x7f7f7f7fu);
     const uint32_t v1 = (a[1] & a[3]) + (((a[1] ^ a[3]) >> 1) & 0x7f7f7f7fu);
     const uint32_t g0 = ((v0 | H) - TC) | v0, g1 = ((v1 | H) - TC) | v1;
     return (high_bits4(~g0) | (high_bits4(~g1) << 4));
   } else if constexpr (M == 8) {
-    constexpr uint32_t H = 0x80808080u, TC = (FILT_THR8 + 1u) * 0x01010101u;
+    constexpr uint32_t H = 0x80808080u, TC = (filt_thr8(false) + 1u) * 0x01010101u;
     const uint32_t g0 = ((a[0] | H) - TC) | a[0], g1 = ((a[1] | H) - TC) | a[1];
     return (high_bits4(~g0) | (high_bits4(~g1) << 4));
   } else if constexpr (Cfg::NQUAD == 2) {
@@ -557,7 +551,7 @@ __device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<
   }
 }
 
-template <int M, bool BIAS>
+template <int M, bool BIAS, bool FINE>
 __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, const uint8_t *codes,
                                           const float *row_bias, uint32_t id_offset, uint32_t cap, const float4 *lut4,
                                           const float4 *gtab, const uint32_t *qtab, const uint32_t *queue, uint32_t count) {
@@ -581,13 +575,13 @@ __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64
     const FV e = qt[k * 256 + byte];
     if constexpr (NQUAD == 2) {
       const uint2 v = *reinterpret_cast<const uint2 *>(&e);
-      a[(k / Cfg::KPA) * 2 + 0] += v.x;
-      a[(k / Cfg::KPA) * 2 + 1] += v.y;
+      a[(k / Cfg::kpa(FINE)) * 2 + 0] += v.x;
+      a[(k / Cfg::kpa(FINE)) * 2 + 1] += v.y;
     } else {
       a[k >> 3] += *reinterpret_cast<const uint32_t *>(&e);
     }
   }
-  uint32_t alive = valid ? filt_alive_bits<M>(a) : 0u;
+  uint32_t alive = valid ? filt_alive_bits<M, FINE>(a) : 0u;
   const uint32_t selmask = __builtin_amdgcn_readfirstlane(ctrl->selmask);
   const float bias = BIAS ? row_bias[row] : 0.0f;
   const float *lutf = reinterpret_cast<const float *>(lut4);
@@ -620,16 +614,16 @@ __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64
   }
 }
 
-template <int M, bool BIAS, bool FILT, class... A>
+template <int M, bool BIAS, bool FILT, bool FINE>
 __device__ __forceinline__ void refine_queue(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, const uint8_t *codes,
                                              const float *row_bias, uint32_t id_offset, uint32_t cap, const float4 *lut4,
                                              const float4 *gtab, const uint32_t *qtab, const uint32_t *queue, uint32_t count) {
   if constexpr (FILT && ScanCfg<M>::HAS_FILT && RQ_REFINE_PAIRS)
-    refine_pairs<M, BIAS>(ctrl, cand_wg, codes, row_bias, id_offset, cap, lut4, gtab, qtab, queue, count);
+    refine_pairs<M, BIAS, FINE>(ctrl, cand_wg, codes, row_bias, id_offset, cap, lut4, gtab, qtab, queue, count);
   else
     refine_rows<M, BIAS>(ctrl, cand_wg, codes, row_bias, id_offset, cap, lut4, gtab, queue, count);
 }
-#define RQ_REFINE(c, cw, cd, rb, io, cp, l4, gt, qu, n) refine_queue<M, BIAS, FILT>(c, cw, cd, rb, io, cp, l4, gt, qtab, qu, n)
+#define RQ_REFINE(c, cw, cd, rb, io, cp, l4, gt, qu, n) refine_queue<M, BIAS, FILT, FINE>(c, cw, cd, rb, io, cp, l4, gt, qtab, qu, n)
 
 // Cut the candidate buffers of the flagged queries back to exactly K keys and refresh tau.
 template <int M>
@@ -728,7 +722,7 @@ __device__ __noinline__ void finish_bigk(const uint32_t *cnt_q, const uint32_t *
   }
 }
 
-template <int M, bool BIAS, bool FILT>
+template <int M, bool BIAS, bool FILT, bool FINE = false>
 __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p) {
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, RPT = Cfg::RPT, BLK = Cfg::BLK;
@@ -889,7 +883,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     uint32_t qtail = 0;      // wave-uniform
     if constexpr (FILT) {
       if (filt_on) {
-        build_qtab<M>(ctrl, lut4, gtab, samp, tid);
+        build_qtab<M, FINE>(ctrl, lut4, gtab, samp, tid);
         __syncthreads();
       }
     }
@@ -922,7 +916,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
         vseq = retune_tau<M>(ctrl, cand_wg, p.cap, retune_rank, vseq);
         if constexpr (FILT) {
           if (filt_on) {
-            build_qtab<M>(ctrl, lut4, gtab, samp, tid);
+            build_qtab<M, FINE>(ctrl, lut4, gtab, samp, tid);
             __syncthreads();
           }
         }
@@ -1056,13 +1050,13 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
             for (int k = 0; k < M; ++k) {
               if constexpr (Cfg::NQUAD == 2) {
                 const uint2 v = *reinterpret_cast<const uint2 *>(&e[r][k]);
-                a[(k / Cfg::KPA) * 2 + 0] += v.x;
-                a[(k / Cfg::KPA) * 2 + 1] += v.y;
+                a[(k / Cfg::kpa(FINE)) * 2 + 0] += v.x;
+                a[(k / Cfg::kpa(FINE)) * 2 + 1] += v.y;
               } else {
                 a[k >> 3] += *reinterpret_cast<const uint32_t *>(&e[r][k]);
               }
             }
-            const bool cand = filt_alive<M>(a) && (row0 + r < r_end);
+            const bool cand = filt_alive<M, FINE>(a) && (row0 + r < r_end);
             const uint64_t mq = __ballot(cand);
             if (mq) {
               if (cand) myq[qtail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u))] = row0 + r;
@@ -1359,6 +1353,14 @@ static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) 
   void (*kern)(ScanParams) = p.row_bias ? adc_scan_kernel<M, true, false> : adc_scan_kernel<M, false, false>;
   if constexpr (Cfg::HAS_FILT) {
     if (p.filter) kern = adc_scan_kernel<M, false, true>;
+    // m = 8, large k: the finer byte tables (6-bit entries, two sum sets) -- more VALU work per row, fewer rows for
+    // the exact evaluation.  Measured at SIFT1M shape, coarse vs fine: k = 1 2.23 / 2.34 ms, k = 100 2.36 / 2.39,
+    // k = 1000 2.91 / 2.91, k = 10000 6.62 / 6.26.
+    if constexpr (M == 8) {
+      int fine_k = tuning("SCAN_FINE_MIN_K", 0);
+      if (fine_k <= 0) fine_k = 8192;            // crossover measured between k = 4096 (level) and 10000
+      if (p.filter && p.K >= fine_k) kern = adc_scan_kernel<M, false, true, true>;
+    }
   } else {
     p.filter = 0;
   }

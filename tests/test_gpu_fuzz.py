@@ -71,6 +71,14 @@ def test_scan_prefilter_on_hostile_tables(rq, oracle, style, m, K):
     finally:
         rq.set_tuning("SCAN_FILTER", 1)
     assert np.array_equal(i1, i2) and _eq_bits(d1, d2)
+    if m == 8:
+        # ... and with the other byte-table variant (6-bit entries, two sum sets: the library's choice for k >= 8192)
+        rq.set_tuning("SCAN_FINE_MIN_K", 1)
+        try:
+            d3, i3 = rq.linscan_aqd_query(codes, centers, queries, K)
+        finally:
+            rq.set_tuning("SCAN_FINE_MIN_K", 0)
+        assert np.array_equal(i1, i3) and _eq_bits(d1, d3)
 
 
 @pytest.mark.parametrize("seed", range(16))

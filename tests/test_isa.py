@@ -30,7 +30,7 @@ def scan_asm(tmp_path_factory):
 
 
 def _kernel(asm, m, filt):
-    name = "_ZN2rq15adc_scan_kernelILi%dELb0ELb%dEEEvNS_10ScanParamsE" % (m, 1 if filt else 0)
+    name = "_ZN2rq15adc_scan_kernelILi%dELb0ELb%dELb0EEEvNS_10ScanParamsE" % (m, 1 if filt else 0)
     start = asm.index("\n" + name + ":")
     end = asm.index("s_endpgm", start)
     return [ln for ln in asm[start:end].splitlines() if ln.strip() and not ln.lstrip().startswith(";")]
@@ -51,9 +51,9 @@ def test_l1_table_release_acquire_around_the_barrier(scan_asm, m, filt):
         "no s_waitcnt vmcnt(0) between the last table store and the barrier:\n" + "\n".join(body[b - 8:b + 2])
 
 
-@pytest.mark.parametrize("m", [8, 16])
-def test_prefilter_hot_loop_has_no_scratch_traffic(scan_asm, m):
-    name = "_ZN2rq15adc_scan_kernelILi%dELb0ELb1EEEvNS_10ScanParamsE" % m
+@pytest.mark.parametrize("m,fine", [(8, 0), (8, 1), (16, 0)])
+def test_prefilter_hot_loop_has_no_scratch_traffic(scan_asm, m, fine):
+    name = "_ZN2rq15adc_scan_kernelILi%dELb0ELb1ELb%dEEEvNS_10ScanParamsE" % (m, fine)
     start = scan_asm.index("\n" + name + ":")
     lines = scan_asm[start:scan_asm.index("s_endpgm", start)].splitlines()
     lo = [i for i, ln in enumerate(lines) if "RQ_FILTER_LOOP_BEGIN" in ln]
