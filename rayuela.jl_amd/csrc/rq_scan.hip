@@ -73,7 +73,7 @@ struct ScanCfg {
   static constexpr int RPT = (32 / (M * NQUAD)) > 0 ? 32 / (M * NQUAD) : 1;   // rows per thread per sub-step
   static constexpr int SUB = SCAN_THREADS * RPT;    // rows per sub-step (one 16/32-byte load per lane)
 #ifndef RQ_SCAN_U8
-#define RQ_SCAN_U8 4
+#define RQ_SCAN_U8 8
 #endif
   static constexpr int U = (M <= 8) ? RQ_SCAN_U8 : (M <= 32) ? 2 : 1;  // sub-steps per block: loads of a block fly together
   static constexpr int BLK = SUB * U;               // rows per workgroup block (barrier / tau refresh period)
