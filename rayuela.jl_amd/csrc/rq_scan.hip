@@ -75,7 +75,10 @@ struct ScanCfg {
 #ifndef RQ_SCAN_U8
 #define RQ_SCAN_U8 8
 #endif
-  static constexpr int U = (M <= 8) ? RQ_SCAN_U8 : (M <= 32) ? 2 : 1;  // sub-steps per block: loads of a block fly together
+#ifndef RQ_SCAN_U16
+#define RQ_SCAN_U16 4
+#endif
+  static constexpr int U = (M <= 8) ? RQ_SCAN_U8 : (M <= 16) ? RQ_SCAN_U16 : (M <= 32) ? 2 : 1;  // sub-steps per block: loads of a block fly together
   static constexpr int BLK = SUB * U;               // rows per workgroup block (barrier / tau refresh period)
   static constexpr int LUT_BYTES = M * QG * 1024;   // full table; the LDS part is LUT_LDS_BYTES below
   // The LDS gather pipe is the kernel's bound (~11-12 cycles per 64-lane ds_read_b128 with random
