@@ -79,7 +79,15 @@ struct ScanCfg {
 #define RQ_SCAN_U16 4
 #endif
   static constexpr int U = (M <= 8) ? RQ_SCAN_U8 : (M <= 16) ? RQ_SCAN_U16 : (M <= 32) ? 2 : 1;  // sub-steps per block: loads of a block fly together
-  static constexpr int BLK = SUB * U;               // rows per workgroup block (barrier / tau refresh period)
+  static constexpr int BLK = SUB * U;               // rows per workgroup block
+  // blocks between two capacity votes (the only barrier of the streaming loop): one vote per ~32768 rows.  Measured at
+  // SIFT1M shape, votes every 1 / 2 / 4 / 8 blocks: k = 1 2.13 / 2.05 / 2.00 / 1.99 ms, k = 1000 2.62 / 2.62 / 2.46 / 2.44;
+  // the candidate buffers grow by 2 * VP * BLK keys (a slow wavefront may still be appending the previous period's rows)
+#ifdef RQ_SCAN_VP
+  static constexpr int VP = RQ_SCAN_VP;
+#else
+  static constexpr int VP = (32768 / BLK) < 1 ? 1 : (32768 / BLK) > 8 ? 8 : (32768 / BLK);
+#endif
   static constexpr int LUT_BYTES = M * QG * 1024;   // full table; the LDS part is LUT_LDS_BYTES below
   // The LDS gather pipe is the kernel's bound (~11-12 cycles per 64-lane ds_read_b128 with random
   // slots).  The vector-memory path can gather the same 16 bytes from an L1-resident table in ~29
@@ -138,7 +146,7 @@ struct ScanParams {
   uint32_t whole;           // query groups [0, whole) are ONE item over all rows (answer written directly);
                             // groups [whole, ngroups) are cut into nslices row slices (key lists -> merge)
   uint32_t cap;             // candidate buffer capacity per query (keys)
-  uint32_t trigger;         // compact when cnt > trigger  (cap - 2*BLK >= trigger >= K)
+  uint32_t trigger;         // compact when cnt > trigger  (cap - 2*VP*BLK >= trigger >= K)
   uint32_t p2;              // next_pow2(K)
   uint32_t scratch_keys;    // LDS sort scratch capacity in keys
   uint32_t sample;          // rows sampled per slice to initialise tau (0 = off)
@@ -924,11 +932,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
           }
         }
       }
-      // ONE barrier per block.  Capacity invariant: cnt[q] + BLK <= cap for every q when a block starts.
+      // ONE barrier per VP blocks.  Capacity invariant: cnt[q] + VP * BLK <= cap for every q when a period starts.
       // The pre-barrier read of cnt may miss what slower wavefronts are still appending for the
-      // previous block (at most BLK keys), hence cap = trigger + 2*BLK; behind the barrier cnt is exact.
+      // previous period (at most VP * BLK keys), hence cap = trigger + 2 * VP * BLK; behind the barrier cnt is exact.
+      const bool vote_now = Cfg::VP == 1 || ((base - r_begin) / (uint32_t)BLK) % (uint32_t)Cfg::VP == 0u;
       const bool maybe = ctrl->cnt[g] > p.trigger;
-      if (block_any(maybe, ctrl->st.vote, vseq)) {
+      if (vote_now && block_any(maybe, ctrl->st.vote, vseq)) {
         const unsigned long long t_c = RQ_STAT_T();
         if (FILT && filt_on) {
           // the cut uses st.hist: every wavefront first runs its queued rows through the exact evaluation
@@ -948,7 +957,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
         // The filter pays off while few rows pass it (0.5 - 5 % on clustered data).  Tables without contrast
         // (e.g. random codes against random codebooks at m = 16) let a large share through; the first block's
         // count decides for the rest of the item, and the exact loop takes over after the queues are drained.
-        if (filt_on && base == r_begin + BLK) {
+        if (filt_on && base == r_begin + (uint32_t)Cfg::VP * BLK) {
           constexpr uint32_t MAX_SHARE_PCT = (M == 8) ? 30u : 12u;
           if (__builtin_amdgcn_readfirstlane(ctrl->fpush) * 100u > (uint32_t)BLK * MAX_SHARE_PCT) {
             while (qtail) {
@@ -1389,7 +1398,7 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   pl.trigger = (uint32_t)K + slack;
   pl.sample = (uint32_t)tuning("SCAN_SAMPLE", 16384);
   // + 2048: rows waiting in the pre-filter's queues (< 128 per wavefront) are appended outside their block
-  pl.cap = pl.trigger + 2 * Cfg::BLK + 2048;
+  pl.cap = pl.trigger + 2 * Cfg::VP * Cfg::BLK + 2048;
   pl.p2 = next_pow2((uint32_t)K);
   // large K finishes with the global-memory sample sort: its LDS need does not grow with K
   pl.bigk = K > tuning("SCAN_SS_MIN_K", 1024);
