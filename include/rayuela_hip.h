@@ -34,6 +34,7 @@
 #ifndef RAYUELA_HIP_H_
 #define RAYUELA_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -242,6 +243,16 @@ void rq_index_destroy(rq_index *ix);
  * pool of staging buffers the host-pointer calls keep between calls: at most HOST_CACHE_MB = 2048 MB per device,
  * buffers of up to HOST_CACHE_MAX_MB = 256 MB each; HOST_CACHE_MB=0 restores hipMalloc / hipFree per call). */
 int rq_release_workspaces(void);
+
+/* Page-locked result buffers for the language shims.  linscan_* return 8 * k * nq bytes; into a freshly allocated
+ * pageable array (src/Linscan.jl:16-17 `zeros(Cfloat, k, nq)`, numpy `empty`) the copies back run at the speed of
+ * first-touch page faults (18 GB/s on the bench box: 4.4 ms for the 80 MB of the SIFT1M-shape answer, more than the
+ * scan).  A shim can instead take its result arrays from rq_host_alloc (hipHostMalloc'ed, pooled), wrap them without
+ * copying (Julia `unsafe_wrap` + finalizer, numpy `__array_interface__`) and return them with rq_host_free when the
+ * array is collected.  NULL = over the limit (HOST_PIN_MAX_MB = 4096 outstanding) or no device: use an ordinary array.
+ * The entry points accept either kind of memory; nothing else changes.  rq_release_workspaces also drops idle buffers. */
+void *rq_host_alloc(size_t bytes);
+void rq_host_free(void *p);
 
 /* Diagnostic knob used by tests and tuning runs (same effect as env RQ_<KEY>):
  *   SCAN_SLICES  force the number of row slices per shard (0 = automatic)

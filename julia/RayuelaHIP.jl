@@ -36,6 +36,23 @@ function _check(status::Cint)
   nothing
 end
 
+# Result arrays of the scans (the reference's `zeros(Cfloat, k, nq)`, src/Linscan.jl:16-17): every element is written
+# by the library, and large ones come page-locked from the library's pool (rq_host_alloc) -- the copy back into a fresh
+# pageable array runs at the speed of its first-touch page faults (4.4 ms for the 80 MB of a SIFT1M-shape answer).
+# They are ordinary `Matrix{T}` to the caller; the finalizer hands the buffer back when the array is collected.
+function _result(::Type{T}, k::Int, nq::Int) where T
+  bytes = sizeof(T) * k * nq
+  if bytes >= (4 << 20)
+    p = ccall((:rq_host_alloc, librayuela_hip), Ptr{Cvoid}, (Csize_t,), bytes)
+    if p != C_NULL
+      A = unsafe_wrap(Array, Ptr{T}(p), (k, nq); own=false)
+      finalizer(a -> ccall((:rq_host_free, librayuela_hip), Cvoid, (Ptr{Cvoid},), pointer(a)), A)
+      return A
+    end
+  end
+  return Matrix{T}(undef, k, nq)
+end
+
 # cat(C..., dims=3) for even splits; plain concatenation of the column-major blocks otherwise
 _cat_codebooks(C::Vector{Matrix{Float32}}) = vcat([vec(Ci) for Ci in C]...)
 
@@ -132,8 +149,8 @@ function linscan_pq(B::Matrix{UInt8}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat
   m, n  = size(B)
   d, nq = size(X)
   @show k, nq
-  dists = zeros(Cfloat, k, nq)
-  res   = zeros(Cuint,  k, nq)
+  dists = _result(Cfloat, k, nq)
+  res   = _result(Cuint,  k, nq)
   _check(ccall((:rq_linscan_pq, librayuela_hip), Cint,
     (Ptr{Cfloat}, Ptr{Cuint}, Ptr{Cuchar}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Int64, Cint, Cint, Cint, Cint),
     dists, res, B, cat(C..., dims=3), X, Int64(n), Int64(nq), Cint(b ÷ 8), Cint(d), Cint(k), Cint(1)))
@@ -152,8 +169,8 @@ function linscan_opq(B::Matrix{UInt8}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloa
                      R::Matrix{Cfloat}, k::Int=10000)
   m, n  = size(B)
   d, nq = size(X)
-  dists = zeros(Cfloat, k, nq)
-  res   = zeros(Cuint,  k, nq)
+  dists = _result(Cfloat, k, nq)
+  res   = _result(Cuint,  k, nq)
   _check(ccall((:rq_linscan_opq, librayuela_hip), Cint,
     (Ptr{Cfloat}, Ptr{Cuint}, Ptr{Cuchar}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Int64, Cint, Cint, Cint, Cint),
     dists, res, B, cat(C..., dims=3), X, R, Int64(n), Int64(nq), Cint(b ÷ 8), Cint(d), Cint(k), Cint(1)))
@@ -175,8 +192,8 @@ function linscan_lsq(B::Matrix{UInt8}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloa
   m, n  = size(B)
   d, nq = size(X)
   _, h  = size(C[1])
-  dists = zeros(Cfloat, k, nq)
-  res   = zeros(Cuint,  k, nq)
+  dists = _result(Cfloat, k, nq)
+  res   = _result(Cuint,  k, nq)
   _check(ccall((:rq_linscan_lsq, librayuela_hip), Cint,
     (Ptr{Cfloat}, Ptr{Cuint}, Ptr{Cuchar}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat},
      Int64, Int64, Cint, Cint, Cint, Cint, Cint),
@@ -196,8 +213,8 @@ function linscan_cq(B::Matrix{UInt8}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat
   m, n  = size(B)
   d, nq = size(X)
   _, h  = size(C[1])
-  dists = zeros(Cfloat, k, nq)
-  res   = zeros(Cuint,  k, nq)
+  dists = _result(Cfloat, k, nq)
+  res   = _result(Cuint,  k, nq)
   _check(ccall((:rq_linscan_cq, librayuela_hip), Cint,
     (Ptr{Cfloat}, Ptr{Cuint}, Ptr{Cuchar}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Int64, Cint, Cint, Cint, Cint, Cint),
     dists, res, B, X, hcat(C...), Int64(n), Int64(nq), Cint(m), Cint(h), Cint(d), Cint(k), Cint(1)))

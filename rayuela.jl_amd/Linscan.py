@@ -41,8 +41,8 @@ def linscan_pq(B, X, C, b, k=10000):
     if b != 8 * m:
         raise ValueError("b must be log2(256)*m = %d" % (8 * m))
     cen = _centers(C, m, d)
-    dists = np.empty((nq, k), dtype=np.float32)     # every element is written by the library
-    idx = np.empty((nq, k), dtype=np.uint32)
+    dists = _lib.result_empty((nq, k), np.float32)     # every element is written by the library
+    idx = _lib.result_empty((nq, k), np.uint32)
     _lib.check(_lib.lib().rq_linscan_pq(dists.ctypes.data, idx.ctypes.data, Bu.ctypes.data, cen.ctypes.data,
                                         X.ctypes.data, n, nq, m, d, k, 1))
     return dists, idx
@@ -60,8 +60,8 @@ def linscan_opq(B, X, C, b, R, k=10000):
     if b != 8 * m:
         raise ValueError("b must be log2(256)*m = %d" % (8 * m))
     cen = _centers(C, m, d)
-    dists = np.empty((nq, k), dtype=np.float32)     # every element is written by the library
-    idx = np.empty((nq, k), dtype=np.uint32)
+    dists = _lib.result_empty((nq, k), np.float32)     # every element is written by the library
+    idx = _lib.result_empty((nq, k), np.uint32)
     _lib.check(_lib.lib().rq_linscan_opq(dists.ctypes.data, idx.ctypes.data, Bu.ctypes.data, cen.ctypes.data,
                                          X.ctypes.data, R.ctypes.data, n, nq, m, d, k, 1))
     return dists, idx
@@ -90,8 +90,8 @@ def linscan_lsq(B, X, C, dbnorms, R, k=10000):
     nrm = np.ascontiguousarray(dbnorms, dtype=np.float32)
     if nrm.shape != (n,):
         raise ValueError("dbnorms must have one entry per database row")
-    dists = np.empty((nq, k), dtype=np.float32)     # every element is written by the library
-    idx = np.empty((nq, k), dtype=np.uint32)
+    dists = _lib.result_empty((nq, k), np.float32)     # every element is written by the library
+    idx = _lib.result_empty((nq, k), np.uint32)
     _lib.check(_lib.lib().rq_linscan_lsq(dists.ctypes.data, idx.ctypes.data, Bu.ctypes.data, X.ctypes.data,
                                          cb.ctypes.data, nrm.ctypes.data, R.ctypes.data, n, nq, m, 256, d, k, 1))
     return dists, idx
@@ -104,8 +104,8 @@ def linscan_cq(B, X, C, k=10000):
     n, m = Bu.shape
     nq, d = X.shape
     cb = _hcat(C, m, d)
-    dists = np.empty((nq, k), dtype=np.float32)     # every element is written by the library
-    idx = np.empty((nq, k), dtype=np.uint32)
+    dists = _lib.result_empty((nq, k), np.float32)     # every element is written by the library
+    idx = _lib.result_empty((nq, k), np.uint32)
     _lib.check(_lib.lib().rq_linscan_cq(dists.ctypes.data, idx.ctypes.data, Bu.ctypes.data, X.ctypes.data,
                                         cb.ctypes.data, n, nq, m, 256, d, k, 1))
     return dists, idx

@@ -5,6 +5,8 @@ and every wrapper raises RayuelaHipError on a non-zero status (message from rq_l
 The binding mirrors include/rayuela_hip.h one to one.
 """
 import ctypes as C
+
+import numpy as np
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -67,6 +69,8 @@ SIGNATURES = {
     "rq_index_search_opq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rq_index_info": (_i32, [_vp, _vp, _i32]),
     "rq_release_workspaces": (_i32, []),
+    "rq_host_alloc": (_vp, [C.c_size_t]),
+    "rq_host_free": (None, [_vp]),
     "rq_index_search": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rq_index_destroy": (None, [_vp]),
     "rq_set_tuning": (_i32, [C.c_char_p, _i32]),
@@ -125,6 +129,38 @@ def scan_stats():
     check(lib().rq_scan_stats(C.cast(out, C.c_void_p)))
     names = ["lut", "sample", "stream", "cuts", "final_cut", "sort_write", "n_cuts", "n_fallbacks", "sample_rows", "sort_load", "sort_stages", "sort_out", "n_items", "n_items_filtered", "first_block_pushed", "first_block_rows"]
     return dict(zip(names, [int(x) for x in out]))
+
+
+class _PinnedBlock:
+    """A page-locked buffer of the library's pool, exposed through the array interface; returned to the pool when the
+    last numpy view of it is collected."""
+
+    def __init__(self, ptr, shape, dtype):
+        self._ptr = ptr
+        self.__array_interface__ = {"shape": tuple(shape), "typestr": np.dtype(dtype).str, "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            lib().rq_host_free(self._ptr)
+        except Exception:     # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+# Results below this size are not worth a pool round trip (and small pinned allocations fragment the pool)
+_PIN_MIN_BYTES = 4 << 20
+
+
+def result_empty(shape, dtype):
+    """An uninitialised result array: page-locked memory from the library's pool (rq_host_alloc) when the array is large,
+    else numpy's own.  Page-locked results skip the first-touch page faults that otherwise bound the copy back
+    (include/rayuela_hip.h); they are ordinary numpy arrays to the caller."""
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dtype.itemsize
+    if nbytes >= _PIN_MIN_BYTES:
+        ptr = lib().rq_host_alloc(nbytes)
+        if ptr:
+            return np.asarray(_PinnedBlock(ptr, shape, dtype))
+    return np.empty(shape, dtype=dtype)
 
 
 def last_timing():

@@ -192,6 +192,79 @@ int release_workspaces() {
   return RQ_OK;
 }
 
+// ---- page-locked result buffers for the language shims --------------------------------------------------------
+// A linscan call returns 8 * k * nq bytes (80 MB at SIFT1M shape, k = 1000).  Into a fresh pageable array (Julia
+// `zeros`, numpy `empty`: untouched pages) the device-to-host copies run at the speed of first-touch page faults --
+// 18 GB/s on the bench box, 4.4 ms, more than the scan itself; 16 host threads copying into fresh pages reach the same
+// 18 GB/s (tools/micro/pagefault_copy.cpp), so it is the kernel's fault path, not the copy.  rq_host_alloc hands the
+// shim a page-locked buffer instead (hipHostMalloc, ~50 GB/s, no faults) that the shim wraps as the result array and
+// gives back with rq_host_free when the array is collected; freed buffers are pooled (hipHostMalloc costs
+// milliseconds).  Limits: HOST_PIN_MAX_MB (4096) handed out at any time -- beyond it rq_host_alloc returns NULL and
+// the shim uses an ordinary array -- and HOST_PIN_POOL_MB (1024) kept idle.
+struct HostPool {
+  struct Buf { void *p; size_t bytes; };
+  std::vector<Buf> idle, live;
+  size_t idle_bytes = 0, live_bytes = 0;
+};
+static HostPool g_hp;
+
+void *host_pool_alloc(size_t bytes) {
+  if (!bytes || !tuning("HOST_PIN", 1)) return nullptr;
+  const size_t want = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+  int max_mb = tuning("HOST_PIN_MAX_MB", 0);
+  if (max_mb <= 0) max_mb = 4096;
+  const size_t max_live = (size_t)max_mb << 20;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_hp.live_bytes + want > max_live) return nullptr;
+  int best = -1;
+  for (size_t i = 0; i < g_hp.idle.size(); ++i)
+    if (g_hp.idle[i].bytes >= want && g_hp.idle[i].bytes <= 2 * want &&
+        (best < 0 || g_hp.idle[i].bytes < g_hp.idle[best].bytes)) best = (int)i;
+  HostPool::Buf b{nullptr, 0};
+  if (best >= 0) {
+    b = g_hp.idle[best];
+    g_hp.idle_bytes -= b.bytes;
+    g_hp.idle.erase(g_hp.idle.begin() + best);
+  } else {
+    if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    b.bytes = want;
+  }
+  g_hp.live.push_back(b);
+  g_hp.live_bytes += b.bytes;
+  return b.p;
+}
+
+void host_pool_free(void *p) {
+  if (!p) return;
+  int keep_mb = tuning("HOST_PIN_POOL_MB", 0);
+  if (keep_mb <= 0) keep_mb = 1024;
+  const size_t keep = (size_t)keep_mb << 20;
+  HostPool::Buf b{nullptr, 0};
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = 0; i < g_hp.live.size(); ++i)
+      if (g_hp.live[i].p == p) { b = g_hp.live[i]; g_hp.live.erase(g_hp.live.begin() + i); break; }
+    if (!b.p) return;                       // not ours
+    g_hp.live_bytes -= b.bytes;
+    if (g_hp.idle_bytes + b.bytes <= keep && g_hp.idle.size() < 64) {
+      g_hp.idle.push_back(b);
+      g_hp.idle_bytes += b.bytes;
+      return;
+    }
+  }
+  (void)hipHostFree(b.p);
+}
+
+void host_pool_trim() {
+  std::vector<HostPool::Buf> drop;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    drop.swap(g_hp.idle);
+    g_hp.idle_bytes = 0;
+  }
+  for (auto &b : drop) (void)hipHostFree(b.p);
+}
+
 // RAII device buffer for the host-pointer entry points.  Buffers up to HOST_CACHE_MAX_MB (256) each go back to a
 // per-device pool of at most HOST_CACHE_MB (2048) instead of hipFree: every host-pointer call synchronises before it
 // returns, so a pooled buffer is idle.
@@ -620,7 +693,13 @@ int rq_scan_stats(unsigned long long *out8) {
   return RQ_OK;
 }
 
-int rq_release_workspaces(void) { return release_workspaces(); }
+int rq_release_workspaces(void) {
+  rq::host_pool_trim();
+  return release_workspaces();
+}
+
+void *rq_host_alloc(size_t bytes) { return rq::host_pool_alloc(bytes); }
+void rq_host_free(void *p) { rq::host_pool_free(p); }
 
 int rq_last_timing(double *total_ms, double *h2d_ms, double *kernel_ms, double *d2h_ms) {
   if (total_ms) *total_ms = g_t_total;

@@ -50,8 +50,8 @@ class Index:
         nq, d = X.shape
         if d != self.d:
             raise ValueError("queries must have d=%d columns" % self.d)
-        dists = np.zeros((nq, k), dtype=np.float32)
-        idx = np.zeros((nq, k), dtype=np.uint32)
+        dists = _lib.result_empty((nq, k), np.float32)
+        idx = _lib.result_empty((nq, k), np.uint32)
         lib = _lib.lib()
         if R is None:
             _lib.check(lib.rq_index_search(self._h, dists.ctypes.data, idx.ctypes.data, X.ctypes.data, nq, k, id_base))

@@ -85,7 +85,7 @@ def test_scan_planner_decisions():
     p = _lib.scan_plan(1_000_000, 1_000, 8, 128, 1000)
     assert (p["whole"], p["slices"]) == (0, 4)
     p = _lib.scan_plan(1_000_000, 8, 8, 128, 10)
-    assert p["whole"] == 0 and p["slices"] == 49 and p["rows_per_slice"] == 20480   # >= 16384, whole 4096-row blocks
+    assert p["whole"] == 0 and p["slices"] == 41 and p["rows_per_slice"] == 24576   # >= 16384, whole 8192-row blocks
     p = _lib.scan_plan(1_000_000, 8, 8, 128, 10_000)
     assert p["slices"] == 3 and p["bigk"] == 1           # 32 k rows per slice at least; sample-sort finish
     # m = 16 groups 4 queries; padded widths plan like the next tiled width
