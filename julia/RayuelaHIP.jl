@@ -64,7 +64,7 @@ function quantize_pq(X::Matrix{Float32}, C::Vector{Matrix{Float32}}, V::Bool=fal
   d, n = size(X)
   m    = length(C)
   h    = size(C[1], 2)
-  B    = Matrix{Int16}(undef, m, n)
+  B    = _result(Int16, m, n)
   if V print("Encoding on $m codebooks with librayuela_hip... ") end
   _check(ccall((:rq_encode_pq_i16, librayuela_hip), Cint,
     (Ptr{Int16}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cint, Cint, Cint),
@@ -80,7 +80,7 @@ function quantize_opq(X::Matrix{Float32}, R::Matrix{Float32}, C::Vector{Matrix{F
   d, n = size(X)
   m    = length(C)
   h    = size(C[1], 2)
-  B    = Matrix{Int16}(undef, m, n)
+  B    = _result(Int16, m, n)
   _check(ccall((:rq_encode_opq_i16, librayuela_hip), Cint,
     (Ptr{Int16}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cint, Cint, Cint),
     B, X, R, _cat_codebooks(C), Int64(n), Cint(d), Cint(m), Cint(h)))
@@ -131,7 +131,7 @@ agree in objective, not bit for bit (and are bit-reproducible for a given `seed`
 function train_rvq(X::Matrix{Float32}, m::Integer, h::Integer, niter::Integer=25, V::Bool=false; seed::Integer=0)
   d, n = size(X)
   Ccat = Array{Float32}(undef, d, h, m)            # C view [m][h][d]
-  B    = Matrix{Int16}(undef, m, n)
+  B    = _result(Int16, m, n)
   err  = Ref{Cdouble}(0.0)
   _check(ccall((:rq_train_rvq, librayuela_hip), Cint,
     (Ptr{Cfloat}, Ptr{Int16}, Ref{Cdouble}, Ptr{Cfloat}, Int64, Cint, Cint, Cint, Cint, UInt64),
@@ -245,7 +245,7 @@ k-means per subspace on the device, kmeans++ seeding (`init=:kmpp`, src/PQ.jl:86
 function train_pq(X::Matrix{Float32}, m::Integer, h::Integer, niter::Integer=25, V::Bool=false; seed::Integer=0)
   d, n = size(X)
   Ccat = Vector{Float32}(undef, h * d)
-  B    = Matrix{Int16}(undef, m, n)
+  B    = _result(Int16, m, n)
   err  = Ref{Cdouble}(0.0)
   _check(ccall((:rq_train_pq, librayuela_hip), Cint,
     (Ptr{Cfloat}, Ptr{Int16}, Ref{Cdouble}, Ptr{Cfloat}, Int64, Cint, Cint, Cint, Cint, UInt64),
@@ -260,7 +260,7 @@ function train_opq(X::Matrix{Float32}, m::Integer, h::Integer, niter::Integer, i
   d, n = size(X)
   init in ("natural", "random") || error("Intialization $init unknown")   # src/OPQ.jl:74
   Ccat = Vector{Float32}(undef, h * d)
-  B    = Matrix{Int16}(undef, m, n)
+  B    = _result(Int16, m, n)
   R    = Matrix{Float32}(undef, d, d)
   obj  = zeros(Float32, niter + 1)
   _check(ccall((:rq_train_opq, librayuela_hip), Cint,

@@ -19,7 +19,7 @@ def quantize_opq(X, R, C, V=False):
     m = len(C)
     h = np.asarray(C[0]).shape[0]
     Cc = cat_codebooks(C)
-    B = np.empty((n, m), dtype=np.int16)
+    B = _lib.result_empty((n, m), np.int16)
     _lib.check(_lib.lib().rq_encode_opq_i16(B.ctypes.data, X.ctypes.data, R.ctypes.data, Cc.ctypes.data,
                                             n, d, m, h))
     return B

@@ -21,7 +21,7 @@ def quantize_pq(X, C, V=False):
         raise ValueError("codebooks do not tile the %d dimensions of X" % d)
     if V:
         print("Encoding on %d codebooks with librayuela_hip... " % m, end="")
-    B = np.empty((n, m), dtype=np.int16)
+    B = _lib.result_empty((n, m), np.int16)
     _lib.check(_lib.lib().rq_encode_pq_i16(B.ctypes.data, X.ctypes.data, Cc.ctypes.data, n, d, m, h))
     if V:
         print("done")
@@ -36,7 +36,7 @@ def quantize_pq_u8(X, C):
     m = len(C)
     h = np.asarray(C[0]).shape[0]
     Cc = cat_codebooks(C)
-    B = np.empty((n, m), dtype=np.uint8)
+    B = _lib.result_empty((n, m), np.uint8)
     _lib.check(_lib.lib().rq_encode_pq(B.ctypes.data, X.ctypes.data, Cc.ctypes.data, n, d, m, h))
     return B
 
