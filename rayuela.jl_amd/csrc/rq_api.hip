@@ -226,7 +226,7 @@ void *host_pool_alloc(size_t bytes) {
     g_hp.idle_bytes -= b.bytes;
     g_hp.idle.erase(g_hp.idle.begin() + best);
   } else {
-    if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostMalloc(&b.p, want, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     b.bytes = want;
   }
   g_hp.live.push_back(b);
@@ -253,6 +253,14 @@ void host_pool_free(void *p) {
     }
   }
   (void)hipHostFree(b.p);
+}
+
+// true when [p, p + bytes) lies inside a buffer rq_host_alloc handed out (page-locked and mapped: the device can write it)
+bool host_pool_owns(const void *p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto &b : g_hp.live)
+    if ((const char *)p >= (const char *)b.p && (const char *)p + bytes <= (const char *)b.p + b.bytes) return true;
+  return false;
 }
 
 void host_pool_trim() {
@@ -384,6 +392,15 @@ static int scan_and_fetch(float *dists, uint32_t *ids, float *dd, uint32_t *di, 
   const int64_t hc = std::max(256, tuning("HOST_CHUNK", 4096));
   const int64_t chunk = (nq >= 2 * hc && tuning("HOST_OVERLAP", 1)) ? hc : nq;
   const size_t row = (size_t)k * 4;
+  if (!dd) {
+    // the caller's result arrays are page-locked buffers of the library (rq_host_alloc): the scan writes its answer
+    // straight into them over PCIe -- one launch over all queries, no copy back
+    Timer t2;
+    RQ_TRY(scan(0, nq, nullptr));
+    RQ_HIP(hipDeviceSynchronize());
+    g_t_kernel = t2.ms();
+    return RQ_OK;
+  }
   if (chunk >= nq) {
     Timer t2;
     RQ_TRY(scan(0, nq, nullptr));
@@ -459,7 +476,8 @@ static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const
   DevBuf dcodes, dcent, dq, dr, drq, dd, di_;
   const size_t cb = (size_t)n * m, ce = (size_t)m * 256 * (d / m) * 4, qb = (size_t)nq * d * 4;
   RQ_TRY(dcodes.alloc(cb)); RQ_TRY(dcent.alloc(ce)); RQ_TRY(dq.alloc(qb));
-  RQ_TRY(dd.alloc((size_t)nq * k * 4)); RQ_TRY(di_.alloc((size_t)nq * k * 4));
+  const bool direct = tuning("HOST_DIRECT", 1) && host_pool_owns(dists, (size_t)nq * k * 4) && host_pool_owns(ids, (size_t)nq * k * 4);
+  if (!direct) { RQ_TRY(dd.alloc((size_t)nq * k * 4)); RQ_TRY(di_.alloc((size_t)nq * k * 4)); }
   Timer t1;
   RQ_HIP(hipMemcpy(dcodes.p, codes, cb, hipMemcpyHostToDevice));
   RQ_HIP(hipMemcpy(dcent.p, centers, ce, hipMemcpyHostToDevice));
@@ -474,11 +492,11 @@ static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const
     RQ_TRY(rotate_launch(drq.as<float>(), dr.as<float>(), dq.as<float>(), d, nq, di.num_cu, nullptr));
     qdev = drq.as<float>();
   }
-  float *ddp = dd.as<float>();
-  uint32_t *dip = di_.as<uint32_t>();
+  float *ddp = direct ? dists : dd.as<float>();       // direct: the kernel's own stores land in the caller's arrays
+  uint32_t *dip = direct ? ids : di_.as<uint32_t>();
   const uint8_t *cdev = dcodes.as<uint8_t>();
   const float *cen = dcent.as<float>();
-  RQ_TRY(scan_and_fetch(dists, ids, ddp, dip, nq, k, [&](int64_t q0, int64_t nqc, hipStream_t stream) {
+  RQ_TRY(scan_and_fetch(dists, ids, direct ? nullptr : ddp, dip, nq, k, [&](int64_t q0, int64_t nqc, hipStream_t stream) {
     return dev_linscan(ddp + (size_t)q0 * k, dip + (size_t)q0 * k, nullptr, cdev, cen, qdev + (size_t)q0 * d, n, nqc, m,
                        d, k, 0, id_base, stream);
   }));
@@ -503,7 +521,8 @@ static int host_linscan_aq(float *dists, uint32_t *ids, const uint8_t *codes, co
   DevBuf dcodes, dcb, dq, dn, dr, drq, dd, di_;
   const size_t cb = (size_t)n * m, ce = (size_t)m * 256 * d * 4, qb = (size_t)nq * d * 4;
   RQ_TRY(dcodes.alloc(cb)); RQ_TRY(dcb.alloc(ce)); RQ_TRY(dq.alloc(qb));
-  RQ_TRY(dd.alloc((size_t)nq * k * 4)); RQ_TRY(di_.alloc((size_t)nq * k * 4));
+  const bool direct = tuning("HOST_DIRECT", 1) && host_pool_owns(dists, (size_t)nq * k * 4) && host_pool_owns(ids, (size_t)nq * k * 4);
+  if (!direct) { RQ_TRY(dd.alloc((size_t)nq * k * 4)); RQ_TRY(di_.alloc((size_t)nq * k * 4)); }
   Timer t1;
   RQ_HIP(hipMemcpy(dcodes.p, codes, cb, hipMemcpyHostToDevice));
   RQ_HIP(hipMemcpy(dcb.p, codebooks, ce, hipMemcpyHostToDevice));
@@ -522,12 +541,12 @@ static int host_linscan_aq(float *dists, uint32_t *ids, const uint8_t *codes, co
     RQ_TRY(rotate_launch(drq.as<float>(), dr.as<float>(), dq.as<float>(), d, nq, di.num_cu, nullptr));
     qdev = drq.as<float>();
   }
-  float *ddp = dd.as<float>();
-  uint32_t *dip = di_.as<uint32_t>();
+  float *ddp = direct ? dists : dd.as<float>();
+  uint32_t *dip = direct ? ids : di_.as<uint32_t>();
   const uint8_t *cdev = dcodes.as<uint8_t>();
   const float *cbk = dcb.as<float>();
   const float *nrm = dbnorms ? dn.as<float>() : nullptr;
-  RQ_TRY(scan_and_fetch(dists, ids, ddp, dip, nq, k, [&](int64_t q0, int64_t nqc, hipStream_t stream) {
+  RQ_TRY(scan_and_fetch(dists, ids, direct ? nullptr : ddp, dip, nq, k, [&](int64_t q0, int64_t nqc, hipStream_t stream) {
     return dev_linscan(ddp + (size_t)q0 * k, dip + (size_t)q0 * k, nullptr, cdev, cbk, qdev + (size_t)q0 * d, n, nqc, m,
                        d, k, 0, id_base, stream, lut_mode, nrm);
   }));
