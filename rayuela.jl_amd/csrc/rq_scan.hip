@@ -61,7 +61,13 @@ template <> struct LutVec<2> {
 };
 
 #ifndef RQ_SCAN_QG8_MAX_M
-#define RQ_SCAN_QG8_MAX_M 8
+#define RQ_SCAN_QG8_MAX_M 16
+#endif
+#ifndef RQ_MAX_SHARE
+#define RQ_MAX_SHARE 60u
+#endif
+#ifndef RQ_UCH_WIDE_BIAS
+#define RQ_UCH_WIDE_BIAS 4
 #endif
 template <int M>
 struct ScanCfg {
@@ -71,7 +77,10 @@ struct ScanCfg {
   static constexpr int QG = (M <= RQ_SCAN_QG8_MAX_M) ? 8 : (M <= 32) ? 4 : 2;   // queries per group
   static constexpr int NQUAD = QG / QPG;                         // gathers per code byte
   static constexpr int RPT = (32 / (M * NQUAD)) > 0 ? 32 / (M * NQUAD) : 1;   // rows per thread per sub-step
-  static constexpr int SUB = SCAN_THREADS * RPT;    // rows per sub-step (one 16/32-byte load per lane)
+  // threads per workgroup: two 512-thread workgroups per CU, or ONE of 1024 where the tables of 8 queries take more than
+  // half of the LDS (m = 16: 96 KiB of f32 tables + 32 KiB of byte tables) -- same 16 wavefronts per CU either way
+  static constexpr int THREADS = (M == 16 && QG == 8) ? 1024 : SCAN_THREADS;
+  static constexpr int SUB = THREADS * RPT;    // rows per sub-step (one 16/32-byte load per lane)
 #ifndef RQ_SCAN_U8
 #define RQ_SCAN_U8 8
 #endif
@@ -105,13 +114,13 @@ struct ScanCfg {
   static constexpr int GTAB_F4 = KG * NQUAD * 256;  // entries (float4 for QPG = 4) of the global (L1) table
   static constexpr int LUT_LDS_BYTES = KL * QG * 1024;
   // integer pre-filter (see build_qtab): one byte per (sub-quantizer, code, query); tiled for M = 8 and 16
-  static constexpr bool HAS_FILT = (M == 8 || M == 16) && SCAN_THREADS == 512;
+  static constexpr bool HAS_FILT = (M == 8 || M == 16) && SCAN_THREADS == 512;     // (the default build)
   // byte accumulator sets: 8 sub-quantizers each; m = 8 in FINE mode: two sets of 4 with 6-bit entries (half the step)
   static constexpr int NACC = HAS_FILT ? (M == 8 ? 2 : M / 8) : 1;
   static constexpr int kpa(bool fine) { return (M == 8 && fine) ? 4 : 8; }   // sub-quantizers per accumulator set
   static constexpr int QTAB_BYTES = HAS_FILT ? M * 256 * QG : 0;
-  // scratch behind the staged queries: the threshold sample's [QG][SCAN_THREADS] minima, later the filter table
-  static constexpr int AUX_BYTES = (QG * SCAN_THREADS * 4 > QTAB_BYTES) ? QG * SCAN_THREADS * 4 : QTAB_BYTES;
+  // scratch behind the staged queries: the threshold sample's [QG][THREADS] minima, later the filter table
+  static constexpr int AUX_BYTES = (QG * THREADS * 4 > QTAB_BYTES) ? QG * THREADS * 4 : QTAB_BYTES;
   static_assert(RPT >= 1, "M too large for this tiling");
 };
 
@@ -184,7 +193,7 @@ __device__ __forceinline__ void build_lut(float *lut, float4 *gtab, const float 
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD;
   const int cdim = mode == 0 ? sub : d;
-  for (int e = tid; e < M * 256; e += SCAN_THREADS) {
+  for (int e = tid; e < M * 256; e += ScanCfg<M>::THREADS) {
     const int k = e >> 8, r = e & 255;
     const float *c = centers + (size_t)e * cdim;
     const int qoff = mode == 0 ? k * sub : 0;
@@ -251,14 +260,26 @@ __device__ __forceinline__ void row_dists(const uint32_t *w, int r, const float4
   const Vec *__restrict__ gtab = reinterpret_cast<const Vec *>(gtab4);
   // issue the L1 gathers of the last sub-quantizers first: their latency hides under the LDS ones
   Vec tg[(Cfg::KG > 0 ? Cfg::KG : 1) * NQUAD];
+  auto load_tg = [&]() {
 #pragma unroll
-  for (int k = KL; k < M; ++k) {
-    const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
+    for (int k = KL; k < M; ++k) {
+      const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
 #pragma unroll
-    for (int quad = 0; quad < NQUAD; ++quad) tg[(k - KL) * NQUAD + quad] = gtab[((k - KL) * NQUAD + quad) * 256 + byte];
-  }
+      for (int quad = 0; quad < NQUAD; ++quad) tg[(k - KL) * NQUAD + quad] = gtab[((k - KL) * NQUAD + quad) * 256 + byte];
+    }
+  };
+  constexpr bool WIDE = M * NQUAD >= 32;     // a row of 32 gathers is summed in two halves (see below)
+  if constexpr (!WIDE) load_tg();
 #pragma unroll
   for (int k = 0; k < M; ++k) {
+    // at most 16 gathers (64 registers of table entries) in flight: a row of 32 (m = 16, 8 queries) is summed in two
+    // halves -- the scheduler otherwise hoists all 32 and spills their results (LSQ variant: 160 spilled registers)
+    if constexpr (WIDE) {
+      if (k * NQUAD == 16) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_tg();                             // the L1 part belongs to the second half (KL >= M / 2)
+      }
+    }
     const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
 #pragma unroll
     for (int quad = 0; quad < NQUAD; ++quad) {
@@ -351,7 +372,7 @@ __device__ __forceinline__ void emit_survivors(const float (&acc)[QG], const flo
 // K = 1000, 25.8 -> 19.9 % at K = 10000; K = 10000 7.38 -> 6.79 ms, K <= 1000 within 1 %; THR 159 / 223 / 255 are level
 // or worse: beyond 191 the clamp bites).  A + B <= THR is tested on the per-byte AVERAGE, which needs no wider
 // fields: floor((A + B) / 2) = (A & B) + (((A ^ B) >> 1) & 0x7f..) <= (THR - 1) / 2 for odd THR.
-// M = 16: two sets of 8 (8 * 31 <= 255), widened to 16-bit fields and compared against THR16.
+// M = 16: two sets of 8 (8 * 31 <= 255), compared against THR16 = 159 through their per-byte average (<= 79).
 constexpr uint32_t FILT_CLAMP = 31;
 constexpr uint32_t filt_thr8(bool fine) { return fine ? 191u : 95u; }
 constexpr uint32_t filt_clamp8(bool fine) { return fine ? 63u : 31u; }
@@ -396,7 +417,7 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
     return kk < KL ? lut4[(kk * NQUAD + quad) * 256 + r] : gtab4[((kk - KL) * NQUAD + quad) * 256 + r];
   };
   // 1. minima of the 256 entries of (k, q): one wavefront per sub-quantizer, lane handles r = lane, lane + 64, ...
-  for (int k = wave; k < M; k += SCAN_THREADS / 64) {
+  for (int k = wave; k < M; k += ScanCfg<M>::THREADS / 64) {
     float mn[QG];
 #pragma unroll
     for (int q = 0; q < QG; ++q) mn[q] = __uint_as_float(0x7f800000u);
@@ -443,7 +464,7 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
   }
   __syncthreads();
   // 2. one byte per (k, r, query): QG bytes per entry
-  for (int e = tid; e < M * 256; e += SCAN_THREADS) {
+  for (int e = tid; e < M * 256; e += ScanCfg<M>::THREADS) {
     const int kk = e >> 8, r = e & 255;
 #pragma unroll
     for (int quad = 0; quad < NQUAD; ++quad) {
@@ -465,7 +486,7 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
 //   M = 8 : a[0], a[1] (and a[2], a[3] for the second set; then s = their per-byte average, T = (THR - 1) / 2) hold 8 byte
 //           sums s <= 252.  ((s | 0x80) - (T+1)) has bit 7 set iff (s & 0x7f) > T, and any s >= 0x80 is > T as well; no
 //           borrow crosses a byte because (s | 0x80) >= T + 1.
-//   M = 16: two sets of 4 byte sums; per query sum = A + B <= 496, widened to 16-bit fields, same trick with bit 15.
+//   M = 16: two sets of 4 byte sums; per query A + B <= THR16  <=>  their per-byte average <= (THR16 - 1) / 2, same trick.
 template <int M, bool FINE>
 __device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC * ScanCfg<M>::NQUAD]) {
   if constexpr (M == 8 && FINE) {
@@ -488,9 +509,11 @@ __device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC 
     const uint32_t g0 = ((v0 | H) - TC) | v0, g1 = ((v1 | H) - TC) | v1;
     return (g0 & g1 & H) != H;
   } else {
-    constexpr uint32_t H = 0x80008000u, F = 0x00ff00ffu, TC = (FILT_THR16 + 1u) * 0x00010001u;
-    const uint32_t lo = (a[0] & F) + (a[1] & F), hi = ((a[0] >> 8) & F) + ((a[1] >> 8) & F);
-    return ((((lo | H) - TC) & ((hi | H) - TC)) & H) != H;
+    // two sets of 4 byte sums, each <= 248: the per-byte average again (no 16-bit widening: 10 instead of 15 VALU)
+    static_assert(FILT_THR16 % 2 == 1 && (FILT_THR16 - 1) / 2 < 128, "average trick");
+    constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR16 - 1u) / 2u + 1u) * 0x01010101u;
+    const uint32_t v = (a[0] & a[1]) + (((a[0] ^ a[1]) >> 1) & 0x7f7f7f7fu);
+    return ((((v | H) - TC) | v) & H) != H;
   }
 }
 
@@ -554,11 +577,9 @@ __device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<
     const uint32_t g0 = ((v0 | H) - TC) | v0, g1 = ((v1 | H) - TC) | v1;
     return (high_bits4(~g0) | (high_bits4(~g1) << 4));
   } else {
-    // 16-bit fields: lo = queries 0 (bits 0-15) and 2 (16-31), hi = queries 1 and 3; bit 15 of (x | H) - TC set = dead
-    constexpr uint32_t H = 0x80008000u, F = 0x00ff00ffu, TC = (FILT_THR16 + 1u) * 0x00010001u;
-    const uint32_t lo = (a[0] & F) + (a[1] & F), hi = ((a[0] >> 8) & F) + ((a[1] >> 8) & F);
-    const uint32_t fl = ~((lo | H) - TC), fh = ~((hi | H) - TC);
-    return ((fl >> 15) & 1u) | (((fh >> 15) & 1u) << 1) | (((fl >> 31) & 1u) << 2) | (((fh >> 31) & 1u) << 3);
+    constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR16 - 1u) / 2u + 1u) * 0x01010101u;
+    const uint32_t v = (a[0] & a[1]) + (((a[0] ^ a[1]) >> 1) & 0x7f7f7f7fu);
+    return high_bits4(~(((v | H) - TC) | v));
   }
 }
 
@@ -641,7 +662,7 @@ template <int M>
 __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg,
                                               const ScanParams &p, bool need, int g, int gi, uint32_t &vseq) {
   constexpr int QG = ScanCfg<M>::QG;
-  constexpr int TPG = SCAN_THREADS / QG;
+  constexpr int TPG = ScanCfg<M>::THREADS / QG;
   const uint32_t cnt = ctrl->cnt[g];
   const uint32_t sel = ctrl->sel[g];
   const uint64_t *src = cand_wg + ((size_t)g * 2 + sel) * p.cap;
@@ -670,7 +691,7 @@ template <int M>
 __device__ __noinline__ uint32_t retune_tau(ScanCtrl<ScanCfg<M>::QG> *ctrl, const uint64_t *cand_wg, uint32_t cap, uint32_t r2,
                                             uint32_t vseq) {
   constexpr int QG = ScanCfg<M>::QG;
-  constexpr int TPG = SCAN_THREADS / QG;
+  constexpr int TPG = ScanCfg<M>::THREADS / QG;
   const int g = threadIdx.x / TPG, gi = threadIdx.x % TPG;
   const uint32_t cnt = ctrl->cnt[g];
   const bool act = cnt > r2 && r2 >= 1;
@@ -705,6 +726,7 @@ __device__ __noinline__ uint32_t retune_tau(ScanCtrl<ScanCfg<M>::QG> *ctrl, cons
 
 // Large-K finish of one work item (out of line: keeps the streaming loop's register allocation
 // independent of it).  cnt/sel: the item's per-query candidate counts and current buffer halves.
+template <int NT>
 __device__ __noinline__ void finish_bigk(const uint32_t *cnt_q, const uint32_t *sel_q, uint32_t QG, uint64_t *cand_wg,
                                          uint16_t *bkt, uint32_t cap, uint32_t K, uint32_t q0, uint32_t nq,
                                          uint64_t *keys_base, uint32_t key_stride, float *dists, uint32_t *ids,
@@ -720,12 +742,12 @@ __device__ __noinline__ void finish_bigk(const uint32_t *cnt_q, const uint32_t *
     const uint32_t n_out = min(K, cnt);
     if (keys_base) {
       uint64_t *o = keys_base + (size_t)qq * key_stride;
-      for (uint32_t i = n_out + tid; i < K; i += SCAN_THREADS) o[i] = KEY_MAX;   // short slice
-      samplesort_topk<SCAN_THREADS>(src, dst, bkt, cnt, n_out, lds, [o](uint32_t r, uint64_t key) { o[r] = key; }, stats);
+      for (uint32_t i = n_out + tid; i < K; i += NT) o[i] = KEY_MAX;   // short slice
+      samplesort_topk<NT>(src, dst, bkt, cnt, n_out, lds, [o](uint32_t r, uint64_t key) { o[r] = key; }, stats);
     } else {
       float *od = dists + (size_t)qq * K;
       uint32_t *oi = ids + (size_t)qq * K;
-      samplesort_topk<SCAN_THREADS>(src, dst, bkt, cnt, n_out, lds, [od, oi, id_base](uint32_t r, uint64_t key) {
+      samplesort_topk<NT>(src, dst, bkt, cnt, n_out, lds, [od, oi, id_base](uint32_t r, uint64_t key) {
         od[r] = key_dist(key);
         oi[r] = key_id(key) + id_base;
       }, stats);
@@ -734,17 +756,17 @@ __device__ __noinline__ void finish_bigk(const uint32_t *cnt_q, const uint32_t *
 }
 
 template <int M, bool BIAS, bool FILT, bool FINE = false>
-__global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p) {
+__global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanParams p) {
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, RPT = Cfg::RPT, BLK = Cfg::BLK;
-  constexpr int TPG = SCAN_THREADS / QG;
+  constexpr int TPG = ScanCfg<M>::THREADS / QG;
   constexpr int CTRL_BYTES = (sizeof(ScanCtrl<QG>) + 15) & ~15;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   ScanCtrl<QG> *ctrl = reinterpret_cast<ScanCtrl<QG> *>(smem);
   // LDS: [ctrl][aux: sample minima, later the byte tables][f32 tables][staged queries].  The byte tables sit
   // right behind ctrl so that their addresses are byte * 8 + a COMPILE-TIME offset below 64 KiB: the hot loop's
   // address is then one SDWA shift and the offset rides in the ds_read instruction.
-  uint32_t *samp = reinterpret_cast<uint32_t *>(smem + CTRL_BYTES);   // [QG][SCAN_THREADS] sample minima / qtab
+  uint32_t *samp = reinterpret_cast<uint32_t *>(smem + CTRL_BYTES);   // [QG][ScanCfg<M>::THREADS] sample minima / qtab
   float *lut = reinterpret_cast<float *>(smem + CTRL_BYTES + Cfg::AUX_BYTES);
   float *qstage = lut + Cfg::LUT_LDS_BYTES / 4;
   uint64_t *scratch = reinterpret_cast<uint64_t *>(smem + CTRL_BYTES);  // aliases lut (dead by then)
@@ -778,7 +800,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     const uint32_t key_stride = sliced ? p.nslices * (uint32_t)p.K : (uint32_t)p.K;
 
     // ---- stage the group's queries, reset the per-query state -------------------------------
-    for (int e = tid; e < QG * p.d; e += SCAN_THREADS) {
+    for (int e = tid; e < QG * p.d; e += ScanCfg<M>::THREADS) {
       const int q = e / p.d, c = e - q * p.d;
       const uint32_t qq = min(q0 + (uint32_t)q, p.nq - 1u);  // ragged last group: repeat a query
       qstage[e] = p.queries[(size_t)qq * p.d + c];
@@ -819,21 +841,21 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     uint32_t srank = 0;
     bool sampled = false;
     const uint32_t Ks = max((uint32_t)p.K, 8u);   // k < 8 aims at the 8th neighbour: same machinery, still exact
-    if (S >= (uint32_t)SCAN_THREADS && rows >= 32u * (uint32_t)SCAN_THREADS && (uint64_t)rows >= 16ull * (uint64_t)Ks) {
+    if (S >= (uint32_t)ScanCfg<M>::THREADS && rows >= 32u * (uint32_t)ScanCfg<M>::THREADS && (uint64_t)rows >= 16ull * (uint64_t)Ks) {
       // The number of thread minima below the true K-th distance is Binomial(512, frac), frac = 1-(1-K/rows)^g.
       // tau = the minimum of rank  mean + z sigma + 2  (z = 3 * srank_mul = 6): fewer than K survivors -- the
       // only cost of a miss is one redone slice -- is a 6-sigma event, and the surplus over K shrinks with K:
       // ~2.5 K survivors at K = 1000 (sigma/mean = 25 %), ~1.5 K at K = 10000 (7 %).
       const float q = (float)Ks / (float)rows;                            // the K-th neighbour's quantile (<= 1/16)
-      uint32_t gsz = S / (uint32_t)SCAN_THREADS;
-      gsz = min(gsz, rows / (8u * (uint32_t)SCAN_THREADS));               // short slice: sample at most 1/8 of it
+      uint32_t gsz = S / (uint32_t)ScanCfg<M>::THREADS;
+      gsz = min(gsz, rows / (8u * (uint32_t)ScanCfg<M>::THREADS));               // short slice: sample at most 1/8 of it
       if (q * (float)gsz > 0.45f) gsz = max(1u, (uint32_t)(0.45f / q));   // keep the rank in the middle of the 512
-      S = gsz * (uint32_t)SCAN_THREADS;
+      S = gsz * (uint32_t)ScanCfg<M>::THREADS;
       const float frac = 1.0f - __expf((float)gsz * __logf(fmaxf(1.0f - q, 1e-6f)));
-      const float mean = frac * (float)SCAN_THREADS;
+      const float mean = frac * (float)ScanCfg<M>::THREADS;
       const float z = 3.0f * (float)p.srank_mul;
       srank = (uint32_t)ceilf(mean + z * sqrtf(mean * (1.0f - frac))) + 2u;
-      sampled = srank * 4u <= 3u * (uint32_t)SCAN_THREADS;
+      sampled = srank * 4u <= 3u * (uint32_t)ScanCfg<M>::THREADS;
     }
 #pragma unroll 1
     for (int attempt = sampled ? 0 : 1; attempt < 2; ++attempt) {
@@ -849,7 +871,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     if (attempt == 1 && sampled) RQ_STAT_INC(7);
     t_ph = RQ_STAT_T();
     if (attempt == 0) {
-      // every thread keeps the minimum of its S/SCAN_THREADS sample rows per query; the `srank`-th
+      // every thread keeps the minimum of its S/ScanCfg<M>::THREADS sample rows per query; the `srank`-th
       // smallest of those minima (an upper bound of the srank-th smallest sample distance, and equal
       // to it unless two of the srank best rows fell to one thread) is selected in LDS
       const uint32_t step = rows / S;
@@ -857,7 +879,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
 #pragma unroll
       for (int q = 0; q < QG; ++q) smin[q] = __uint_as_float(0x7f800000u);
 #pragma unroll 1
-      for (uint32_t i = tid; i < S; i += SCAN_THREADS) {
+      for (uint32_t i = tid; i < S; i += ScanCfg<M>::THREADS) {
         const uint32_t row = r_begin + i * step + ((i * 2654435761u) >> 8) % step;
         uint32_t w1[(M + 3) / 4];
         load_row<M>(w1, p.codes, row);
@@ -872,10 +894,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
         for (int q = 0; q < QG; ++q) smin[q] = fminf(smin[q], acc[q]);
       }
 #pragma unroll
-      for (int q = 0; q < QG; ++q) samp[q * SCAN_THREADS + tid] = f2ord(smin[q] + 0.0f);
+      for (int q = 0; q < QG; ++q) samp[q * ScanCfg<M>::THREADS + tid] = f2ord(smin[q] + 0.0f);
       __syncthreads();
       RQ_STAT_ADD(8, t_ph);
-      const uint32_t tk = radix_select_lds<QG, TPG, uint32_t>(&ctrl->st, samp + g * SCAN_THREADS, SCAN_THREADS,
+      const uint32_t tk = radix_select_lds<QG, TPG, uint32_t>(&ctrl->st, samp + g * ScanCfg<M>::THREADS, ScanCfg<M>::THREADS,
                                                                 srank, true, g, gi);
       if (gi == 0) ctrl->tau[g] = ord2f(tk);
       __syncthreads();
@@ -885,7 +907,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     // (__builtin_amdgcn_groupstaticsize() == 0: the byte tables are addressed absolutely, see the hot loop)
     bool filt_on = FILT && p.filter && attempt == 0 && (uint64_t)rows >= 64ull * (uint64_t)Ks &&
                    __builtin_amdgcn_groupstaticsize() == 0;
-    constexpr uint32_t FILT_QCAP = QG * 256 / (SCAN_THREADS / 64);   // queue entries per wavefront: st.hist split over the waves
+    constexpr uint32_t FILT_QCAP = QG * 256 / (ScanCfg<M>::THREADS / 64);   // queue entries per wavefront: st.hist split over the waves
     static_assert(!FILT || FILT_QCAP >= 128, "a wavefront's queue holds 64 waiting rows + one row-step of pushes");
     const uint32_t *qtab = samp;
     // this wavefront's queue: the offset is wave-uniform, so it lives in an SGPR (a VGPR pointer got spilled to
@@ -958,7 +980,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
         // (e.g. random codes against random codebooks at m = 16) let a large share through; the first block's
         // count decides for the rest of the item, and the exact loop takes over after the queues are drained.
         if (filt_on && base == r_begin + (uint32_t)Cfg::VP * BLK) {
-          constexpr uint32_t MAX_SHARE_PCT = (M == 8) ? 30u : 12u;
+          // (60 % since the exact evaluation is per pair: at Deep1M shape, k = 10000, 29 % of the first block's rows are alive
+          // and the filter still wins -- 10.2 ms against 14.9 with the old 12 / 30 % limits)
+          constexpr uint32_t MAX_SHARE_PCT = RQ_MAX_SHARE;
           if (__builtin_amdgcn_readfirstlane(ctrl->fpush) * 100u > (uint32_t)BLK * MAX_SHARE_PCT) {
             while (qtail) {
               const uint32_t take = min(qtail, 64u);
@@ -974,14 +998,27 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
       for (int q = 0; q < QG; ++q) tau[q] = ctrl->tau[q];
       const uint32_t selmask = __builtin_amdgcn_readfirstlane(ctrl->selmask);
 
+      // (norm-adding kernels with 32 gathers per row: one sub-step at a time -- with all U code words live next to a row's
+      // 64 + 32 registers of table entries the allocator spilled the code words themselves, 160 registers in all)
+      constexpr int UCH = (BIAS && M * Cfg::NQUAD >= 32 && RQ_UCH_WIDE_BIAS < Cfg::U) ? RQ_UCH_WIDE_BIAS : Cfg::U;
+#pragma unroll 1
+      for (int uc = 0; uc < Cfg::U; uc += UCH) {
       // the thread's rows of this block: U sub-steps of RPT rows, each one packed little-endian
       // byte string (byte (r*M + k) of w[u]); all U loads are issued before the first gather
       static_assert((RPT * M) % 16 == 0, "a thread's rows are a whole number of 16-byte loads");
-      uint32_t wu[Cfg::U][RPT * M / 4];
+      uint32_t wu[UCH][RPT * M / 4];
+      // LSQ, rows of 32 gathers: the rows' norms travel with their code words (a load per row inside the gather sequence
+      // made every row wait for all memory traffic in flight: m = 16 43 -> 12.6 ms; at m = 8 the 16 extra registers
+      // spill and the per-row load stays: 7.3 against 22.5 ms)
+      constexpr bool PRE_BIAS = BIAS && M * Cfg::NQUAD >= 32;
+      float bu[PRE_BIAS ? UCH : 1][RPT];
 #pragma unroll
-      for (int u = 0; u < Cfg::U; ++u) {
+      for (int u = 0; u < UCH; ++u) {
         uint32_t *w = wu[u];
-        const uint32_t row0 = base + (uint32_t)u * Cfg::SUB + (uint32_t)tid * RPT;
+        const uint32_t row0 = base + (uint32_t)(uc + u) * Cfg::SUB + (uint32_t)tid * RPT;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+          if constexpr (PRE_BIAS) bu[u][r] = (row0 + r < r_end) ? p.row_bias[row0 + r] : 0.0f;
         if (row0 + RPT <= r_end) {
           const uint4 *src = reinterpret_cast<const uint4 *>(p.codes + (size_t)row0 * M);
 #pragma unroll
@@ -1019,9 +1056,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
         // ---- pre-filter: byte lower bounds for the 8 queries, 8 bytes per gather; rows that may still beat a
         // threshold are queued for the exact evaluation, which runs 64 queued rows at a time
 #pragma unroll
-        for (int u = 0; u < Cfg::U; ++u) {
+        for (int u = 0; u < UCH; ++u) {
           const uint32_t *w = wu[u];
-          const uint32_t row0 = base + (uint32_t)u * Cfg::SUB + (uint32_t)tid * RPT;
+          const uint32_t row0 = base + (uint32_t)(uc + u) * Cfg::SUB + (uint32_t)tid * RPT;
           // all RPT * M gathers of the sub-step are issued before the first sum (16 x ds_read_b64 / 32 x ds_read_b32)
           using FV = typename FiltVec<M>::type;
           const FV *qt = reinterpret_cast<const FV *>(qtab);
@@ -1100,23 +1137,29 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
       }
       if (!filtered) {
 #pragma unroll
-      for (int u = 0; u < Cfg::U; ++u) {
+      for (int u = 0; u < UCH; ++u) {
       const uint32_t *w = wu[u];
-      const uint32_t row0 = base + (uint32_t)u * Cfg::SUB + (uint32_t)tid * RPT;
+      const uint32_t row0 = base + (uint32_t)(uc + u) * Cfg::SUB + (uint32_t)tid * RPT;
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         float acc[QG];
         row_dists<M>(w, r, lut4, gtab, acc);
         if (BIAS) {   // deps/src/linscan_aqd_pairwise_byte.cpp:74  pairs[j].first += dbnorms[normidx]
-          const float bias = (row0 + r < r_end) ? p.row_bias[row0 + r] : 0.0f;
+          float bias;
+          if constexpr (PRE_BIAS) bias = bu[u][r];
+          else bias = (row0 + r < r_end) ? p.row_bias[row0 + r] : 0.0f;
 #pragma unroll
           for (int q = 0; q < QG; ++q) acc[q] = acc[q] + bias;
         }
         // ---- survivors: rows whose distance beats the query's threshold ------------------------
         emit_survivors<QG>(acc, tau, row0 + r < r_end, row0 + r + p.id_offset, selmask, ctrl, cand_wg, p.cap, lane);
+        // one row at a time when a row's gathers alone fill half of the register budget (m = 16, 8 queries: 32 x 16 bytes):
+        // interleaving two rows spilled 160 registers in the norm-adding (LSQ) variant
+        if constexpr (M * Cfg::NQUAD >= 32) __builtin_amdgcn_sched_barrier(0);
       }
       }  // sub-steps
       }
+      }  // sub-step chunks
     }
     if (FILT && filt_on) {
       while (qtail) {          // slice end: the rest of the queue
@@ -1152,7 +1195,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     t_ph = RQ_STAT_T();
     if (p.bigk) {
       // large K: select + sort in one sample-sort pass per query, keys stay in global memory
-      finish_bigk(ctrl->cnt, ctrl->sel, QG, cand_wg, p.bkt + (size_t)blockIdx.x * p.cap, p.cap, (uint32_t)p.K,
+      finish_bigk<Cfg::THREADS>(ctrl->cnt, ctrl->sel, QG, cand_wg, p.bkt + (size_t)blockIdx.x * p.cap, p.cap, (uint32_t)p.K,
                   q0, p.nq, keys_base, key_stride, p.dists, p.ids,
                   (uint32_t)p.id_base, smem + CTRL_BYTES, p.stats);
       RQ_STAT_ADD(5, t_ph);
@@ -1163,7 +1206,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void adc_scan_kernel(ScanParams p)
     if (nconc > (uint32_t)QG) nconc = QG;
     // round down to a power of two so the thread split is even
     while (nconc & (nconc - 1)) nconc &= nconc - 1;
-    const uint32_t tps = SCAN_THREADS / nconc;  // threads per concurrent sort
+    const uint32_t tps = ScanCfg<M>::THREADS / nconc;  // threads per concurrent sort
     const uint32_t sg = tid / tps, sgi = tid % tps;
     for (uint32_t qb = 0; qb < (uint32_t)QG; qb += nconc) {
       const uint32_t q = qb + sg;
@@ -1378,7 +1421,7 @@ static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) 
   }
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(SCAN_THREADS), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(Cfg::THREADS), lds, stream, p);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
 }
@@ -1413,7 +1456,7 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   pl.scratch_keys = (uint32_t)keys;
   // workgroups per CU: as many as the LDS request admits (2 x 512 threads when it is <= 80 KiB)
   const size_t lds_req = CTRL_BYTES + std::max<size_t>(base_keys * 8, (size_t)pl.scratch_keys * 8);
-  const int wgs = std::max(1, std::min<int>(SCAN_WGS_PER_CU, (int)(160 * 1024 / lds_req)));
+  const int wgs = std::max(1, std::min<int>(1024 / Cfg::THREADS, (int)(160 * 1024 / lds_req)));
   // Work items = (8-query group, row range), handed out by an atomic counter to the resident workgroups
   // (2 per CU).  Per item there is a fixed cost (LUT, threshold sample, select + sort, and a merge pass for
   // sliced groups), so whole-base items are best whenever they fill the chip:

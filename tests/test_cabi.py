@@ -88,8 +88,11 @@ def test_scan_planner_decisions():
     assert p["whole"] == 0 and p["slices"] == 41 and p["rows_per_slice"] == 24576   # >= 16384, whole 8192-row blocks
     p = _lib.scan_plan(1_000_000, 8, 8, 128, 10_000)
     assert p["slices"] == 3 and p["bigk"] == 1           # 32 k rows per slice at least; sample-sort finish
-    # m = 16 groups 4 queries; padded widths plan like the next tiled width
-    assert _lib.scan_plan(1_000_000, 1_000, 16, 96, 100)["qg"] == 4
+    # m = 16 groups 8 queries too, in ONE 1024-thread workgroup per CU (96 KiB of f32 tables + 32 KiB of byte tables);
+    # m = 32 groups 4; padded widths plan like the next tiled width
+    p = _lib.scan_plan(1_000_000, 10_000, 16, 96, 1000)
+    assert p["qg"] == 8 and p["grid"] == 256 and p["whole"] == 1250
+    assert _lib.scan_plan(1_000_000, 1_000, 32, 128, 100)["qg"] == 4
     assert _lib.scan_plan(1_000_000, 1_000, 12, 96, 100) == _lib.scan_plan(1_000_000, 1_000, 16, 96, 100)
     # SIFT1B shard: 1.25e8 rows, 1024 queries -> 128 groups, 4 slices
     p = _lib.scan_plan(125_000_000, 1024, 8, 128, 100)
