@@ -63,6 +63,12 @@ template <> struct LutVec<2> {
 #ifndef RQ_SCAN_QG8_MAX_M
 #define RQ_SCAN_QG8_MAX_M 16
 #endif
+// (RQ_SCAN_QG16_MAX_M=8: 16 queries per 16-byte gather at m = 8, one 1024-thread workgroup per CU.  Correct -- the GPU
+// suite passes -- and slower: k = 1 2.25 against 2.01 ms, k = 1000 3.28 against 2.46.  A 16-byte entry costs four adds, so
+// the VALU work per (row, query) does not drop, and 16 accumulators + 32 registers of entries spill 115 registers.)
+#ifndef RQ_SCAN_QG16_MAX_M
+#define RQ_SCAN_QG16_MAX_M 0
+#endif
 #ifndef RQ_MAX_SHARE
 #define RQ_MAX_SHARE 60u
 #endif
@@ -74,12 +80,13 @@ struct ScanCfg {
   // queries per LDS gather: a float4 entry (ds_read_b128) up to m = 32; m = 64 only fits the 160 KiB of
   // LDS with float2 entries (ds_read_b64, 2 queries per gather)
   static constexpr int QPG = (M <= 32) ? 4 : 2;
-  static constexpr int QG = (M <= RQ_SCAN_QG8_MAX_M) ? 8 : (M <= 32) ? 4 : 2;   // queries per group
+  static constexpr int QG = (M == 8 && RQ_SCAN_QG16_MAX_M >= 8) ? 16 : (M <= RQ_SCAN_QG8_MAX_M) ? 8 : (M <= 32) ? 4 : 2;   // queries per group
   static constexpr int NQUAD = QG / QPG;                         // gathers per code byte
-  static constexpr int RPT = (32 / (M * NQUAD)) > 0 ? 32 / (M * NQUAD) : 1;   // rows per thread per sub-step
+  // rows per thread per sub-step: ~32 gathers' worth, and a whole number of 16-byte code loads
+  static constexpr int RPT = (32 / (M * NQUAD)) > (M < 16 ? 16 / M : 1) ? 32 / (M * NQUAD) : (M < 16 ? 16 / M : 1);
   // threads per workgroup: two 512-thread workgroups per CU, or ONE of 1024 where the tables of 8 queries take more than
   // half of the LDS (m = 16: 96 KiB of f32 tables + 32 KiB of byte tables) -- same 16 wavefronts per CU either way
-  static constexpr int THREADS = (M == 16 && QG == 8) ? 1024 : SCAN_THREADS;
+  static constexpr int THREADS = (M * QG >= 128) ? 1024 : SCAN_THREADS;
   static constexpr int SUB = THREADS * RPT;    // rows per sub-step (one 16/32-byte load per lane)
 #ifndef RQ_SCAN_U8
 #define RQ_SCAN_U8 8
@@ -106,7 +113,7 @@ struct ScanCfg {
 #ifndef RQ_SCAN_KG8
 #define RQ_SCAN_KG8 2
 #endif
-  static constexpr int KG = (M == 8) ? RQ_SCAN_KG8 : (M == 16) ? 4 : (M == 32) ? 4 : (M == 4) ? 1 : 0;   // M = 64: all in LDS
+  static constexpr int KG = (M == 8) ? (QG == 16 ? 4 : RQ_SCAN_KG8) : (M == 16) ? 4 : (M == 32) ? 4 : (M == 4) ? 1 : 0;   // M = 64: all in LDS
 #else
   static constexpr int KG = 0;
 #endif
@@ -396,13 +403,24 @@ template <> __device__ __forceinline__ uint2 lds_abs_load<uint2>(uint32_t addr) 
   const unsigned long long v = *(lds_u64_t *)(uintptr_t)addr;
   return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
+template <> __device__ __forceinline__ uint4 lds_abs_load<uint4>(uint32_t addr) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef const u32x4 __attribute__((address_space(3))) lds_u128_t;
+  const u32x4 v = *(lds_u128_t *)(uintptr_t)addr;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 template <> __device__ __forceinline__ uint32_t lds_abs_load<uint32_t>(uint32_t addr) {
   typedef const uint32_t __attribute__((address_space(3))) lds_u32_t;
   return *(lds_u32_t *)(uintptr_t)addr;
 }
 
+// dword j of a byte-table entry (4 queries per dword)
+__device__ __forceinline__ uint32_t fv_word(const uint32_t &v, int) { return v; }
+__device__ __forceinline__ uint32_t fv_word(const uint2 &v, int j) { return j == 0 ? v.x : v.y; }
+__device__ __forceinline__ uint32_t fv_word(const uint4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
 template <int M> struct FiltVec;               // table entry: one byte per query of the group
-template <> struct FiltVec<8> { using type = uint2; };      // QG = 8: ds_read_b64
+template <> struct FiltVec<8> { using type = std::conditional<ScanCfg<8>::QG == 16, uint4, uint2>::type; };   // ds_read_b128 / b64
 template <> struct FiltVec<16> { using type = std::conditional<ScanCfg<16>::QG == 8, uint2, uint32_t>::type; };
 
 template <int M, bool FINE>
@@ -489,16 +507,19 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
 //   M = 16: two sets of 4 byte sums; per query A + B <= THR16  <=>  their per-byte average <= (THR16 - 1) / 2, same trick.
 template <int M, bool FINE>
 __device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC * ScanCfg<M>::NQUAD]) {
-  if constexpr (M == 8 && FINE) {
-    constexpr uint32_t H = 0x80808080u, TC = ((filt_thr8(true) - 1u) / 2u + 1u) * 0x01010101u;
-    const uint32_t v0 = (a[0] & a[2]) + (((a[0] ^ a[2]) >> 1) & 0x7f7f7f7fu);
-    const uint32_t v1 = (a[1] & a[3]) + (((a[1] ^ a[3]) >> 1) & 0x7f7f7f7fu);
-    const uint32_t g0 = ((v0 | H) - TC) | v0, g1 = ((v1 | H) - TC) | v1;
-    return (g0 & g1 & H) != H;
-  } else if constexpr (M == 8) {
-    constexpr uint32_t H = 0x80808080u, TC = (filt_thr8(false) + 1u) * 0x01010101u;
-    const uint32_t g0 = ((a[0] | H) - TC) | a[0], g1 = ((a[1] | H) - TC) | a[1];
-    return (g0 & g1 & H) != H;
+  if constexpr (M == 8) {
+    // NQUAD dwords of 4 byte sums per set; FINE: two sets (k < 4, k >= 4), compared through their per-byte average
+    constexpr int NQ = ScanCfg<M>::NQUAD;
+    constexpr uint32_t H = 0x80808080u;
+    constexpr uint32_t TC = (FINE ? (filt_thr8(true) - 1u) / 2u + 1u : filt_thr8(false) + 1u) * 0x01010101u;
+    uint32_t all = H;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      uint32_t v = a[j];
+      if constexpr (FINE) v = (a[j] & a[NQ + j]) + (((a[j] ^ a[NQ + j]) >> 1) & 0x7f7f7f7fu);
+      all &= ((v | H) - TC) | v;
+    }
+    return (all & H) != H;
   } else if constexpr (ScanCfg<M>::NQUAD == 2) {
     // two sets (k < 8, k >= 8) of 8 byte sums, each <= 248: A + B <= THR  <=>  floor((A + B) / 2) <= (THR - 1) / 2 for
     // odd THR, and the per-byte average needs no wider fields: (A & B) + (((A ^ B) >> 1) & 0x7f..)
@@ -560,16 +581,18 @@ __device__ __forceinline__ uint32_t high_bits4(uint32_t x) {   // bits 7, 15, 23
 template <int M, bool FINE>
 __device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<M>::NACC * ScanCfg<M>::NQUAD]) {
   using Cfg = ScanCfg<M>;
-  if constexpr (M == 8 && FINE) {
-    constexpr uint32_t H = 0x80808080u, TC = ((filt_thr8(true) - 1u) / 2u + 1u) * 0x01010101u;
-    const uint32_t v0 = (a[0] & a[2]) + (((a[0] ^ a[2]) >> 1) & 0x7f7f7f7fu);
-    const uint32_t v1 = (a[1] & a[3]) + (((a[1] ^ a[3]) >> 1) & 0x7f7f7f7fu);
-    const uint32_t g0 = ((v0 | H) - TC) | v0, g1 = ((v1 | H) - TC) | v1;
-    return (high_bits4(~g0) | (high_bits4(~g1) << 4));
-  } else if constexpr (M == 8) {
-    constexpr uint32_t H = 0x80808080u, TC = (filt_thr8(false) + 1u) * 0x01010101u;
-    const uint32_t g0 = ((a[0] | H) - TC) | a[0], g1 = ((a[1] | H) - TC) | a[1];
-    return (high_bits4(~g0) | (high_bits4(~g1) << 4));
+  if constexpr (M == 8) {
+    constexpr int NQ = Cfg::NQUAD;
+    constexpr uint32_t H = 0x80808080u;
+    constexpr uint32_t TC = (FINE ? (filt_thr8(true) - 1u) / 2u + 1u : filt_thr8(false) + 1u) * 0x01010101u;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      uint32_t v = a[j];
+      if constexpr (FINE) v = (a[j] & a[NQ + j]) + (((a[j] ^ a[NQ + j]) >> 1) & 0x7f7f7f7fu);
+      bits |= high_bits4(~(((v | H) - TC) | v)) << (4 * j);
+    }
+    return bits;
   } else if constexpr (Cfg::NQUAD == 2) {
     constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR16 - 1u) / 2u + 1u) * 0x01010101u;
     const uint32_t v0 = (a[0] & a[2]) + (((a[0] ^ a[2]) >> 1) & 0x7f7f7f7fu);
@@ -605,13 +628,8 @@ __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64
   for (int k = 0; k < M; ++k) {
     const uint32_t byte = (w1[k >> 2] >> (8 * (k & 3))) & 0xffu;
     const FV e = qt[k * 256 + byte];
-    if constexpr (NQUAD == 2) {
-      const uint2 v = *reinterpret_cast<const uint2 *>(&e);
-      a[(k / Cfg::kpa(FINE)) * 2 + 0] += v.x;
-      a[(k / Cfg::kpa(FINE)) * 2 + 1] += v.y;
-    } else {
-      a[k >> 3] += *reinterpret_cast<const uint32_t *>(&e);
-    }
+#pragma unroll
+    for (int j = 0; j < NQUAD; ++j) a[(k / Cfg::kpa(FINE)) * NQUAD + j] += fv_word(e, j);
   }
   uint32_t alive = valid ? filt_alive_bits<M, FINE>(a) : 0u;
   const uint32_t selmask = __builtin_amdgcn_readfirstlane(ctrl->selmask);
@@ -1062,10 +1080,10 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
           // all RPT * M gathers of the sub-step are issued before the first sum (16 x ds_read_b64 / 32 x ds_read_b32)
           using FV = typename FiltVec<M>::type;
           const FV *qt = reinterpret_cast<const FV *>(qtab);
-          const uint32_t shreg = sizeof(FV) == 8 ? 3u : 2u;
+          const uint32_t shreg = sizeof(FV) == 16 ? 4u : sizeof(FV) == 8 ? 3u : 2u;
           // gathers in flight together: 16 (M = 8: both rows of the sub-step; M = 16: one row -- 32 of them with
           // their 32 addresses spill registers in this loop)
-          constexpr int RB = (RPT * M > 16) ? 1 : RPT;      // rows per gather batch
+          constexpr int RB = (RPT * M * (int)sizeof(FV) > 128) ? 1 : RPT;      // rows per gather batch: <= 32 registers of entries
           FV e[RPT][M];
 #pragma unroll
           for (int rb = 0; rb < RPT; rb += RB) {
@@ -1074,7 +1092,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
 #pragma unroll
             for (int k = 0; k < M; ++k) {
               // address = byte * sizeof(FV) (one SDWA shift) + compile-time offset of table k (in the instruction)
-              constexpr int SH = sizeof(FV) == 8 ? 3 : 2;
+              constexpr int SH = sizeof(FV) == 16 ? 4 : sizeof(FV) == 8 ? 3 : 2;
               const uint32_t w32 = w[(r * M + k) >> 2];
               uint32_t boff;
               switch ((r * M + k) & 3) {
@@ -1097,13 +1115,8 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
             for (int i = 0; i < Cfg::NACC * Cfg::NQUAD; ++i) a[i] = 0;
 #pragma unroll
             for (int k = 0; k < M; ++k) {
-              if constexpr (Cfg::NQUAD == 2) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(&e[r][k]);
-                a[(k / Cfg::kpa(FINE)) * 2 + 0] += v.x;
-                a[(k / Cfg::kpa(FINE)) * 2 + 1] += v.y;
-              } else {
-                a[k >> 3] += *reinterpret_cast<const uint32_t *>(&e[r][k]);
-              }
+#pragma unroll
+              for (int j = 0; j < Cfg::NQUAD; ++j) a[(k / Cfg::kpa(FINE)) * Cfg::NQUAD + j] += fv_word(e[r][k], j);
             }
             const bool cand = filt_alive<M, FINE>(a) && (row0 + r < r_end);
             const uint64_t mq = __ballot(cand);
