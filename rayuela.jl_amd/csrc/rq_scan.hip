@@ -84,8 +84,9 @@ struct ScanCfg {
   static constexpr int NQUAD = QG / QPG;                         // gathers per code byte
   // rows per thread per sub-step: ~32 gathers' worth, and a whole number of 16-byte code loads
   static constexpr int RPT = (32 / (M * NQUAD)) > (M < 16 ? 16 / M : 1) ? 32 / (M * NQUAD) : (M < 16 ? 16 / M : 1);
-  // threads per workgroup: two 512-thread workgroups per CU, or ONE of 1024 where the tables of 8 queries take more than
-  // half of the LDS (m = 16: 96 KiB of f32 tables + 32 KiB of byte tables) -- same 16 wavefronts per CU either way
+  // threads per workgroup: two 512-thread workgroups per CU, or ONE of 1024 where a group's tables take more than half of
+  // the LDS (m = 16: 96 KiB of f32 tables + 32 KiB of byte tables; m = 32, 64: 112 KiB of f32 tables) -- the same 16
+  // wavefronts per CU either way (m = 32 exact scan 27.1 -> 24.6 ms against one 512-thread workgroup per CU)
   static constexpr int THREADS = (M * QG >= 128) ? 1024 : SCAN_THREADS;
   static constexpr int SUB = THREADS * RPT;    // rows per sub-step (one 16/32-byte load per lane)
 #ifndef RQ_SCAN_U8
