@@ -370,9 +370,12 @@ int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *code
   const bool both = keys && (dists || ids);      // keys requested together with dists/ids: unpack at the end
   void *part = nullptr;
   if (sliced) RQ_TRY(workspace(WS_KEYS, (size_t)(nq - q_tail) * pl.nslices * k * sizeof(uint64_t), &part, stream));
+  void *normb = nullptr;     // LSQ pre-filter: one byte per row, 32 bytes of min / step, |c|^2 tables, f32 residual norms
+  if (lut_mode == LUT_LSQ && row_bias)
+    RQ_TRY(workspace(WS_NORMB, (((size_t)n + 63) & ~(size_t)63) + 32 + 16 * 256 * 4 + (size_t)n * 4, &normb, stream));
   RQ_TRY(scan_launch(pl, both ? nullptr : dists, both ? nullptr : ids, keys, (uint64_t *)part, codes, centers, queries,
                      n, nq, m, d, k, id_offset, id_base, (uint32_t *)counter, (uint64_t *)cand, stream, lut_mode,
-                     row_bias));
+                     row_bias, (uint8_t *)normb));
   if (sliced) {
     const size_t off = (size_t)q_tail * k;
     RQ_TRY(merge_launch(both || !dists ? nullptr : dists + off, both || !ids ? nullptr : ids + off,

@@ -44,7 +44,7 @@ void *host_pool_alloc(size_t bytes);
 void host_pool_free(void *p);
 void host_pool_trim();
 int aux_streams(hipStream_t *compute, hipStream_t *transfer);
-enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_PAD = 4, WS_MERGE = 5, WS_SLOTS = 6 };
+enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_PAD = 4, WS_MERGE = 5, WS_NORMB = 6, WS_SLOTS = 7 };
 
 // Per-device launch lock (recursive): held while a call looks up scratch, resets the work counter and
 // launches, so two host threads cannot interleave those sequences on one device.
@@ -73,7 +73,7 @@ int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_
 int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, uint64_t *part, const uint8_t *codes,
                 const float *centers, const float *queries, int64_t n, int64_t nq, int m, int d, int K,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
-                hipStream_t stream, int lut_mode = 0, const float *row_bias = nullptr);
+                hipStream_t stream, int lut_mode = 0, const float *row_bias = nullptr, uint8_t *norm_buf = nullptr);
 enum { LUT_PQ = 0, LUT_LSQ = 1, LUT_CQ = 2 };
 // argument checks + planner + launches of one resident shard (rq_dev_linscan's body)
 int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes, const float *centers,

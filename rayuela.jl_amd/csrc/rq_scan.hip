@@ -17,7 +17,7 @@
 //     instead (the LDS pipe is the bound; the vector-memory pipe runs beside it).
 //   * Codes stream from HBM/L2 coalesced, 16 or 32 bytes per lane per sub-step, U sub-steps per
 //     block; every code byte is read once per query GROUP, not per query.
-//   * Top-k: per-query threshold tau.  A row survives the hot loop only if dist < tau; survivors
+//   * Top-k: per-query threshold tau.  A row survives the hot loop only if dist <= tau; survivors
 //     are appended (one LDS atomic per row for all QG queries) to a per-query candidate buffer in
 //     global memory.  tau starts from a sampled estimate (per-thread minima of a stratified
 //     sample, rank selected in LDS); if fewer than k rows beat it the slice is redone from
@@ -126,7 +126,7 @@ struct ScanCfg {
   // byte accumulator sets: 8 sub-quantizers each; m = 8 in FINE mode: two sets of 4 with 6-bit entries (half the step)
   static constexpr int NACC = HAS_FILT ? (M == 8 ? 2 : M / 8) : 1;
   static constexpr int kpa(bool fine) { return (M == 8 && fine) ? 4 : 8; }   // sub-quantizers per accumulator set
-  static constexpr int QTAB_BYTES = HAS_FILT ? M * 256 * QG : 0;
+  static constexpr int QTAB_BYTES = HAS_FILT ? (M + 1) * 256 * QG : 0;   // + 1: the row-norm table of LSQ scans
   // scratch behind the staged queries: the threshold sample's [QG][THREADS] minima, later the filter table
   static constexpr int AUX_BYTES = (QG * THREADS * 4 > QTAB_BYTES) ? QG * THREADS * 4 : QTAB_BYTES;
   static_assert(RPT >= 1, "M too large for this tiling");
@@ -142,6 +142,7 @@ struct ScanCtrl {
   uint32_t pad[2];
   // integer pre-filter (FILT kernels): per-(sub-quantizer, query) table minima and the per-query scale
   float fmin[16][QG];
+  float fmax[16][QG];   // LSQ scans: per-(sub-quantizer, query) max |entry| (absolute rounding margins)
   float finv[QG];
   uint32_t fpush;       // rows the pre-filter let through in the item's first block (it is switched off if too many)
   int32_t base2[QG];    // after a second threshold estimate: (#candidates below the new tau) - (#candidates) at that moment
@@ -157,6 +158,9 @@ struct ScanParams {
   int m_real;               // sub-quantizers that exist; tables k >= m_real are all-zero padding
   int lut_mode;             // 0 PQ sub-space (c-q)^2 | 1 LSQ -2<q,c> full-dim | 2 CQ (q-c)^2 full-dim
   const float *row_bias;    // LSQ: dbnorms[n], added after the table sum; else nullptr
+  const uint8_t *norm_bytes;  // LSQ pre-filter: row norms quantised to 256 lower edges, [n]
+  const float *norm_info;     // ... {nmin, nstep, max |.|} of the quantised quantity: norm[row] - sum_k |c_k[b_k]|^2
+  const float *cnorm;         // ... |c_k[r]|^2, [M][256]: folded into the filter's tables (see build_qtab)
   uint32_t id_offset;
   int id_base;
   uint32_t nslices, rows_per_slice, ngroups;
@@ -318,7 +322,9 @@ __device__ __forceinline__ void load_row(uint32_t *w, const uint8_t *codes, uint
 
 // ------------------------------------------------------------------------------------------
 // Survivors of one wave-row-step: lane `lane` holds the exact distances acc[q] of ONE row (key id `kid`) to the
-// QG queries; rows with acc[q] < tau[q] are appended to query q's candidate buffer.  ONE LDS atomic for all QG
+// QG queries; rows with acc[q] <= tau[q] are appended to query q's candidate buffer (INCLUSIVE: tau is a sampled
+// distance, and on heavily duplicated codes hundreds of rows share the K-th neighbour's distance exactly -- with a strict
+// test they all drop out and the slice has to be redone exactly; 3 % of the groups on 1024-cluster data).  ONE LDS atomic for all QG
 // queries: lane q reserves popc(mk[q]) slots of query q.
 // ------------------------------------------------------------------------------------------
 template <int QG>
@@ -329,7 +335,7 @@ __device__ __forceinline__ void emit_survivors(const float (&acc)[QG], const flo
   uint64_t any = 0;
 #pragma unroll
   for (int q = 0; q < QG; ++q) {
-    mk[q] = __ballot(valid && (acc[q] < tau[q]));
+    mk[q] = __ballot(valid && (acc[q] <= tau[q]));
     any |= mk[q];
   }
   if (any) {
@@ -372,7 +378,8 @@ __device__ __forceinline__ void emit_survivors(const float (&acc)[QG], const flo
 // inv_q dominate every rounding of its own computation and of (T - min) * inv (accounting in build_qtab), so the
 // computed entry never exceeds the real (T - min) * THR / range with range >= S - sum_k min_k, the real sum of
 // those is <= THR, and the integer sum of their floors is <= THR.  Clamping only lowers entries.
-// The filter therefore passes a SUPERSET of {d < tau}; the exact evaluation decides, so results do not change.
+// The filter therefore passes a SUPERSET of {d <= tau} (the margins are strict); the exact evaluation decides, so results
+// do not change.
 // ------------------------------------------------------------------------------------------
 // Byte accumulators.  M = 8, FINE kernels (chosen for k >= 8192): TWO sets of 4 sub-quantizers with 6-bit entries (4 * 63 <= 255) and
 // THR8 = 191 -- half the quantisation step of one set of 8 with 5-bit entries and THR 95, same relative clamp (1/3 of
@@ -424,22 +431,48 @@ template <int M> struct FiltVec;               // table entry: one byte per quer
 template <> struct FiltVec<8> { using type = std::conditional<ScanCfg<8>::QG == 16, uint4, uint2>::type; };   // ds_read_b128 / b64
 template <> struct FiltVec<16> { using type = std::conditional<ScanCfg<16>::QG == 8, uint2, uint32_t>::type; };
 
-template <int M, bool FINE>
+// per-entry clamp of the byte tables: (entries per byte sum) * clamp <= 255.  LSQ scans add the row-norm entry to the
+// LAST byte sum: 5 entries of <= 51 at m = 8 (two sets of 4 and 4 + 1), 9 of <= 28 at m = 16 (sets of 8 and 8 + 1)
+template <int M, bool FINE, bool LSQ>
+constexpr uint32_t filt_clamp() { return LSQ ? (M == 8 ? 51u : 28u) : (M == 8 ? filt_clamp8(FINE) : FILT_CLAMP); }
+
+// row norm -> its quantisation cell's LOWER edge, with exactly these two rounded operations (the quantiser checks its
+// choice against the same expression, so EDGE(byte of a row) <= the row's norm holds in exact arithmetic)
+__device__ __forceinline__ float norm_edge(float nmin, float nstep, uint32_t b) {
+  const float t = (float)b * nstep;
+  return nmin + t;
+}
+
+template <int M, bool FINE, bool LSQ = false>
 __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const float4 *lut4, const float4 *gtab4,
-                                           uint32_t *qtab, int tid) {
+                                           uint32_t *qtab, int tid, const float *norm_info = nullptr,
+                                           const float *cnorm = nullptr) {
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD, KL = Cfg::KL;
   static_assert(Cfg::QPG == 4, "pre-filter tiling: float4 table entries");
   constexpr float THR = (float)(M == 8 ? filt_thr8(FINE) : FILT_THR16);
   const int wave = tid >> 6, lane = tid & 63;
   auto entry = [&](int kk, int quad, int r) -> float4 {
-    return kk < KL ? lut4[(kk * NQUAD + quad) * 256 + r] : gtab4[((kk - KL) * NQUAD + quad) * 256 + r];
+    float4 v = kk < KL ? lut4[(kk * NQUAD + quad) * 256 + r] : gtab4[((kk - KL) * NQUAD + quad) * 256 + r];
+    if constexpr (LSQ) {
+      // LSQ: T = -2 <q, c> and the row adds |x_hat|^2.  Bounding the two separately is useless (the centroid with the
+      // largest <q, c> also has a large norm: 76 % of the rows stayed alive); so the filter works on
+      //   T'_k[r] = T_k[r] + |c_k[r]|^2      and      rho(row) = norm(row) - sum_k |c_k[b_k]|^2   (the cross terms),
+      // whose sum is the same distance in exact arithmetic.  rho is what the row byte quantises.
+      const float cn = cnorm[kk * 256 + r];
+      v.x = v.x + cn; v.y = v.y + cn; v.z = v.z + cn; v.w = v.w + cn;
+    }
+    return v;
   };
   // 1. minima of the 256 entries of (k, q): one wavefront per sub-quantizer, lane handles r = lane, lane + 64, ...
   for (int k = wave; k < M; k += ScanCfg<M>::THREADS / 64) {
-    float mn[QG];
+    float mn[QG], mx[LSQ ? QG : 1];
 #pragma unroll
     for (int q = 0; q < QG; ++q) mn[q] = __uint_as_float(0x7f800000u);
+    if constexpr (LSQ) {
+#pragma unroll
+      for (int q = 0; q < QG; ++q) mx[q] = 0.0f;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -449,19 +482,66 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
         mn[quad * 4 + 1] = fminf(mn[quad * 4 + 1], v.y);
         mn[quad * 4 + 2] = fminf(mn[quad * 4 + 2], v.z);
         mn[quad * 4 + 3] = fminf(mn[quad * 4 + 3], v.w);
+        if constexpr (LSQ) {
+          mx[quad * 4 + 0] = fmaxf(mx[quad * 4 + 0], fabsf(v.x));
+          mx[quad * 4 + 1] = fmaxf(mx[quad * 4 + 1], fabsf(v.y));
+          mx[quad * 4 + 2] = fmaxf(mx[quad * 4 + 2], fabsf(v.z));
+          mx[quad * 4 + 3] = fmaxf(mx[quad * 4 + 3], fabsf(v.w));
+        }
       }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
       for (int q = 0; q < QG; ++q) mn[q] = fminf(mn[q], __shfl_xor(mn[q], off));
+      if constexpr (LSQ) {
+#pragma unroll
+        for (int q = 0; q < QG; ++q) mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], off));
+      }
+    }
+    float mc = 0.0f;      // LSQ: max_r |c_k[r]|^2 -- the ORIGINAL magnitudes are bounded by |T| <= |T'| + |c|^2, |norm| <= |rho| + sum |c|^2
+    if constexpr (LSQ) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mc = fmaxf(mc, cnorm[k * 256 + lane + 64 * i]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mc = fmaxf(mc, __shfl_xor(mc, off));
     }
     if (lane == 0) {
 #pragma unroll
       for (int q = 0; q < QG; ++q) ctrl->fmin[k][q] = mn[q];
+      if constexpr (LSQ) {
+#pragma unroll
+        for (int q = 0; q < QG; ++q) ctrl->fmax[k][q] = mx[q] + 2.0f * mc;
+      }
     }
   }
   __syncthreads();
+  float nmin = 0.0f, nstep = 0.0f;
+  if constexpr (LSQ) { nmin = norm_info[0]; nstep = norm_info[1]; }
+  if constexpr (LSQ) {
+    // LSQ tables are signed (-2 <q, c>) and every row adds its norm.  Shifted by their minima the entries are >= 0 again;
+    // the norm enters as one more table, indexed by the row's norm BYTE, whose entry is the cell's lower edge -- a lower
+    // bound of it.  Rounding is accounted for ABSOLUTELY: with A >= sum_k max|T_k| + max|norm| (original magnitudes,
+    // bounded through the folded ones: fmax = max|T'| + 2 max|c|^2), the sequential f32
+    // distance of a row (M + 1 <= 17 terms) is within 17u A < 2^-19.9 A of the real sum, so is the f32 sum of the minima,
+    // and (tau - base) itself rounds by 2^-24 |tau - base|.  The margin 2^-16 A + 2^-18 |tau - base| covers the three
+    // seven times over; A is a few ranges, so it costs < 1e-3 of a filter step.
+    if (tid < QG) {
+      float base = nmin, A = fabsf(norm_info[2]);
+      for (int kk = 0; kk < M; ++kk) { base = base + ctrl->fmin[kk][tid]; A = A + ctrl->fmax[kk][tid]; }
+      const float tau = ctrl->tau[tid];
+      const float gap = tau - base;
+      const float range = gap + (A * 1.52587890625e-5f + fabsf(gap) * 3.814697265625e-6f);
+      float inv = 0.0f;     // 0: the filter passes everything for this query
+      if (tau < __uint_as_float(0x7f800000u) && range > 0.0f && A < __uint_as_float(0x7f800000u)) {
+        const float step = range / THR;
+        const float cand = (1.0f / step) * (1.0f - 1.9073486328125e-6f);
+        if (step > 0.0f && cand < __uint_as_float(0x7f800000u)) inv = cand;
+      }
+      ctrl->finv[tid] = inv;
+    }
+  } else
+
   if (tid < QG) {
     float base = 0.0f;
     for (int kk = 0; kk < M; ++kk) base = base + ctrl->fmin[kk][tid];
@@ -494,9 +574,25 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
       for (int c = 0; c < 4; ++c) {
         const float diff = t[c] - ctrl->fmin[kk][quad * 4 + c];
         const float x = diff * ctrl->finv[quad * 4 + c];
-        w |= (uint32_t)fminf(fmaxf(x, 0.0f), (float)(M == 8 ? filt_clamp8(FINE) : FILT_CLAMP)) << (8 * c);   // float -> uint truncates = floor (x >= 0)
+        w |= (uint32_t)fminf(fmaxf(x, 0.0f), (float)filt_clamp<M, FINE, LSQ>()) << (8 * c);   // float -> uint truncates = floor (x >= 0)
       }
       qtab[e * NQUAD + quad] = w;
+    }
+  }
+  if constexpr (LSQ) {
+    // 3. the row-norm table: entry r = the lower edge of cell r above the smallest norm, in the query's steps
+    for (int r = tid; r < 256; r += ScanCfg<M>::THREADS) {
+      const float diff = norm_edge(nmin, nstep, (uint32_t)r) - nmin;
+#pragma unroll
+      for (int quad = 0; quad < NQUAD; ++quad) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float x = diff * ctrl->finv[quad * 4 + c];
+          w |= (uint32_t)fminf(fmaxf(x, 0.0f), (float)filt_clamp<M, FINE, LSQ>()) << (8 * c);
+        }
+        qtab[(M * 256 + r) * NQUAD + quad] = w;
+      }
     }
   }
 }
@@ -610,7 +706,8 @@ __device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<
 template <int M, bool BIAS, bool FINE>
 __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, const uint8_t *codes,
                                           const float *row_bias, uint32_t id_offset, uint32_t cap, const float4 *lut4,
-                                          const float4 *gtab, const uint32_t *qtab, const uint32_t *queue, uint32_t count) {
+                                          const float4 *gtab, const uint32_t *qtab, const uint32_t *queue, uint32_t count,
+                                          const uint8_t *norm_bytes) {
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD, KL = Cfg::KL;
   static_assert(Cfg::QPG == 4, "pair refinement: float4 table entries");
@@ -631,6 +728,11 @@ __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64
     const FV e = qt[k * 256 + byte];
 #pragma unroll
     for (int j = 0; j < NQUAD; ++j) a[(k / Cfg::kpa(FINE)) * NQUAD + j] += fv_word(e, j);
+  }
+  if constexpr (BIAS) {        // LSQ: the row-norm entry belongs to the last byte sum, as in the hot loop
+    const FV e = qt[M * 256 + norm_bytes[row]];
+#pragma unroll
+    for (int j = 0; j < NQUAD; ++j) a[(Cfg::NACC - 1) * NQUAD + j] += fv_word(e, j);
   }
   uint32_t alive = valid ? filt_alive_bits<M, FINE>(a) : 0u;
   const uint32_t selmask = __builtin_amdgcn_readfirstlane(ctrl->selmask);
@@ -656,7 +758,7 @@ __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64
         acc = (k == 0) ? t : acc + t;        // deps/src/linscan_aqd.cpp:85-87, sequential f32
       }
       if (BIAS) acc = acc + bias;
-      if (acc < ctrl->tau[q]) {
+      if (acc <= ctrl->tau[q]) {
         const uint32_t pos = atomicAdd(&ctrl->cnt[q], 1u);
         uint64_t *buf = cand_wg + ((size_t)q * 2 + ((selmask >> q) & 1u)) * cap;
         buf[pos] = make_key(acc, row + id_offset);
@@ -668,13 +770,14 @@ __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64
 template <int M, bool BIAS, bool FILT, bool FINE>
 __device__ __forceinline__ void refine_queue(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, const uint8_t *codes,
                                              const float *row_bias, uint32_t id_offset, uint32_t cap, const float4 *lut4,
-                                             const float4 *gtab, const uint32_t *qtab, const uint32_t *queue, uint32_t count) {
+                                             const float4 *gtab, const uint32_t *qtab, const uint32_t *queue, uint32_t count,
+                                             const uint8_t *norm_bytes) {
   if constexpr (FILT && ScanCfg<M>::HAS_FILT && RQ_REFINE_PAIRS)
-    refine_pairs<M, BIAS, FINE>(ctrl, cand_wg, codes, row_bias, id_offset, cap, lut4, gtab, qtab, queue, count);
+    refine_pairs<M, BIAS, FINE>(ctrl, cand_wg, codes, row_bias, id_offset, cap, lut4, gtab, qtab, queue, count, norm_bytes);
   else
     refine_rows<M, BIAS>(ctrl, cand_wg, codes, row_bias, id_offset, cap, lut4, gtab, queue, count);
 }
-#define RQ_REFINE(c, cw, cd, rb, io, cp, l4, gt, qu, n) refine_queue<M, BIAS, FILT, FINE>(c, cw, cd, rb, io, cp, l4, gt, qtab, qu, n)
+#define RQ_REFINE(c, cw, cd, rb, io, cp, l4, gt, qu, n) refine_queue<M, BIAS, FILT, FINE>(c, cw, cd, rb, io, cp, l4, gt, qtab, qu, n, p.norm_bytes)
 
 // Cut the candidate buffers of the flagged queries back to exactly K keys and refresh tau.
 template <int M>
@@ -721,7 +824,7 @@ __device__ __noinline__ uint32_t retune_tau(ScanCtrl<ScanCfg<M>::QG> *ctrl, cons
   __syncthreads();
   if (act) {
     uint32_t c = 0;
-    for (uint32_t i = gi; i < cnt; i += TPG) c += (uint32_t)(src[i] >> 32) < td ? 1u : 0u;
+    for (uint32_t i = gi; i < cnt; i += TPG) c += (uint32_t)(src[i] >> 32) <= td ? 1u : 0u;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
     if ((gi & 63) == 0) atomicAdd(&ctrl->st.newcnt[g], c);
@@ -935,7 +1038,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
     uint32_t qtail = 0;      // wave-uniform
     if constexpr (FILT) {
       if (filt_on) {
-        build_qtab<M, FINE>(ctrl, lut4, gtab, samp, tid);
+        build_qtab<M, FINE, BIAS>(ctrl, lut4, gtab, samp, tid, p.norm_info, p.cnorm);
         __syncthreads();
       }
     }
@@ -968,7 +1071,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
         vseq = retune_tau<M>(ctrl, cand_wg, p.cap, retune_rank, vseq);
         if constexpr (FILT) {
           if (filt_on) {
-            build_qtab<M, FINE>(ctrl, lut4, gtab, samp, tid);
+            build_qtab<M, FINE, BIAS>(ctrl, lut4, gtab, samp, tid, p.norm_info, p.cnorm);
             __syncthreads();
           }
         }
@@ -1031,13 +1134,25 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
       // spill and the per-row load stays: 7.3 against 22.5 ms)
       constexpr bool PRE_BIAS = BIAS && M * Cfg::NQUAD >= 32;
       float bu[PRE_BIAS ? UCH : 1][RPT];
+      uint32_t nbw[(FILT && BIAS) ? UCH : 1];   // LSQ pre-filter: RPT norm bytes per sub-step (RPT <= 4)
 #pragma unroll
       for (int u = 0; u < UCH; ++u) {
         uint32_t *w = wu[u];
         const uint32_t row0 = base + (uint32_t)(uc + u) * Cfg::SUB + (uint32_t)tid * RPT;
 #pragma unroll
         for (int r = 0; r < RPT; ++r)
-          if constexpr (PRE_BIAS) bu[u][r] = (row0 + r < r_end) ? p.row_bias[row0 + r] : 0.0f;
+          if constexpr (PRE_BIAS) bu[u][r] = (row0 + r < r_end && !(FILT && filt_on)) ? p.row_bias[row0 + r] : 0.0f;
+        if constexpr (FILT && BIAS) {        // the rows' norm bytes: the "codes" of the row-norm table
+          nbw[u] = 0;
+          if (filt_on) {
+            if (RPT == 2 && row0 + 2 <= r_end) nbw[u] = *reinterpret_cast<const uint16_t *>(p.norm_bytes + row0);
+            else {
+#pragma unroll
+              for (int r = 0; r < RPT; ++r)
+                if (row0 + r < r_end) nbw[u] |= (uint32_t)p.norm_bytes[row0 + r] << (8 * r);
+            }
+          }
+        }
         if (row0 + RPT <= r_end) {
           const uint4 *src = reinterpret_cast<const uint4 *>(p.codes + (size_t)row0 * M);
 #pragma unroll
@@ -1086,6 +1201,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
           // their 32 addresses spill registers in this loop)
           constexpr int RB = (RPT * M * (int)sizeof(FV) > 128) ? 1 : RPT;      // rows per gather batch: <= 32 registers of entries
           FV e[RPT][M];
+          FV en[BIAS ? RPT : 1];
 #pragma unroll
           for (int rb = 0; rb < RPT; rb += RB) {
 #pragma unroll
@@ -1107,6 +1223,17 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
               // ds_read offset field and the whole address costs the one SDWA shift above
               e[r][k] = lds_abs_load<FV>(boff + (uint32_t)(CTRL_BYTES + k * 256 * sizeof(FV)));
             }
+            if constexpr (BIAS) {      // the row-norm table, indexed by the row's norm byte
+              constexpr int SHN = sizeof(FV) == 16 ? 4 : sizeof(FV) == 8 ? 3 : 2;
+              uint32_t boff;
+              switch (r & 3) {
+                case 0: boff = byte_shl<0, SHN>(nbw[u], shreg); break;
+                case 1: boff = byte_shl<1, SHN>(nbw[u], shreg); break;
+                case 2: boff = byte_shl<2, SHN>(nbw[u], shreg); break;
+                default: boff = byte_shl<3, SHN>(nbw[u], shreg); break;
+              }
+              en[r] = lds_abs_load<FV>(boff + (uint32_t)(CTRL_BYTES + M * 256 * sizeof(FV)));
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1118,6 +1245,10 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
             for (int k = 0; k < M; ++k) {
 #pragma unroll
               for (int j = 0; j < Cfg::NQUAD; ++j) a[(k / Cfg::kpa(FINE)) * Cfg::NQUAD + j] += fv_word(e[r][k], j);
+            }
+            if constexpr (BIAS) {
+#pragma unroll
+              for (int j = 0; j < Cfg::NQUAD; ++j) a[(Cfg::NACC - 1) * Cfg::NQUAD + j] += fv_word(en[r], j);
             }
             const bool cand = filt_alive<M, FINE>(a) && (row0 + r < r_end);
             const uint64_t mq = __ballot(cand);
@@ -1422,13 +1553,15 @@ static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) 
   void (*kern)(ScanParams) = p.row_bias ? adc_scan_kernel<M, true, false> : adc_scan_kernel<M, false, false>;
   if constexpr (Cfg::HAS_FILT) {
     if (p.filter) kern = adc_scan_kernel<M, false, true>;
+    // LSQ (signed tables + row norms): the two-set byte sums (m = 8: 4 and 4 + 1 entries, m = 16: 8 and 8 + 1)
+    if (p.filter && p.row_bias) kern = adc_scan_kernel<M, true, true, (M == 8)>;
     // m = 8, large k: the finer byte tables (6-bit entries, two sum sets) -- more VALU work per row, fewer rows for
     // the exact evaluation.  Measured at SIFT1M shape, coarse vs fine: k = 1 2.23 / 2.34 ms, k = 100 2.36 / 2.39,
     // k = 1000 2.91 / 2.91, k = 10000 6.62 / 6.26.
     if constexpr (M == 8) {
       int fine_k = tuning("SCAN_FINE_MIN_K", 0);
       if (fine_k <= 0) fine_k = 8192;            // crossover measured between k = 4096 (level) and 10000
-      if (p.filter && p.K >= fine_k) kern = adc_scan_kernel<M, false, true, true>;
+      if (p.filter && !p.row_bias && p.K >= fine_k) kern = adc_scan_kernel<M, false, true, true>;
     }
   } else {
     p.filter = 0;
@@ -1539,10 +1672,71 @@ int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_
   return RQ_OK;
 }
 
+// ---- LSQ pre-filter: the rows' norms as one byte each (the "code" of the row-norm table, see build_qtab) -----------
+// info (uint32 view): [0] ordered(min), [1] ordered(max); (float view) [4] nmin, [5] nstep, [6] max |norm|
+// |c_k[r]|^2 of the full-dimensional codebooks [m * 256][d] (any rounding will do: the residual below uses these values)
+__global__ void cnorm_kernel(const float *__restrict__ cb, int entries, int d, float *cn) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= entries) return;
+  float s = 0.0f;
+  for (int i = 0; i < d; ++i) s = __builtin_fmaf(cb[(size_t)e * d + i], cb[(size_t)e * d + i], s);
+  cn[e] = s;
+}
+
+// rho(row) = norm(row) - sum_k cn[k][b_k], in float64 (exact for f32 inputs up to m = 16) and rounded DOWN to f32
+__global__ void norm_residual_kernel(const float *__restrict__ nrm, const uint8_t *__restrict__ codes, uint32_t n, int mrow,
+                                     int mreal, const float *__restrict__ cn, float *rho) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    double s = (double)nrm[i];
+    for (int k = 0; k < mreal; ++k) s -= (double)cn[k * 256 + codes[(size_t)i * mrow + k]];
+    rho[i] = __double2float_rd(s);
+  }
+}
+
+__global__ void norm_minmax_kernel(const float *__restrict__ nrm, uint32_t n, uint32_t *info) {
+  uint32_t lo = 0xffffffffu, hi = 0u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t o = f2ord(nrm[i] + 0.0f);
+    lo = min(lo, o);
+    hi = max(hi, o);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
+    hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+  }
+  if ((threadIdx.x & 63) == 0) { atomicMin(&info[0], lo); atomicMax(&info[1], hi); }
+}
+
+__global__ void norm_info_kernel(uint32_t *info) {
+  float *f = reinterpret_cast<float *>(info);
+  const float nmin = ord2f(info[0]), nmax = ord2f(info[1]);
+  float nstep = (nmax - nmin) / 255.0f;
+  if (!(nstep > 0.0f) || !(nstep < __uint_as_float(0x7f800000u))) nstep = 0.0f;   // constant norms (or not finite): one cell
+  f[4] = nmin;
+  f[5] = nstep;
+  f[6] = fmaxf(fabsf(nmin), fabsf(nmax));
+}
+
+__global__ void norm_quant_kernel(const float *__restrict__ nrm, uint32_t n, const uint32_t *info, uint8_t *nb) {
+  const float *f = reinterpret_cast<const float *>(info);
+  const float nmin = f[4], nstep = f[5];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float v = nrm[i];
+    uint32_t b = 0;
+    if (nstep > 0.0f) {
+      const float t = (v - nmin) / nstep;
+      b = t >= 255.0f ? 255u : t > 0.0f ? (uint32_t)t : 0u;
+      while (b > 0 && !(norm_edge(nmin, nstep, b) <= v)) --b;     // the cell's lower edge must not exceed the norm
+    }
+    nb[i] = (uint8_t)b;
+  }
+}
+
 int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, uint64_t *part, const uint8_t *codes,
                 const float *centers, const float *queries, int64_t n, int64_t nq, int m, int d, int K,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
-                hipStream_t stream, int lut_mode, const float *row_bias) {
+                hipStream_t stream, int lut_mode, const float *row_bias, uint8_t *norm_buf) {
   ScanParams p;
   p.codes = codes; p.centers = centers; p.queries = queries;
   p.n = (uint32_t)n; p.nq = (uint32_t)nq; p.sub = d / m; p.d = d; p.K = K;
@@ -1564,6 +1758,29 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.bkt = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(cand) + pl.bkt_off);
   p.bigk = pl.bigk ? 1 : 0;
   p.filter = (lut_mode != LUT_LSQ && !row_bias && tuning("SCAN_FILTER", 1)) ? 1 : 0;
+  p.norm_bytes = nullptr; p.norm_info = nullptr; p.cnorm = nullptr;
+  if (lut_mode == LUT_LSQ && row_bias && norm_buf && (m == 8 || m == 16) && tuning("SCAN_FILTER", 1) &&
+      tuning("SCAN_FILTER_LSQ", 1)) {
+    // norm_buf: [n rounded up to 64] row bytes | 8 words of info | |c|^2 [16][256] f32 | rho [n] f32
+    const size_t nb_bytes = ((size_t)n + 63) & ~(size_t)63;
+    uint32_t *info = reinterpret_cast<uint32_t *>(norm_buf + nb_bytes);
+    float *cn = reinterpret_cast<float *>(info + 8);
+    float *rho = cn + 16 * 256;
+    RQ_HIP(hipMemsetAsync(info, 0xff, 4, stream));
+    RQ_HIP(hipMemsetAsync(info + 1, 0, 4, stream));
+    RQ_HIP(hipMemsetAsync(cn, 0, 16 * 256 * 4, stream));       // padding tables (m_real < m): |c|^2 = 0
+    const uint32_t grid = (uint32_t)std::min<int64_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(cnorm_kernel, dim3((p.m_real * 256 + 255) / 256), dim3(256), 0, stream, centers, p.m_real * 256, d, cn);
+    hipLaunchKernelGGL(norm_residual_kernel, dim3(grid), dim3(256), 0, stream, row_bias, codes, (uint32_t)n, m, p.m_real, cn, rho);
+    hipLaunchKernelGGL(norm_minmax_kernel, dim3(grid), dim3(256), 0, stream, (const float *)rho, (uint32_t)n, info);
+    hipLaunchKernelGGL(norm_info_kernel, dim3(1), dim3(1), 0, stream, info);
+    hipLaunchKernelGGL(norm_quant_kernel, dim3(grid), dim3(256), 0, stream, (const float *)rho, (uint32_t)n, info, norm_buf);
+    RQ_HIP(hipGetLastError());
+    p.norm_bytes = norm_buf;
+    p.norm_info = reinterpret_cast<const float *>(info) + 4;
+    p.cnorm = cn;
+    p.filter = 1;
+  }
   p.stats = tuning("SCAN_STATS", 0) ? reinterpret_cast<unsigned long long *>(work_counter + 16) : nullptr;
   p.dists = dists; p.ids = ids; p.keys = keys; p.part = part;
   RQ_HIP(hipMemsetAsync(work_counter, 0, p.stats ? 256 : sizeof(uint32_t), stream));

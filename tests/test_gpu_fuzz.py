@@ -81,6 +81,53 @@ def test_scan_prefilter_on_hostile_tables(rq, oracle, style, m, K):
         assert np.array_equal(i1, i3) and _eq_bits(d1, d3)
 
 
+@pytest.mark.parametrize("style", range(7))
+@pytest.mark.parametrize("m,K", [(8, 10), (8, 1000), (16, 100)])
+def test_lsq_prefilter_on_hostile_tables(rq, oracle, style, m, K):
+    """linscan_lsq at sizes that run the LSQ pre-filter (signed tables -2<q,c>, row norms as a ninth byte table after
+    |c|^2 has been folded into the tables): norms that are the true |x_hat|^2, constant, negative, with a huge spread,
+    unrelated to the codebooks; near-orthogonal and heavily correlated codebooks; a few distinct rows (massive ties).
+    Ids and distance bits must equal the oracle's (which is pinned against the compiled reference on the goldens),
+    with the filter on and off."""
+    import rayuela_jl_amd.synth as synth
+    rng = np.random.default_rng(9000 + 10 * style + m)
+    d, n, nq, h = 24, 200_000, 9, 256
+    cb = rng.standard_normal((m * h, d)).astype(np.float32)
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=100 + style)
+    if style == 1:                       # near-orthogonal codebooks (PQ written as an additive quantizer)
+        sub = d // m if d % m == 0 else 1
+        cb[:] = 0
+        for i in range(m):
+            cb[i * h:(i + 1) * h, (i * sub) % d:(i * sub) % d + sub] = rng.standard_normal((h, sub)).astype(np.float32) * 3
+    elif style == 2:                     # heavily correlated codebooks: large cross terms
+        cb += rng.standard_normal((1, d)).astype(np.float32) * 5
+    elif style == 5:
+        codes = codes[rng.integers(0, 40, n)]
+    xhat = np.zeros((n, d), dtype=np.float64)
+    for i in range(m):
+        xhat += cb[i * h + codes[:, i].astype(np.int64)]
+    norms = (xhat ** 2).sum(1).astype(np.float32)
+    if style == 3:
+        norms[:] = 7.25                  # constant
+    elif style == 4:
+        norms = (rng.standard_normal(n) * 1e4).astype(np.float32)     # signed, unrelated, huge spread
+    elif style == 6:
+        norms = -norms
+    d0, i0 = oracle.linscan_lsq(codes, cb, queries, norms, K)
+    C = [cb[i * h:(i + 1) * h] for i in range(m)]
+    R = np.eye(d, dtype=np.float32)
+    d1, i1 = rq.linscan_lsq(codes, queries, C, norms, R, K)
+    assert np.array_equal(i0.astype(np.int64), i1.astype(np.int64)), (style, m, K)
+    assert _eq_bits(d0, d1), (style, m, K)
+    rq.set_tuning("SCAN_FILTER_LSQ", 0)
+    try:
+        d2, i2 = rq.linscan_lsq(codes, queries, C, norms, R, K)
+    finally:
+        rq.set_tuning("SCAN_FILTER_LSQ", 1)
+    assert np.array_equal(i1, i2) and _eq_bits(d1, d2)
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_encode_fuzz(rq, oracle, seed):
     import rayuela_jl_amd.synth as synth
