@@ -257,6 +257,7 @@ void rq_host_free(void *p);
 /* Diagnostic knob used by tests and tuning runs (same effect as env RQ_<KEY>):
  *   SCAN_SLICES  force the number of row slices per shard (0 = automatic)
  *   ENC_WAVES    wavefronts per encode workgroup (8 or 16)
+ *   SCAN_FILTER / SCAN_FILTER_LSQ  0 switches the integer pre-filter of the PQ/CQ / LSQ scans off (same results)
  *   others (SCAN_SAMPLE, SCAN_SRANK_MUL, SCAN_SLACK, SCAN_SS_MIN_K, SCAN_TAIL_SLICES, SCAN_MIN_ROWS, ENC_DIRECT,
  *   ROT_V2, HOST_OVERLAP, SCAN_STATS) are experiment switches documented where they are read */
 int rq_set_tuning(const char *key, int value);
