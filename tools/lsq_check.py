@@ -32,7 +32,9 @@ Xhat = np.concatenate([C[i][B[:, i]] for i in range(m)], axis=1)
 norms = (Xhat.astype(np.float64) ** 2).sum(1).astype(np.float32)
 Cl = [cb[i * h:(i + 1) * h] for i in range(m)]
 R = np.eye(d, dtype=np.float32)
-d0, i0 = oracle.linscan_lsq(B, cb, Q[:64], norms, K)
+use_ref = oracle.ref_aq_available()      # the compiled reference (deps/src/linscan_aqd_pairwise_byte.cpp) when it travelled along
+d0, i0 = oracle.linscan_lsq(B, cb, Q[:64], norms, K, use_ref=use_ref)
+print("checker: %s" % ("compiled reference" if use_ref else "oracle restatement"))
 for flt in (1, 0):
     rq.set_tuning("SCAN_FILTER_LSQ", flt)
     best = 1e9
@@ -41,7 +43,7 @@ for flt in (1, 0):
         D, I = rq.linscan_lsq(B, Q, Cl, norms, R, K)
         best = min(best, rq.last_timing()["kernel_ms"])
     same = np.array_equal(I[:64].astype(np.int64), i0.astype(np.int64)) and np.array_equal(D[:64].view(np.uint32), d0.view(np.uint32))
-    print("m=%d k=%d filter=%d: kernel %.2f ms, same as the oracle on 64 queries: %s" % (m, K, flt, best, same), flush=True)
+    print("m=%d k=%d filter=%d: kernel %.2f ms, same as the checker on 64 queries: %s" % (m, K, flt, best, same), flush=True)
 rq.set_tuning("SCAN_FILTER_LSQ", 1)
 
 # resident timing + the kernel's own counters
