@@ -128,6 +128,27 @@ def test_lsq_prefilter_on_hostile_tables(rq, oracle, style, m, K):
     assert np.array_equal(i1, i2) and _eq_bits(d1, d2)
 
 
+@pytest.mark.parametrize("m,K", [(7, 100), (12, 50), (5, 10), (3, 10), (16, 1), (8, 1)])
+def test_lsq_prefilter_padded_widths(rq, oracle, m, K):
+    """m that is padded to the next tiled width (7 -> 8, 12 -> 16: the padding tables and their |c|^2 are zero) and widths
+    without a pre-filter (3, 5), at sizes where the filter runs."""
+    import rayuela_jl_amd.synth as synth
+    rng = np.random.default_rng(m)
+    d, n, nq, h = 20, 150_000, 7, 256
+    cb = np.zeros((m * h, d), np.float32)
+    for i in range(m):
+        cb[i * h:(i + 1) * h, (2 * i) % d:(2 * i) % d + 2] = rng.standard_normal((h, 2)).astype(np.float32) * 3
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=m)
+    xh = np.zeros((n, d))
+    for i in range(m):
+        xh += cb[i * h + codes[:, i].astype(np.int64)]
+    norms = (xh ** 2).sum(1).astype(np.float32)
+    d0, i0 = oracle.linscan_lsq(codes, cb, q, norms, K)
+    d1, i1 = rq.linscan_lsq(codes, q, [cb[i * h:(i + 1) * h] for i in range(m)], norms, np.eye(d, dtype=np.float32), K)
+    assert np.array_equal(i0.astype(np.int64), i1.astype(np.int64)) and _eq_bits(d0, d1)
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_encode_fuzz(rq, oracle, seed):
     import rayuela_jl_amd.synth as synth
