@@ -352,6 +352,9 @@ __host__ __device__ inline uint32_t next_pow2(uint32_t v) {
 // Keys equal to KEY_MAX are padding (short slices / shards): they are ignored, and the return
 // value is the number of keys emitted, min(n_out, #real keys) -- the caller pads the rest.
 // ------------------------------------------------------------------------------------------
+#ifndef RQ_SS_UB
+#define RQ_SS_UB 4
+#endif
 constexpr uint32_t SS_NS = 2048;
 constexpr uint32_t SS_LDS_BYTES = SS_NS * 8 + SS_NS * 4 + 128 + SS_NS * 8;
 
@@ -489,7 +492,7 @@ __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_
   // rotating the other chunk around the row -- one global load per 16 keys instead of one per
   // comparison.  nxt[b] is the bucket's end now, nxt[b-1] its start.
   {
-    constexpr uint32_t NR = NT / 16, UB = 4;   // rows per block; buckets a row has in flight
+    constexpr uint32_t NR = NT / 16, UB = RQ_SS_UB;   // rows per block; buckets a row has in flight
     const uint32_t row = tid >> 4, l16 = tid & 15;
     // r += #{rotations 1..15 of `other` around the 16-lane row that are < mine}: a 64-bit compare is
     // the borrow of (other - mine), so each rotation is sub / subb with the rotation folded into the
