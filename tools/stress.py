@@ -28,7 +28,7 @@ fails = 0
 t0 = time.time()
 for r in range(a.rounds):
     rng = np.random.default_rng(a.seed * 100003 + r)
-    kind = r % 4
+    kind = r % 5
     if kind == 3:      # scan shapes that run the integer pre-filter (rows >= 64 k, m in {8, 16}) on hostile tables
         m = int(rng.choice([8, 8, 16]))
         sub = int(rng.choice([1, 2, 6]))
@@ -57,6 +57,46 @@ for r in range(a.rounds):
         d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
         ok = np.array_equal(i0, i1) and np.array_equal(bits(d0), bits(d1))
         desc = "filter-scan m=%d sub=%d n=%d nq=%d K=%d style=%d" % (m, sub, n, nq, K, style)
+    elif kind == 4:      # LSQ / CQ scans at sizes that run their pre-filters, hostile norms and codebooks
+        m = int(rng.choice([8, 8, 16, 7, 12]))
+        d = int(rng.choice([16, 24, 40]))
+        n = int(rng.choice([70000, 200000, 600000]))
+        nq = int(rng.choice([3, 8, 24]))
+        K = int(rng.choice([1, 10, 100, 1000]))
+        style = int(rng.integers(0, 8))
+        h = 256
+        cb = rng.standard_normal((m * h, d)).astype(np.float32)
+        queries = rng.standard_normal((nq, d)).astype(np.float32)
+        codes = synth.random_codes(n, m, seed=r)
+        if style in (1, 7):      # near-orthogonal codebooks
+            w = max(1, d // m)
+            cb[:] = 0
+            for i in range(m):
+                a0 = (i * w) % (d - w + 1)
+                cb[i * h:(i + 1) * h, a0:a0 + w] = rng.standard_normal((h, w)).astype(np.float32) * 3
+        elif style == 2:         # common offset: large cross terms
+            cb += rng.standard_normal((1, d)).astype(np.float32) * 5
+        elif style == 5:
+            codes = codes[rng.integers(0, 40, n)]
+        xh = np.zeros((n, d))
+        for i in range(m):
+            xh += cb[i * h + codes[:, i].astype(np.int64)]
+        norms = (xh ** 2).sum(1).astype(np.float32)
+        if style == 3:
+            norms[:] = float(rng.standard_normal() * 10)
+        elif style == 4:
+            norms = (rng.standard_normal(n) * 1e4).astype(np.float32)
+        elif style == 6:
+            norms = -norms
+        C = [cb[i * h:(i + 1) * h] for i in range(m)]
+        if style == 7:           # CQ: no norms, non-negative full-dimensional tables
+            d0, i0 = oracle.linscan_cq(codes, cb, queries, K)
+            d1, i1 = rq.linscan_cq(codes, queries, C, K)
+        else:
+            d0, i0 = oracle.linscan_lsq(codes, cb, queries, norms, K)
+            d1, i1 = rq.linscan_lsq(codes, queries, C, norms, np.eye(d, dtype=np.float32), K)
+        ok = np.array_equal(i0.astype(np.int64), i1.astype(np.int64)) and np.array_equal(bits(d0), bits(d1))
+        desc = "aq-scan m=%d d=%d n=%d nq=%d K=%d style=%d" % (m, d, n, nq, K, style)
     elif kind == 0:      # scan
         m = int(rng.choice([2, 4, 8, 8, 8, 16, 32, 64, 5, 11]))
         sub = int(rng.choice([1, 2, 4, 8]))
