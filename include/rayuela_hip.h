@@ -222,8 +222,10 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
  *   rq_index_info            out[0] shards, [1] distinct devices, [2] exchange (0 none, 1 peer copies, 2 RCCL),
  *                            [3] rows, [4..] rows per shard (as many as fit in cap)
  * The host-pointer calls rq_linscan_pq / rq_linscan_opq / linscan_aqd_query build such an index for the
- * duration of the call when the environment variable RAYUELA_HIP_DEVICES lists more than one device
- * ("0,1,2,3" or "all"), so the stock Julia signatures use every GPU without a code change. */
+ * call when the environment variable RAYUELA_HIP_DEVICES lists more than one device ("0,1,2,3" or "all"), so the
+ * stock Julia signatures use every GPU without a code change.  That index (RCCL communicator, streams, per-device
+ * buffers) is kept for the next call with the same device list, m and d -- only codebooks and code shards are
+ * uploaded again -- until rq_release_workspaces(). */
 typedef struct rq_index rq_index;
 rq_index *rq_index_create(int m, int d, const float *centers_host);
 rq_index *rq_index_create_sharded(int m, int d, const float *centers_host, const int *devices, int ndev);

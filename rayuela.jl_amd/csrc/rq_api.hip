@@ -716,6 +716,7 @@ int rq_scan_stats(unsigned long long *out8) {
 }
 
 int rq_release_workspaces(void) {
+  rq::sharded_cache_release();
   rq::host_pool_trim();
   return release_workspaces();
 }

@@ -511,16 +511,53 @@ int env_devices(int *out, int cap) {
   return n;
 }
 
-// linscan_pq / linscan_opq on host pointers over several devices: a temporary sharded index
+// linscan_pq / linscan_opq on host pointers over several devices (RAYUELA_HIP_DEVICES).  The sharded index behind these
+// calls is KEPT between calls with the same device list, m and d: building one costs the RCCL communicator
+// (ncclCommInitAll over the clique: hundreds of milliseconds), peer-access setup, streams and events -- a Julia session
+// that calls linscan_pq in a loop would pay that every time.  Per call only the codebooks (128 KiB) and the code shards
+// are uploaded again.  rq_release_workspaces() drops the cached index (its shards stay allocated until then).
+static std::mutex g_shc_mu;
+static rq_index *g_shc_ix = nullptr;
+static std::vector<int> g_shc_devs;
+
+void sharded_cache_release() {
+  std::lock_guard<std::mutex> lk(g_shc_mu);
+  if (g_shc_ix) index_free(g_shc_ix);
+  g_shc_ix = nullptr;
+  g_shc_devs.clear();
+}
+
 int host_linscan_sharded(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers, const float *queries,
                          const float *R, int64_t n, int64_t nq, int m, int d, int k, int id_base, const int *devices,
                          int ndev) {
-  rq_index *ix = new rq_index();
+  std::lock_guard<std::mutex> lk(g_shc_mu);      // host-pointer calls over a device set run one at a time
   SavedDevice saved;
-  int rc = index_build(ix, m, d, centers, devices, ndev);
-  if (rc == RQ_OK) rc = rq_index_set_codes(ix, codes, n, 0);
-  if (rc == RQ_OK) rc = index_search(ix, dists, ids, queries, R, nq, k, id_base);
-  index_free(ix);
+  const std::vector<int> devs(devices, devices + ndev);
+  int rc = RQ_OK;
+  if (g_shc_ix && (g_shc_devs != devs || g_shc_ix->m != m || g_shc_ix->d != d || !tuning("SHARDED_CACHE", 1))) {
+    index_free(g_shc_ix);
+    g_shc_ix = nullptr;
+  }
+  if (!g_shc_ix) {
+    rq_index *ix = new rq_index();
+    rc = index_build(ix, m, d, centers, devices, ndev);
+    if (rc != RQ_OK) { index_free(ix); return rc; }
+    g_shc_ix = ix;
+    g_shc_devs = devs;
+  } else {
+    const size_t ce = (size_t)m * 256 * (d / m) * 4;      // same shape, new codebooks
+    for (auto &dv : g_shc_ix->devs) {
+      RQ_HIP(hipSetDevice(dv.device));
+      RQ_HIP(hipMemcpy(dv.centers, centers, ce, hipMemcpyHostToDevice));
+    }
+  }
+  rc = rq_index_set_codes(g_shc_ix, codes, n, 0);
+  if (rc == RQ_OK) rc = index_search(g_shc_ix, dists, ids, queries, R, nq, k, id_base);
+  if (rc != RQ_OK || !tuning("SHARDED_CACHE", 1)) {       // never keep an index that failed half-way
+    index_free(g_shc_ix);
+    g_shc_ix = nullptr;
+    g_shc_devs.clear();
+  }
   return rc;
 }
 

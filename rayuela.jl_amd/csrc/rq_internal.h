@@ -43,6 +43,7 @@ int release_stream_workspace(hipStream_t stream);
 void *host_pool_alloc(size_t bytes);
 void host_pool_free(void *p);
 void host_pool_trim();
+void sharded_cache_release();
 int aux_streams(hipStream_t *compute, hipStream_t *transfer);
 enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_PAD = 4, WS_MERGE = 5, WS_NORMB = 6, WS_SLOTS = 7 };
 

@@ -103,6 +103,21 @@ def test_env_device_list_shards_the_stock_entry_points(rq, monkeypatch):
         assert np.array_equal(ids, g["ids_K%d" % K]) and _eq_bits(dists, g["dists_K%d" % K])
     dists, idx = rq.linscan_pq(g["codes"], g["queries"], C, 8 * m, 100)
     assert np.array_equal(idx, g["ids_K100"] + 1) and _eq_bits(dists, g["dists_K100"])
+    # the sharded index behind these calls is kept between calls: other codebooks, another base size, another device
+    # list and a release in between must all give the single-device answers
+    from rayuela_jl_amd import _lib
+    C2 = [c * np.float32(0.5) + np.float32(1.0) for c in C]
+    half = g["codes"][: g["codes"].shape[0] // 2]
+    monkeypatch.delenv("RAYUELA_HIP_DEVICES")
+    d_ref, i_ref = rq.linscan_pq(half, g["queries"], C2, 8 * m, 100)
+    for devs in ("0,0,0", "0,0,0", "0,0", "0,0,0,0,0"):
+        monkeypatch.setenv("RAYUELA_HIP_DEVICES", devs)
+        d2, i2 = rq.linscan_pq(half, g["queries"], C2, 8 * m, 100)
+        assert np.array_equal(i2, i_ref) and _eq_bits(d2, d_ref), devs
+        if devs == "0,0":
+            assert _lib.lib().rq_release_workspaces() == 0
+    dists, idx = rq.linscan_pq(g["codes"], g["queries"], C, 8 * m, 100)
+    assert np.array_equal(idx, g["ids_K100"] + 1) and _eq_bits(dists, g["dists_K100"])
 
 
 def test_index_argument_errors(rq):
