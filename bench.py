@@ -27,6 +27,10 @@ Rank 0 prints ONE JSON line (contract in the task description) with two extra ob
                 (the same bytes vs 8 TB/s, and the PMC-measured traffic) is reported next to it
   cpu_baseline  the reference's own deps/src/linscan_aqd.cpp (oracle/_ref, built by oracle/Makefile) timed on
                 this box's host cores on a bounded sample of the same workload
+and, because N = 1 and N > 1 default to DIFFERENT BASELINE configs (2 and 5), the anchors that make a series of
+`--gpus 1, 2, 4, 8` runs comparable: the default N = 1 line carries `scale_anchor_1gpu` (config 5's workload on this one
+GPU: ~0.6 s extra), every N > 1 line carries `same_workload_1gpu` (rank 0 alone on the whole base).  Efficiency over N
+is value(N) / (N x that single-GPU value) -- not value(N) / (N x value(1)).
 """
 import argparse
 import json
@@ -56,7 +60,7 @@ def parse():
     ap.add_argument("--k", type=int, default=0, help="neighbours (default 1000; sift1b: 100)")
     ap.add_argument("--inproc", action="store_true", help="N GPUs from one process via rq_index_create_sharded")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-ref1", action="store_true", help="sift1b, N > 1: skip the same-workload single-GPU timing")
+    ap.add_argument("--no-ref1", action="store_true", help="skip the single-GPU timing of the N > 1 workload (N > 1: same_workload_1gpu; default N = 1 run: scale_anchor_1gpu)")
     ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (PCIe-inclusive) timing")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -429,6 +433,25 @@ def main():
         except Exception as e:   # noqa: BLE001 -- an anchor, not the measurement
             ref1 = {"error": repr(e)[:200]}
 
+    # ---- default N = 1 run: also the N > 1 lines' workload (1e9-row base, 1024 queries, k = 100) on this one GPU, so a
+    # series of `bench.py --gpus 1, 2, 4, 8` runs has its single-GPU anchor in the N = 1 line (the headline `value`
+    # stays BASELINE's SIFT1M-shape metric; efficiency over N is  value(N) / (N * scale_anchor_1gpu.value)) ----------
+    anchor = None
+    if ngpu == 1 and a.workload == "auto" and not a.inproc and not a.no_ref1 and a.n == 0 and a.k == 0 and a.nq == 0 and m == 8:
+        try:
+            nA, nqA, kA = 1_000_000_000, 1024, 100
+            whole = rqd.synth_codes(nA, m, synth.SEED_BASE, row0=0, device=device)
+            qA = Qs[:nqA].contiguous()
+            oA = (torch.empty((nqA, kA), dtype=torch.float32, device=device), torch.empty((nqA, kA), dtype=torch.int32, device=device))
+            t_ms, _ = timed(lambda: rqd.linscan(whole, centers, qA, kA, out=oA), 2, 1, lambda: None)
+            anchor = {"workload": "SIFT1B-shape base (synthetic uint8 codes) m=8 h=256 ADC linscan: what `--gpus N` (N > 1) shards",
+                      "n_base_total": nA, "nq": nqA, "k": kA, "n_gpus": 1, "ms_per_step": round(t_ms / 2, 3),
+                      "value": round(nqA / (t_ms / 2 * 1e-3), 1), "unit": "queries/s"}
+            del whole, oA
+            torch.cuda.empty_cache()
+        except Exception as e:   # noqa: BLE001 -- an anchor, not the measurement
+            anchor = {"error": repr(e)[:200]}
+
     if a.inproc:
         par = "one process, rq_index_create_sharded over %d device(s): exchange=%s" % (ngpu, ix_lib.info()["exchange"] if ix_lib else "?")
     elif world > 1:
@@ -452,6 +475,7 @@ def main():
         "checks": checks,
         "host_path": host,
         "same_workload_1gpu": ref1,
+        "scale_anchor_1gpu": anchor,
         "wall_ms_per_step": round(scan_wall / a.steps, 4),
     }
     print(json.dumps(line))

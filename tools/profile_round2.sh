@@ -17,13 +17,13 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_k10000 -o s -- python $R/bench.py --k 10000 --no-cpu --no-host > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sift1b -o s -- python $R/bench.py --workload sift1b --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python $R/bench.py --no-cpu --no-host --steps 3 > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python $R/bench.py --no-cpu --no-host --no-ref1 --steps 3 > /dev/null 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_deep_$c -o p -- python $R/bench.py --workload deep --no-cpu --no-host --steps 3 > /dev/null 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_sift1b_$c -o p -- python $R/bench.py --workload sift1b --no-cpu --steps 2 --warmup 1 > /dev/null 2>&1
 done
-rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq1 -o p -- python $R/bench.py --no-cpu --no-host --steps 3 > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq2 -o p -- python $R/bench.py --no-cpu --no-host --steps 3 > /dev/null 2>&1
-rocprofv3 --pmc TA_BUSY_avr SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $O/pmc_ta -o p -- python $R/bench.py --no-cpu --no-host --steps 3 > /dev/null 2>&1
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq1 -o p -- python $R/bench.py --no-cpu --no-host --no-ref1 --steps 3 > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq2 -o p -- python $R/bench.py --no-cpu --no-host --no-ref1 --steps 3 > /dev/null 2>&1
+rocprofv3 --pmc TA_BUSY_avr SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $O/pmc_ta -o p -- python $R/bench.py --no-cpu --no-host --no-ref1 --steps 3 > /dev/null 2>&1
 cd $R
 python tools/pmc_csv_summary.py $O > $O/pmc_summary.txt
 cat $O/pmc_summary.txt
