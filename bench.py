@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--nq", type=int, default=0, help="queries per step (default 10000; sift1b: 1024)")
     ap.add_argument("--k", type=int, default=0, help="neighbours (default 1000; sift1b: 100)")
     ap.add_argument("--inproc", action="store_true", help="N GPUs from one process via rq_index_create_sharded")
+    ap.add_argument("--devices", default="", help="--inproc only: explicit device list, e.g. 0,0,0,0 = four LOGICAL shards on "
+                    "device 0 (functional check of the sharded index on a one-GPU box; --gpus is set to its length)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-ref1", action="store_true", help="skip the single-GPU timing of the N > 1 workload (N > 1: same_workload_1gpu; default N = 1 run: scale_anchor_1gpu)")
     ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (PCIe-inclusive) timing")
@@ -147,6 +149,12 @@ def scan_roofline(m, n_local, nq, K, kernel_ms):
 
 def main():
     a = parse()
+    dev_list = [int(x) for x in a.devices.split(",") if x.strip() != ""] if a.devices else None
+    if dev_list:
+        if not a.inproc:
+            sys.stderr.write("bench.py: --devices needs --inproc\n")
+            sys.exit(2)
+        a.gpus = len(dev_list)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and a.gpus > 1 and not a.inproc:
         sys.exit(self_spawn(a))
@@ -161,7 +169,8 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    if torch.cuda.device_count() < (a.gpus if a.inproc else local + 1) and os.environ.get("RQ_BENCH_BACKEND") != "gloo":
+    need = (max(dev_list) + 1 if dev_list else a.gpus) if a.inproc else local + 1
+    if torch.cuda.device_count() < need and os.environ.get("RQ_BENCH_BACKEND") != "gloo":
         sys.stderr.write("bench.py: %d GPUs requested, %d visible\n" % (a.gpus, torch.cuda.device_count()))
         sys.exit(2)
     # RQ_BENCH_BACKEND=gloo: debugging aid for a one-GPU box -- the ranks share the visible GPUs and the
@@ -241,7 +250,7 @@ def main():
     res = {}
     ix_lib = None
     if a.inproc:
-        ix_lib = rq.Index(C, d, devices=list(range(ngpu)))
+        ix_lib = rq.Index(C, d, devices=dev_list or list(range(ngpu)))
         if big:
             ix_lib.set_codes_synth(n, synth.SEED_BASE)
         else:
@@ -263,6 +272,7 @@ def main():
         def scan():
             res["r"] = ix.search(Qs, K)
     scan_ms, scan_wall = timed(scan, a.steps, a.warmup, barrier)
+    ix_info = ix_lib.info() if ix_lib is not None else None
     if os.environ.get("RQ_SCAN_STATS") and rank == 0:      # development aid: the scan kernel's phase / filter counters
         from rayuela_jl_amd import _lib
         sys.stderr.write("scan_stats %s\n" % json.dumps(_lib.scan_stats()))
@@ -453,7 +463,8 @@ def main():
             anchor = {"error": repr(e)[:200]}
 
     if a.inproc:
-        par = "one process, rq_index_create_sharded over %d device(s): exchange=%s" % (ngpu, ix_lib.info()["exchange"] if ix_lib else "?")
+        par = "one process, rq_index_create_sharded over %d shard(s) on device list %s: exchange=%s" % (
+            ngpu, dev_list or list(range(ngpu)), ix_info["exchange"] if ix_info else "?")
     elif world > 1:
         par = "one process per GPU (torch.distributed nccl=RCCL): rows sharded x%d, all_to_all of per-shard top-k keys + merge + gather to rank 0" % world
     else:
@@ -464,6 +475,8 @@ def main():
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "debug_backend": "gloo (ranks share GPUs, collectives on host copies: NOT a measurement)" if debug_gloo and world > 1 else None,
+        "logical_shards": ("device list %s repeats devices: several shards share one GPU -- a functional check, NOT a measurement" % dev_list)
+                          if dev_list and len(set(dev_list)) < len(dev_list) else None,
         "config": {"workload": name + (" ADC linscan + RCCL top-k merge" if big else " encode + ADC linscan"),
                    "n_base_total": n, "n_base_per_gpu": (n + ngpu - 1) // ngpu, "nq": nq, "k": K, "d": d, "m": m, "h": h,
                    "generator": "splitmix64 (rayuela.jl_amd/synth.py; seeds base 1234, codebooks 99, rotation 7)",

@@ -15,6 +15,7 @@
 namespace rq {
 
 static thread_local char g_err[512] = "";
+static thread_local unsigned g_err_seq = 0;     // errors raised on this thread so far (DevBuf: "is my call unwinding?")
 static thread_local double g_t_total = 0, g_t_h2d = 0, g_t_kernel = 0, g_t_d2h = 0;
 
 int fail(int code, const char *fmt, ...) {
@@ -22,6 +23,7 @@ int fail(int code, const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+  ++g_err_seq;
   return code;
 }
 
@@ -32,13 +34,14 @@ void set_timing(double total_ms, double h2d_ms, double kernel_ms, double d2h_ms)
 int fail_hip(hipError_t e, const char *what, const char *file, int line) {
   snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d in `%s`", (int)e, hipGetErrorString(e), file,
            line, what);
+  ++g_err_seq;
   (void)hipGetLastError();
   return (int)e > 0 ? (int)e : 1;
 }
 
 // ---- tuning knobs: env RQ_<KEY>, or rq_set_tuning() ---------------------------------------------
 struct Knob { char key[32]; int value; };
-static Knob g_knobs[16];
+static Knob g_knobs[64];
 static int g_nknobs = 0;
 static std::mutex g_mu;
 
@@ -174,6 +177,7 @@ int release_stream_workspace(hipStream_t stream) {
 int release_workspaces() {
   int dev = 0;
   RQ_HIP(hipGetDevice(&dev));
+  DeviceLock launch_lock;   // no other host thread is between "look up scratch" and "launch" on this device
   RQ_HIP(hipDeviceSynchronize());
   std::lock_guard<std::mutex> lk(g_mu);
   DevCtx &c = g_dev[dev];
@@ -280,8 +284,18 @@ struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
   int dev = -1;
+  unsigned err_seq = 0;   // g_err_seq when the buffer was taken
   ~DevBuf() {
     if (!p) return;
+    // A call that returns normally has synchronised its streams.  One that unwinds early (RQ_TRY / RQ_HIP return with
+    // kernels or async copies still queued on the aux streams) has not: drain the device before the buffer can be
+    // handed to the next call.  Every error path goes through fail() / fail_hip(), which bump the thread's counter.
+    if (err_seq != g_err_seq) {
+      int cur = -1;
+      if (hipGetDevice(&cur) == hipSuccess && dev >= 0 && cur != dev) (void)hipSetDevice(dev);
+      (void)hipDeviceSynchronize();
+      if (cur >= 0 && cur != dev) (void)hipSetDevice(cur);
+    }
     const size_t each = (size_t)std::max(0, tuning("HOST_CACHE_MAX_MB", 256)) << 20;
     const size_t total = (size_t)std::max(0, tuning("HOST_CACHE_MB", 2048)) << 20;
     if (dev >= 0 && dev < 16 && bytes <= each) {
@@ -300,6 +314,7 @@ struct DevBuf {
   }
   int alloc(size_t want) {
     want = ((want ? want : 16) + 255) & ~(size_t)255;
+    err_seq = g_err_seq;
     RQ_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 16) {
       std::lock_guard<std::mutex> lk(g_mu);
@@ -460,6 +475,7 @@ static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const
   if (nq <= 0) return RQ_OK;
   if (n < 1 || m < 1 || d < m || d % m) return fail(RQ_EINVAL, "bad shape n=%lld m=%d d=%d", (long long)n, m, d);
   if (k < 1 || k > n) return fail(RQ_EINVAL, "k=%d must be in [1, n=%lld]", k, (long long)n);
+  SavedDevice saved;      // RAYUELA_HIP_DEVICES may move this call to another device: the caller's device comes back
   {
     // RAYUELA_HIP_DEVICES lists more than one entry: row-shard the base over those devices (rq_index.hip)
     int devs[64];
@@ -471,7 +487,7 @@ static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const
       set_timing(tt.ms(), a, b, c);
       return rc;
     }
-    if (nd == 1) RQ_HIP(hipSetDevice(devs[0]));
+    if (nd == 1) RQ_HIP(hipSetDevice(devs[0]));      // `saved` below puts the caller's device back on every exit path
   }
   DeviceInfo di;
   RQ_TRY(device_info(&di));
@@ -656,6 +672,7 @@ static int host_encode(uint8_t *codes, int16_t *codes1, const float *X, const fl
     g_t_kernel = 0;
     return RQ_OK;
   }
+  SavedDevice saved;
   if (nd == 1) RQ_HIP(hipSetDevice(devs[0]));
   double h2d = 0, tail = 0;
   RQ_TRY(encode_host_rows(codes, codes1, X, R, C, n, d, m, h, &h2d, &tail));
@@ -690,7 +707,7 @@ int rq_set_tuning(const char *key, int value) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (int i = 0; i < g_nknobs; ++i)
     if (!strcmp(g_knobs[i].key, key)) { g_knobs[i].value = value; return RQ_OK; }
-  if (g_nknobs >= 16) return fail(RQ_EINVAL, "too many tuning keys");
+  if (g_nknobs >= 64) return fail(RQ_EINVAL, "too many tuning keys");
   strncpy(g_knobs[g_nknobs].key, key, 31);
   g_knobs[g_nknobs].key[31] = 0;
   g_knobs[g_nknobs++].value = value;

@@ -133,11 +133,6 @@ struct IxShard {
   size_t tmp_cap = 0;
 };
 
-struct SavedDevice {    // the calling thread's current device is restored on every exit path
-  int dev = -1;
-  SavedDevice() { if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; } }
-  ~SavedDevice() { if (dev >= 0) (void)hipSetDevice(dev); }
-};
 
 static int grow(void **p, size_t *cap, size_t bytes) {
   if (*cap >= bytes && *p) return RQ_OK;
@@ -303,7 +298,8 @@ template <class Fill>
 static int index_set(rq_index *ix, int64_t n, uint32_t id_offset, Fill fill) {
   if (!ix) return fail(RQ_EINVAL, "index is NULL");
   if (n < 1) return fail(RQ_EINVAL, "index: n=%lld must be >= 1", (long long)n);
-  if ((uint64_t)id_offset + (uint64_t)n > 0x100000000ull) return fail(RQ_EINVAL, "index: row ids overflow uint32");
+  // same bound as dev_linscan: the last id must stay below 0xFFFFFFFF (that id is the padding key KEY_MAX's)
+  if ((uint64_t)id_offset + (uint64_t)n > 0xFFFFFFFFull) return fail(RQ_EINVAL, "index: row ids overflow uint32 (id_offset + n must be <= 2^32 - 1)");
   std::lock_guard<std::mutex> lk(ix->mu);
   SavedDevice saved;
   shard_bounds(ix, n);

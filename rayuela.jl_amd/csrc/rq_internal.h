@@ -59,6 +59,15 @@ class DeviceLock {
   void *mu_;
 };
 
+// The calling thread's current device, restored on every exit path of a call that switches devices.
+struct SavedDevice {
+  int dev = -1;
+  SavedDevice() { if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; } }
+  ~SavedDevice() { if (dev >= 0) (void)hipSetDevice(dev); }
+  SavedDevice(const SavedDevice &) = delete;
+  SavedDevice &operator=(const SavedDevice &) = delete;
+};
+
 // Milliseconds reported by rq_last_timing() for the calling thread.
 void set_timing(double total_ms, double h2d_ms, double kernel_ms, double d2h_ms);
 

@@ -17,13 +17,17 @@
 //     instead (the LDS pipe is the bound; the vector-memory pipe runs beside it).
 //   * Codes stream from HBM/L2 coalesced, 16 or 32 bytes per lane per sub-step, U sub-steps per
 //     block; every code byte is read once per query GROUP, not per query.
-//   * Top-k: per-query threshold tau.  A row survives the hot loop only if dist <= tau; survivors
+//   * Top-k: per-query threshold tau.  A row survives the hot loop only if dist <= tau (INCLUSIVE); survivors
 //     are appended (one LDS atomic per row for all QG queries) to a per-query candidate buffer in
 //     global memory.  tau starts from a sampled estimate (per-thread minima of a stratified
-//     sample, rank selected in LDS); if fewer than k rows beat it the slice is redone from
-//     tau = +inf, which cuts the buffer back to exactly k keys by an 8-pass radix select whenever
-//     it could overflow.  Strict '<' is exact because row ids only grow from block to block: a
-//     later row that ties tau's distance has a larger id, i.e. a larger key.
+//     sample, rank selected in LDS) and is tightened once after 1/8 of the slice (retune_tau); if fewer
+//     than k rows beat it the slice is redone from tau = +inf, which cuts the buffer back to exactly k keys
+//     by an 8-pass radix select whenever it could overflow.  The inclusive test is exact: a cut keeps the k
+//     smallest (dist, id) KEYS and sets tau to the k-th key's distance, so every later row that could still
+//     enter the top-k has dist <= tau and is appended (rows that tie tau's distance with a larger id are
+//     appended too and lose to the k-th key at the next cut or in the final select -- at most one key per
+//     row per query, which the capacity accounting already assumes).  With a strict '<' a whole tie group
+//     at a SAMPLED tau would drop out and force the exact redo (emit_survivors).
 //   * At the end of a slice the k survivors are bitonic-sorted in LDS (the LUT is dead by then
 //     and its space is reused) and written either as final (dist,id) or as packed keys for
 //     the slice/GPU merge kernel.
@@ -139,7 +143,8 @@ struct ScanCtrl {
   uint32_t sel[QG];     // which half of the candidate ping-pong buffer is current
   uint32_t item;
   uint32_t selmask;     // bit q == sel[q] (one LDS word the hot loop reads per block)
-  uint32_t pad[2];
+  uint32_t inexact;     // a capacity cut ran while fewer than K candidates beat a tightened tau: the slice is redone exactly
+  uint32_t pad;
   // integer pre-filter (FILT kernels): per-(sub-quantizer, query) table minima and the per-query scale
   float fmin[16][QG];
   float fmax[16][QG];   // LSQ scans: per-(sub-quantizer, query) max |entry| (absolute rounding margins)
@@ -793,6 +798,11 @@ __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, ui
   const uint64_t tau_key = ctrl->st.prefix[g];
   compact_leq<QG, TPG>(&ctrl->st, src, dst, cnt, tau_key, need, g, gi);
   if (need && gi == 0) {
+    // After a second threshold estimate (retune_tau) rows above the tightened tau are no longer appended.  If fewer than K
+    // of the buffered candidates beat it, the K-th key kept here lies ABOVE it, and rows in between that were scanned
+    // since the estimate are already gone: this cut cannot restore exactness.  The item is flagged and redone from
+    // tau = +inf at the end-of-slice vote (tests/test_gpu_scan.py::test_capacity_cut_after_second_estimate).
+    if ((int32_t)cnt + ctrl->base2[g] < (int32_t)p.K) ctrl->inexact = 1u;
     ctrl->cnt[g] = ctrl->st.newcnt[g];  // == K (keys are unique)
     ctrl->base2[g] = 0;                 // the K kept keys are the K smallest so far: exact again
     ctrl->sel[g] = sel ^ 1u;
@@ -987,7 +997,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
       ctrl->cnt[tid] = 0;
       ctrl->sel[tid] = 0;
       ctrl->base2[tid] = 0;
-      if (tid == 0) { ctrl->selmask = 0; ctrl->fpush = 0; }
+      if (tid == 0) { ctrl->selmask = 0; ctrl->fpush = 0; ctrl->inexact = 0; }
     }
     __syncthreads();
     if (attempt == 1 && sampled) RQ_STAT_INC(7);
@@ -1327,7 +1337,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
     if (attempt == 0) {
       // the sampled tau must have let at least min(K, rows) rows through for EVERY query
       // (after a second estimate only the candidates below the tightened tau count: cnt + base2)
-      const bool shortfall = (int32_t)ctrl->cnt[g] + ctrl->base2[g] < (int32_t)min((uint32_t)p.K, rows);
+      const bool shortfall = (int32_t)ctrl->cnt[g] + ctrl->base2[g] < (int32_t)min((uint32_t)p.K, rows) || ctrl->inexact != 0u;
       if (block_any(shortfall, ctrl->st.vote, vseq)) continue;  // exact fallback: redo the slice from tau = +inf
     }
     if (!p.bigk) {

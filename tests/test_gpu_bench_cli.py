@@ -1,0 +1,80 @@
+"""bench.py at N > 1, run the way the driver runs it (Next #1a).
+
+The 8-GPU scaling run is the driver's; nothing here can measure it.  What these tests pin is that the literal command
+path -- `python bench.py --gpus N ...` self-launching N ranks through torch.distributed.run, the sharded search, the
+exchange + merge, rank 0's JSON line -- works end to end and returns the single-GPU answer.  On the one-GPU test box the
+ranks share the device and the collectives run on host copies (RQ_BENCH_BACKEND=gloo, a debugging switch of bench.py);
+`--inproc --devices 0,0,0,0` drives the in-library multi-device index (what a Julia session uses) with four logical
+shards, through the RCCL send/recv gather when librccl loads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None, timeout=600):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, timeout=timeout,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def _common(line, n_gpus, rows, nq, k):
+    assert line["n_gpus"] == n_gpus and line["steps"] == 2 and line["warmup"] == 1
+    assert line["unit"] == "queries/s" and line["higher_is_better"] is True and line["scaling"] == "strong"
+    assert line["value"] > 0 and line["ms_per_step"] > 0
+    cfg = line["config"]
+    assert cfg["n_base_total"] == rows and cfg["nq"] == nq and cfg["k"] == k and cfg["m"] == 8
+    assert "SIFT1B-shape" in cfg["workload"]
+    chk = line["checks"]
+    assert chk["ascending"] and chk["ids_in_range"] and chk["ids_unique_per_query"]
+    assert chk["returned_dists_recomputed_bit_exact"] and chk["queries_checked"] == min(nq, 32)
+
+
+@pytest.mark.parametrize("ngpu", [2, 4])
+def test_driver_command_shape_one_process_per_gpu(ngpu):
+    """`python bench.py --gpus N --steps K --warmup W` (BASELINE config 5, shrunk): rc 0, one JSON line, the sharded
+    answer identical to one scan of the whole base on one GPU."""
+    rows, nq, k = 4_000_000, 64, 100
+    line = _run(["--gpus", str(ngpu), "--rows", str(rows), "--nq", str(nq), "--k", str(k), "--steps", "2", "--warmup", "1"],
+                {"RQ_BENCH_BACKEND": "gloo"})
+    _common(line, ngpu, rows, nq, k)
+    assert line["debug_backend"] and "gloo" in line["debug_backend"]      # flagged as not-a-measurement
+    assert "one process per GPU" in line["config"]["parallelism"]
+    assert line["config"]["n_base_per_gpu"] == rows // ngpu
+    ref = line["same_workload_1gpu"]
+    assert ref and "error" not in ref, ref
+    assert ref["answer_identical_to_the_sharded_run"] is True
+    assert line["roofline"] and line["roofline"]["kernel"] == "adc_scan_kernel<8>"
+
+
+def test_inproc_logical_shards_through_the_library_index():
+    """`--inproc --devices 0,0,0,0`: the in-library sharded index (rq_index_create_sharded) with four logical shards."""
+    rows, nq, k = 4_000_000, 64, 100
+    line = _run(["--inproc", "--devices", "0,0,0,0", "--workload", "sift1b", "--rows", str(rows), "--nq", str(nq), "--k", str(k),
+                 "--steps", "2", "--warmup", "1"])
+    _common(line, 4, rows, nq, k)
+    assert line["logical_shards"]
+    assert "rq_index_create_sharded over 4 shard(s)" in line["config"]["parallelism"]
+    ref = line["same_workload_1gpu"]
+    assert ref and "error" not in ref, ref
+    assert ref["answer_identical_to_the_sharded_run"] is True
+
+
+def test_world_size_mismatch_is_an_error_not_a_silent_single_gpu_run():
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, timeout=300,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 2 and "WORLD_SIZE" in p.stderr

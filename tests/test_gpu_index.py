@@ -135,6 +135,27 @@ def test_index_argument_errors(rq):
             ix.search(g["queries"], g["codes"].shape[0] + 1)  # k > n
         with pytest.raises(rq.RayuelaHipError):
             ix.search(g["queries"], 0)
+        # row ids must stay below 0xFFFFFFFF (the padding key's id): set_codes and search use the SAME bound, so a base
+        # that loads can always be searched (id_offset + n == 2^32 used to load and then fail every search)
+        n = g["codes"].shape[0]
+        with pytest.raises(rq.RayuelaHipError):
+            ix.set_codes(g["codes"], id_offset=2 ** 32 - n)
+        ix.set_codes(g["codes"], id_offset=2 ** 32 - 1 - n)
+        dists, ids = ix.search(g["queries"], 10, id_base=0)
+        assert np.array_equal(ids, g["ids_K10"] + np.uint32(2 ** 32 - 1 - n)) and _eq_bits(dists, g["dists_K10"])
+
+
+def test_env_single_device_restores_the_callers_device(rq, monkeypatch):
+    """RAYUELA_HIP_DEVICES with ONE entry switched the calling thread's device and left it switched."""
+    import torch
+    g = golden("scan_sift_mini")
+    m = g["codes"].shape[1]
+    C = [g["centers"][i] for i in range(m)]
+    monkeypatch.setenv("RAYUELA_HIP_DEVICES", "0")
+    before = torch.cuda.current_device()
+    dists, idx = rq.linscan_pq(g["codes"], g["queries"], C, 8 * m, 100)
+    assert np.array_equal(idx, g["ids_K100"] + 1) and _eq_bits(dists, g["dists_K100"])
+    assert torch.cuda.current_device() == before
 
 
 def test_two_host_threads_two_streams_do_not_interfere(rq):

@@ -340,3 +340,36 @@ def test_second_threshold_estimate_and_its_fallback(rq, oracle, z):
             assert np.array_equal(i0, i1) and _eq_bits(d0, d1), (z, K)
     finally:
         rq.set_tuning("SCAN_RETUNE_Z", 6)
+
+
+@pytest.mark.parametrize("z", [6, -2])
+@pytest.mark.parametrize("filt", [1, 0])
+def test_capacity_cut_after_second_estimate(rq, oracle, filt, z):
+    """a capacity cut that fires AFTER the second threshold estimate, while fewer than K buffered candidates
+    beat the tightened threshold, keeps keys above it -- rows between the two thresholds scanned in the meantime are
+    already gone, so the item must be redone exactly.  SCAN_SLACK = 1 makes the cut fire that early on ordinary data
+    (whole-base items: SCAN_SLICES=1 gives every group the 400 000 rows the second estimate needs).  With the shipped
+    z = 6 the tightened threshold still admits the true top-k, so the old code's answer happened to stay right; z = -2
+    makes the estimate too tight on purpose (what a base whose row order correlates with distance does), and there the
+    round-2 library returned wrong neighbours."""
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import _lib
+    rng = np.random.default_rng(77)
+    m, sub, n, nq = 8, 4, 400_000, 64
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=21)
+    knobs = {"SCAN_SLACK": 1, "SCAN_SLICES": 1, "SCAN_STATS": 1, "SCAN_FILTER": filt, "SCAN_RETUNE_Z": z}
+    for k_, v in knobs.items():
+        rq.set_tuning(k_, v)
+    try:
+        for K in (100, 1000):
+            d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+            d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+            st = _lib.scan_stats()
+            assert np.array_equal(i0, i1) and _eq_bits(d0, d1), (K, filt, z, st)
+            # the path under test ran: in-stream cuts happened and the flagged items were redone exactly
+            assert st["n_cuts"] > 0 and st["n_fallbacks"] > 0, st
+    finally:
+        for k_, v in {"SCAN_SLACK": 0, "SCAN_SLICES": 0, "SCAN_STATS": 0, "SCAN_FILTER": 1, "SCAN_RETUNE_Z": 6}.items():
+            rq.set_tuning(k_, v)

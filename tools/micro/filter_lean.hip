@@ -9,7 +9,7 @@
 #include <stdlib.h>
 #include <vector>
 
-template <int NT, int QGB, int R>
+template <int NT, int QGB, int R, int KG = 0>
 __global__ __launch_bounds__(NT) void filt_kernel(const uint8_t *__restrict__ codes, const uint2 *__restrict__ tabs, uint32_t n,
                                                   uint32_t ngroups, uint32_t nslices, uint32_t rows_per_slice,
                                                   uint32_t thr, unsigned long long *alive_out, uint32_t *counter) {
@@ -33,6 +33,7 @@ __global__ __launch_bounds__(NT) void filt_kernel(const uint8_t *__restrict__ co
     const uint32_t group = item % ngroups, slice = item / ngroups;
     for (int i = tid; i < NS * 8 * 256 * R; i += NT) qt[i] = tabs[(size_t)group * NS * 8 * 256 + i / R];
     const int rep = lane % R;
+    const uint2 *__restrict__ gt = tabs + (size_t)group * NS * 8 * 256;
     __syncthreads();
     const uint32_t r_begin = slice * rows_per_slice, r_end = min(n, r_begin + rows_per_slice);
     uint32_t qtail = 0;
@@ -54,7 +55,12 @@ __global__ __launch_bounds__(NT) void filt_kernel(const uint8_t *__restrict__ co
 #pragma unroll
           for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) e[r][k] = qt[((s * 8 + k) * 256 + ((w[(r * 8 + k) >> 2] >> (8 * ((r * 8 + k) & 3))) & 0xffu)) * R + rep];
+            for (int k = 0; k < 8; ++k) {
+              const uint32_t byte = (w[(r * 8 + k) >> 2] >> (8 * ((r * 8 + k) & 3))) & 0xffu;
+              // KG > 0: the last KG sub-quantizers' tables are gathered through the vector-memory path (L1) instead of LDS
+              if (k >= 8 - KG) e[r][k] = gt[(s * 8 + k) * 256 + byte];
+              else e[r][k] = qt[((s * 8 + k) * 256 + byte) * R + rep];
+            }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(NT) void filt_kernel(const uint8_t *__restrict__ co
   if (lane == 0) atomicAdd(alive_out, alive_total);
 }
 
-template <int NT, int QGB, int R = 1>
+template <int NT, int QGB, int R = 1, int KG = 0>
 static void run(const uint8_t *codes, const uint2 *tabs, uint32_t n, uint32_t nq, uint32_t thr, int wgs_per_cu) {
   constexpr int NS = QGB / 8;
   const uint32_t ngroups = nq / QGB;
@@ -91,20 +97,20 @@ static void run(const uint8_t *codes, const uint2 *tabs, uint32_t n, uint32_t nq
   unsigned long long *alive; uint32_t *counter;
   hipMalloc(&alive, 8); hipMalloc(&counter, 4);
   const size_t lds = (size_t)NS * 8 * 256 * 8 * R + (size_t)(NT / 64) * 256 * 4;
-  hipFuncSetAttribute(reinterpret_cast<const void *>(filt_kernel<NT, QGB, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(filt_kernel<NT, QGB, R, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e9;
   unsigned long long al = 0;
   for (int rep = 0; rep < 4; ++rep) {
     hipMemset(alive, 0, 8); hipMemset(counter, 0, 4);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((filt_kernel<NT, QGB, R>), dim3(grid), dim3(NT), lds, 0, codes, tabs, n, ngroups, nslices, rps, thr, alive, counter);
+    hipLaunchKernelGGL((filt_kernel<NT, QGB, R, KG>), dim3(grid), dim3(NT), lds, 0, codes, tabs, n, ngroups, nslices, rps, thr, alive, counter);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
     hipMemcpy(&al, alive, 8, hipMemcpyDeviceToHost);
   }
-  printf("R=%d NT=%4d QGB=%2d WGs/CU=%d slices=%u lds=%zu KB: %.3f ms  alive (row,set) share %.3f%%  err=%s\n", R, NT, QGB, wgs_per_cu, nslices, lds / 1024, best,
+  printf("KG=%d R=%d NT=%4d QGB=%2d WGs/CU=%d slices=%u lds=%zu KB: %.3f ms  alive (row,set) share %.3f%%  err=%s\n", KG, R, NT, QGB, wgs_per_cu, nslices, lds / 1024, best,
          100.0 * (double)al / ((double)n * (nq / 8)), hipGetErrorString(hipGetLastError()));
 }
 
@@ -128,6 +134,15 @@ int main() {
   run<512, 32>(codes, tabs, n, nq, thr, 2);
   run<1024, 32>(codes, tabs, n, nq, thr, 2);
   run<1024, 32>(codes, tabs, n, nq, thr, 1);
+  // L1 path for the last KG sub-quantizers
+  run<512, 8, 1, 1>(codes, tabs, n, nq, thr, 2);
+  run<512, 8, 1, 2>(codes, tabs, n, nq, thr, 2);
+  run<512, 8, 1, 3>(codes, tabs, n, nq, thr, 2);
+  run<512, 8, 1, 2>(codes, tabs, n, nq, thr, 4);
+  run<512, 8, 1, 3>(codes, tabs, n, nq, thr, 4);
+  run<512, 8, 1, 4>(codes, tabs, n, nq, thr, 4);
+  run<512, 8, 2, 2>(codes, tabs, n, nq, thr, 4);
+  run<512, 8, 4, 2>(codes, tabs, n, nq, thr, 2);
   // table replicas against bank conflicts (8 queries per workgroup: 16 KB x R)
   run<512, 8, 2>(codes, tabs, n, nq, thr, 4);
   run<512, 8, 4>(codes, tabs, n, nq, thr, 2);
