@@ -104,9 +104,11 @@ def timed(fn, steps, warmup, barrier):
 
 
 def load_traffic(kernel_key):
-    """HBM/fabric bytes per launch of `kernel_key` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE, separate runs; FETCH doubled per MI355X_MICROARCH.md section HBM)."""
-    for name in ("r2_traffic.json", "r1_traffic.json"):
+    """HBM/fabric bytes per launch of `kernel_key` from the NEWEST committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate runs; FETCH doubled per MI355X_MICROARCH.md section HBM).  Only the newest round's file counts:
+    a shape that was not re-measured after the kernels changed reports null, never an older round's bytes
+    (tools/profile_round3.sh + tools/collect_profiles.py rewrite the file)."""
+    for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -114,6 +116,7 @@ def load_traffic(kernel_key):
         if kernel_key in tj:
             e = tj[kernel_key]
             return 2.0 * e["FETCH_SIZE_KiB"] * 1024 + e["WRITE_SIZE_KiB"] * 1024, "profiles/%s (%s)" % (name, e.get("source", ""))
+        return None, None
     return None, None
 
 

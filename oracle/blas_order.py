@@ -99,7 +99,7 @@ def near_tie_report(X, C_list, offsets, codes_a, codes_b):
         da = d64[np.arange(rows.size), codes_a[rows, i]]
         db = d64[np.arange(rows.size), codes_b[rows, i]]
         gap = np.abs(da - db)
-        bound = 4.0 * (sub + 2) * 2.0 ** -24 * (xx + cc.max())
+        bound = 2.0 * (sub + 2) * 2.0 ** -24 * (2.0 * xx + cc[codes_a[rows, i]] + cc[codes_b[rows, i]])   # the two centroids involved
         flips += rows.size
         outside += int((gap > bound).sum())
         worst = max(worst, float((gap / bound).max()))

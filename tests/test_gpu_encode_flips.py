@@ -21,7 +21,11 @@ def _flips(X, Ccat_list, codes, off):
         sub = Ci.shape[1]
         C64 = Ci.double()
         cc = (C64 * C64).sum(1)
-        eps = 4.0 * (sub + 2) * 2.0 ** -24
+        # f32 rounding of ONE distance v_k = fl(fl(sa_k + sb) - 2 g_k): the three sub-term chains carry gamma_sub each
+        # (|g| <= (|x|^2 + |c_k|^2) / 2), plus two roundings: |v32_k - v_k| <= 2 (sub + 2) u (|x|^2 + |c_k|^2).  If f32 prefers
+        # `mine` to the float64 winner `best`, the float64 gap is at most the SUM of the two errors -- with the two
+        # centroids involved, not the largest |c|^2 of the codebook
+        eps = 2.0 * (sub + 2) * 2.0 ** -24
         for a in range(0, n, 250_000):
             Xs = X[a:a + 250_000, off[i]:off[i + 1]].double()
             xx = (Xs * Xs).sum(1)
@@ -31,7 +35,7 @@ def _flips(X, Ccat_list, codes, off):
             diff = best != mine
             if diff.any():
                 gap = d64[diff, mine[diff]] - d64[diff, best[diff]]
-                bound = eps * (xx[diff] + cc.max())
+                bound = eps * (2.0 * xx[diff] + cc[mine[diff]] + cc[best[diff]])
                 flips += int(diff.sum())
                 outside += int((gap > bound).sum())
                 worst = max(worst, float((gap / bound).max()))

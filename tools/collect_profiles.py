@@ -1,33 +1,45 @@
 #!/usr/bin/env python3
-"""Copy the judged summaries of gpurun_out/r2 (written by tools/profile_round2.sh on the GPU box) into profiles/:
-bench lines, the library's rows of the rocprofv3 kernel stats, the PMC table and the FETCH/WRITE traffic per launch."""
+"""Copy the judged summaries of gpurun_out/<round> (written by tools/profile_round<N>.sh on the GPU box) into profiles/:
+bench lines, the library's rows of the rocprofv3 kernel stats, the PMC table and the FETCH/WRITE traffic per launch
+(profiles/<round>_traffic.json is REWRITTEN from the PMC passes every time, so the bytes bench.py replays follow the kernels).
+usage: python tools/collect_profiles.py [r3]"""
 import csv
+import glob
 import json
 import os
 import re
 import shutil
+import sys
 
-O = "gpurun_out/r2"
-for f in ("bench_pq", "bench_opq", "bench_deep", "bench_pq_k10000", "bench_sift1b_1gpu", "bench_sift1b_inproc"):
-    open("profiles/r2_%s.json" % f, "w").write(open("%s/%s.json" % (O, f)).read().strip().splitlines()[-1] + "\n")
-for w in ("pq", "opq", "deep", "k10000", "sift1b"):
-    rows = list(csv.reader(open("%s/stats_%s/s_kernel_stats.csv" % (O, w))))
-    csv.writer(open("profiles/r2_bench_%s_kernel_stats.csv" % w, "w")).writerows([rows[0]] + [r for r in rows[1:] if "rq::" in r[0]])
-shutil.copy(O + "/pmc_summary.txt", "profiles/r2_pmc_counters.md")
+RND = sys.argv[1] if len(sys.argv) > 1 else "r3"
+O = "gpurun_out/" + RND
+for f in ("bench_pq", "bench_opq", "bench_deep", "bench_pq_k10000", "bench_sift1b_1gpu", "bench_sift1b_shard", "bench_sift1b_inproc"):
+    if os.path.exists("%s/%s.json" % (O, f)):
+        open("profiles/%s_%s.json" % (RND, f), "w").write(open("%s/%s.json" % (O, f)).read().strip().splitlines()[-1] + "\n")
+for w in ("pq", "opq", "deep", "k10000", "sift1b", "sift1b_shard"):
+    g = glob.glob("%s/stats_%s/**/s_kernel_stats.csv" % (O, w), recursive=True)
+    if not g:
+        continue
+    rows = list(csv.reader(open(g[0])))
+    csv.writer(open("profiles/%s_bench_%s_kernel_stats.csv" % (RND, w), "w")).writerows([rows[0]] + [r for r in rows[1:] if "rq::" in r[0]])
+shutil.copy(O + "/pmc_summary.txt", "profiles/%s_pmc_counters.md" % RND)
+if os.path.exists(O + "/index_overhead.md"):
+    shutil.copy(O + "/index_overhead.md", "profiles/%s_index_overhead.md" % RND)
 shape = {"pmc_FETCH_SIZE": "adc_scan_kernel<8> n=1000000 nq=10000 k=1000", "pmc_WRITE_SIZE": "adc_scan_kernel<8> n=1000000 nq=10000 k=1000",
          "pmc_deep_FETCH_SIZE": "adc_scan_kernel<16> n=1000000 nq=10000 k=1000", "pmc_deep_WRITE_SIZE": "adc_scan_kernel<16> n=1000000 nq=10000 k=1000",
-         "pmc_sift1b_FETCH_SIZE": "adc_scan_kernel<8> n=1000000000 nq=1024 k=100", "pmc_sift1b_WRITE_SIZE": "adc_scan_kernel<8> n=1000000000 nq=1024 k=100"}
+         "pmc_sift1b_FETCH_SIZE": "adc_scan_kernel<8> n=1000000000 nq=1024 k=100", "pmc_sift1b_WRITE_SIZE": "adc_scan_kernel<8> n=1000000000 nq=1024 k=100",
+         "pmc_shard_FETCH_SIZE": "adc_scan_kernel<8> n=125000000 nq=1024 k=100", "pmc_shard_WRITE_SIZE": "adc_scan_kernel<8> n=125000000 nq=1024 k=100"}
 t = {}
-for line in open("profiles/r2_pmc_counters.md"):
+for line in open("profiles/%s_pmc_counters.md" % RND):
     m = re.match(r"\| (pmc_\S+) \| (.*?) \| (\S+) \| (\d+) \| (\S+) \|", line)
     if not m or m.group(3) not in ("FETCH_SIZE", "WRITE_SIZE") or "adc_scan" not in m.group(2):
         continue
     e = t.setdefault(shape[m.group(1)], {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py of that "
-                                                   "workload (tools/profile_round2.sh); profiles/r2_pmc_counters.md"})
+                                                   "workload (tools/profile_round%s.sh); profiles/%s_pmc_counters.md" % (RND[1:], RND)})
     e[m.group(3) + "_KiB"] = float(m.group(5))
-json.dump(t, open("profiles/r2_traffic.json", "w"), indent=1)
+json.dump(t, open("profiles/%s_traffic.json" % RND, "w"), indent=1)
 for f in sorted(os.listdir("profiles")):
-    if f.startswith("r2_bench") and f.endswith(".json"):
+    if f.startswith(RND + "_bench") and f.endswith(".json"):
         d = json.load(open("profiles/" + f))
         r = d.get("roofline") or {}
         print(f, d["value"], d["ms_per_step"], "frac", r.get("frac"), "f32roof", (r.get("f32_table_roof") or {}).get("frac"),
