@@ -143,14 +143,12 @@ struct ScanCtrl {
   uint32_t sel[QG];     // which half of the candidate ping-pong buffer is current
   uint32_t item;
   uint32_t selmask;     // bit q == sel[q] (one LDS word the hot loop reads per block)
-  uint32_t inexact;     // a capacity cut ran while fewer than K candidates beat a tightened tau: the slice is redone exactly
-  uint32_t pad;
+  uint32_t pad[2];
   // integer pre-filter (FILT kernels): per-(sub-quantizer, query) table minima and the per-query scale
   float fmin[16][QG];
   float fmax[16][QG];   // LSQ scans: per-(sub-quantizer, query) max |entry| (absolute rounding margins)
   float finv[QG];
   uint32_t fpush;       // rows the pre-filter let through in the item's first block (it is switched off if too many)
-  int32_t base2[QG];    // after a second threshold estimate: (#candidates below the new tau) - (#candidates) at that moment
   SelState<QG> st;      // st.hist doubles as the per-wavefront queues of rows waiting for the exact evaluation
 };
 
@@ -798,13 +796,7 @@ __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, ui
   const uint64_t tau_key = ctrl->st.prefix[g];
   compact_leq<QG, TPG>(&ctrl->st, src, dst, cnt, tau_key, need, g, gi);
   if (need && gi == 0) {
-    // After a second threshold estimate (retune_tau) rows above the tightened tau are no longer appended.  If fewer than K
-    // of the buffered candidates beat it, the K-th key kept here lies ABOVE it, and rows in between that were scanned
-    // since the estimate are already gone: this cut cannot restore exactness.  The item is flagged and redone from
-    // tau = +inf at the end-of-slice vote (tests/test_gpu_scan.py::test_capacity_cut_after_second_estimate).
-    if ((int32_t)cnt + ctrl->base2[g] < (int32_t)p.K) ctrl->inexact = 1u;
     ctrl->cnt[g] = ctrl->st.newcnt[g];  // == K (keys are unique)
-    ctrl->base2[g] = 0;                 // the K kept keys are the K smallest so far: exact again
     ctrl->sel[g] = sel ^ 1u;
     atomicXor(&ctrl->selmask, 1u << g);
     ctrl->tau[g] = key_dist(tau_key);
@@ -816,36 +808,34 @@ __device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, ui
 // are an exact sample of that fraction, so the number of them below the true K-th distance is Binomial(K, f); tau
 // becomes the distance of the candidate of rank  K f + z sqrt(K f (1 - f)) + 2  (z = 6), which lets ~K + z sqrt(K/f)
 // rows through the whole slice instead of the first estimate's 1.5-2.5 K: fewer exact re-evaluations, appends and
-// keys to cut at the end.  Nothing is discarded; candidates between the new and the old tau stay in the buffer, and
-// base2 = (#candidates below the new tau) - (#candidates) makes the end-of-slice check count only the former --
-// if fewer than K rows beat the tightened tau the slice is redone exactly, as after a failed first estimate.
+// keys to cut at the end.  The candidates ABOVE the new tau are dropped on the spot (one compaction pass over the few
+// hundred keys collected so far): they can only matter if fewer than K rows beat the new tau, and in that case the
+// end-of-slice check (cnt < K) redoes the slice exactly anyway.  So the invariant of the streaming loop holds before and
+// after: the buffer is exactly the set of rows seen so far with dist <= tau -- which is what makes a later capacity cut
+// (K smallest keys, tau = the K-th) exact.  (Round 2 kept the stale candidates and a correction count instead; a
+// capacity cut after the estimate could then keep stale keys above the new tau and silently lose rows in between --
+// ADVICE r2; flagging such cuts for the exact redo instead made 6 % of the items of a 1e9-row scan fall back.)
 template <int M>
-__device__ __noinline__ uint32_t retune_tau(ScanCtrl<ScanCfg<M>::QG> *ctrl, const uint64_t *cand_wg, uint32_t cap, uint32_t r2,
+__device__ __noinline__ uint32_t retune_tau(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, uint32_t cap, uint32_t r2,
                                             uint32_t vseq) {
   constexpr int QG = ScanCfg<M>::QG;
   constexpr int TPG = ScanCfg<M>::THREADS / QG;
   const int g = threadIdx.x / TPG, gi = threadIdx.x % TPG;
   const uint32_t cnt = ctrl->cnt[g];
+  const uint32_t sel = ctrl->sel[g];
   const bool act = cnt > r2 && r2 >= 1;
-  const uint64_t *src = cand_wg + ((size_t)g * 2 + ctrl->sel[g]) * cap;
+  const uint64_t *src = cand_wg + ((size_t)g * 2 + sel) * cap;
+  uint64_t *dst = cand_wg + ((size_t)g * 2 + (sel ^ 1u)) * cap;
   radix_select<QG, TPG>(&ctrl->st, src, cnt, r2, act, g, gi, vseq);
   const uint32_t td = (uint32_t)(ctrl->st.prefix[g] >> 32);     // ordered bits of the r2-th smallest distance
-  if (gi == 0) ctrl->st.newcnt[g] = 0;
-  __syncthreads();
-  if (act) {
-    uint32_t c = 0;
-    for (uint32_t i = gi; i < cnt; i += TPG) c += (uint32_t)(src[i] >> 32) <= td ? 1u : 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    if ((gi & 63) == 0) atomicAdd(&ctrl->st.newcnt[g], c);
-  }
-  __syncthreads();
-  if (act && gi == 0) {
-    const float tau2 = ord2f(td);
-    if (tau2 < ctrl->tau[g]) {
-      ctrl->tau[g] = tau2;
-      ctrl->base2[g] = (int32_t)ctrl->st.newcnt[g] - (int32_t)cnt;
-    }
+  const bool tighten = act && ord2f(td) < ctrl->tau[g];          // (tau is rewritten behind compact_leq's barriers)
+  // keep every key whose DISTANCE is <= the new tau (all ids): the inclusive rule of emit_survivors
+  compact_leq<QG, TPG>(&ctrl->st, src, dst, cnt, ((uint64_t)td << 32) | 0xFFFFFFFFull, tighten, g, gi);
+  if (tighten && gi == 0) {
+    ctrl->tau[g] = ord2f(td);
+    ctrl->cnt[g] = ctrl->st.newcnt[g];
+    ctrl->sel[g] = sel ^ 1u;
+    atomicXor(&ctrl->selmask, 1u << g);
   }
   __syncthreads();
   return vseq;
@@ -996,8 +986,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
       ctrl->tau[tid] = __uint_as_float(0x7f800000u);  // +inf: everything passes until the first cut
       ctrl->cnt[tid] = 0;
       ctrl->sel[tid] = 0;
-      ctrl->base2[tid] = 0;
-      if (tid == 0) { ctrl->selmask = 0; ctrl->fpush = 0; ctrl->inexact = 0; }
+      if (tid == 0) { ctrl->selmask = 0; ctrl->fpush = 0; }
     }
     __syncthreads();
     if (attempt == 1 && sampled) RQ_STAT_INC(7);
@@ -1336,8 +1325,8 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
     // ---- finish the item: cut to K, sort, write ----------------------------------------------
     if (attempt == 0) {
       // the sampled tau must have let at least min(K, rows) rows through for EVERY query
-      // (after a second estimate only the candidates below the tightened tau count: cnt + base2)
-      const bool shortfall = (int32_t)ctrl->cnt[g] + ctrl->base2[g] < (int32_t)min((uint32_t)p.K, rows) || ctrl->inexact != 0u;
+      // (the buffer holds exactly the rows with dist <= tau, also after a second estimate: retune_tau)
+      const bool shortfall = ctrl->cnt[g] < min((uint32_t)p.K, rows);
       if (block_any(shortfall, ctrl->st.vote, vseq)) continue;  // exact fallback: redo the slice from tau = +inf
     }
     if (!p.bigk) {

@@ -15,9 +15,10 @@ import rayuela_jl_amd.synth as synth             # noqa: E402
 
 def main():
     d, m, nq, k = 128, 8, 1024, 100
-    rng = np.random.default_rng(5)
-    C = [rng.standard_normal((256, d // m)).astype(np.float32) for _ in range(m)]
-    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    # bench.py's sift1b inputs: codebooks and queries from sift-like vectors, base = hash-generated code bytes
+    S = synth.sift_like(20_000, d, seed=synth.SEED_BASE, ncentres=65536, row0=3_100_000_000)
+    C = synth.codebooks(S, m, 256, seed=synth.SEED_CODEBOOK, iters=5, sample=20000)
+    Q = synth.sift_like(nq, d, seed=synth.SEED_BASE, ncentres=65536, row0=3_000_000_000)
     print("| rows | shards | exchange | ms per search (best of 7) | per extra shard (us) |")
     print("|---|---|---|---|---|")
     for n in (100_000, 16_000_000, 125_000_000):
