@@ -273,7 +273,8 @@ int rq_scan_stats(unsigned long long *out16);
 /* Diagnostics (pure host code, no device needed): the scan planner's decision for a shard of n rows, nq queries,
  * m sub-quantizers, dimension d, k neighbours on a device with num_cu compute units.  out[0] queries per group,
  * [1] groups, [2] groups scanned as whole-base items, [3] row slices of the remaining groups, [4] rows per slice,
- * [5] workgroups launched, [6] candidate capacity per query, [7] 1 = sample-sort finish (k > 1024). */
+ * [5] workgroups launched, [6] candidate capacity per query, [7] bit 0: sample-sort finish (k > 1024), bit 1: big base --
+ * row windows handed out per XCD (L2 affinity). */
 int rq_scan_plan(int64_t n, int64_t nq, int m, int d, int k, int num_cu, int64_t *out8);
 
 /* Milliseconds spent in the last host-pointer call on this thread: total wall, H2D, kernels

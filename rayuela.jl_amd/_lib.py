@@ -117,11 +117,13 @@ def set_tuning(key, value):
 
 
 def scan_plan(n, nq, m, d, k, num_cu=256):
-    """The planner's decision (host code only): dict of qg, groups, whole, slices, rows_per_slice, grid, cap, bigk."""
+    """The planner's decision (host code only): dict of qg, groups, whole, slices, rows_per_slice, grid, cap, bigk, xcd."""
     out = (C.c_int64 * 8)()
     check(lib().rq_scan_plan(n, nq, m, d, k, num_cu, C.cast(out, C.c_void_p)))
-    keys = ("qg", "groups", "whole", "slices", "rows_per_slice", "grid", "cap", "bigk")
-    return dict(zip(keys, [int(x) for x in out]))
+    keys = ("qg", "groups", "whole", "slices", "rows_per_slice", "grid", "cap", "flags")
+    p = dict(zip(keys, [int(x) for x in out]))
+    p["bigk"], p["xcd"] = p["flags"] & 1, (p["flags"] >> 1) & 1
+    return p
 
 
 def scan_stats():

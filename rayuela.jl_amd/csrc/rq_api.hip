@@ -719,7 +719,7 @@ int rq_scan_plan(int64_t n, int64_t nq, int m, int d, int k, int num_cu, int64_t
   ScanPlan pl;
   RQ_TRY(scan_plan(pl, n, nq, m, d, k, num_cu, tuning("SCAN_SLICES", 0)));
   out8[0] = pl.qg; out8[1] = pl.ngroups; out8[2] = pl.whole; out8[3] = pl.nslices; out8[4] = pl.rows_per_slice;
-  out8[5] = pl.grid; out8[6] = pl.cap; out8[7] = pl.bigk ? 1 : 0;
+  out8[5] = pl.grid; out8[6] = pl.cap; out8[7] = (pl.bigk ? 1 : 0) | (pl.xcd ? 2 : 0);
   return RQ_OK;
 }
 

@@ -78,6 +78,7 @@ struct ScanPlan {
   uint32_t cap, trigger, p2, scratch_keys, grid, sample;
   size_t cand_bytes, gtab_off, bkt_off;
   bool lds_ok, bigk, spread;
+  bool xcd;        // big base: short row windows handed out per XCD (see plan_for)
 };
 int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_cu, int force_slices);
 int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, uint64_t *part, const uint8_t *codes,

@@ -169,6 +169,9 @@ struct ScanParams {
   uint32_t nslices, rows_per_slice, ngroups;
   uint32_t whole;           // query groups [0, whole) are ONE item over all rows (answer written directly);
                             // groups [whole, ngroups) are cut into nslices row slices (key lists -> merge)
+  uint32_t xcd_mode;        // 1: big base -- row windows are handed out per XCD (work_counter[0..7]), see the item loop
+  uint32_t xcd_slack;       // ... an item may start while at most this many items of the XCD's earlier rounds still run
+  uint32_t xcd_round;       // ... items per pacing round (a window's items, or the XCD's resident workgroups)
   uint32_t cap;             // candidate buffer capacity per query (keys)
   uint32_t trigger;         // compact when cnt > trigger  (cap - 2*VP*BLK >= trigger >= K)
   uint32_t p2;              // next_pow2(K)
@@ -902,10 +905,53 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
   const uint32_t nitems = p.whole + tail_groups * p.nslices;
   uint32_t vseq = 0;                         // block_any() call counter (workgroup-uniform)
   if (tid < 2) ctrl->st.vote[tid] = 0;
+  if (tid == 0) ctrl->pad[0] = 0xffffffffu;  // xcd_mode: the XCD whose item this workgroup is working on
+  uint32_t xcd = 0;                          // the XCD this workgroup runs on (a speed hint only: L2 affinity)
+  if (p.xcd_mode) {
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcd));
+    xcd &= 7u;
+  }
 
   for (;;) {
     __syncthreads();
-    if (tid == 0) ctrl->item = atomicAdd(p.work_counter, 1u);
+    if (tid == 0) {
+      if (!p.xcd_mode) {
+        ctrl->item = atomicAdd(p.work_counter, 1u);
+      } else {
+        // Big bases (plan_for): the rows are cut into windows of a few tens of MB and window s belongs to XCD s mod 8,
+        // which runs ALL query groups over it before its next window -- the 64 workgroups of an XCD then stream the same
+        // rows at about the same time and share them through that XCD's 4 MiB L2, instead of every workgroup pulling its
+        // own copy of the base through the fabric (8 GB base, 128 groups: 79x the code bytes fetched per launch).
+        // One work counter per XCD; an XCD that runs dry takes windows of the next one.  Placement only changes speed.
+        // Pacing (a speed hint, no data depends on it): with nothing else the workgroups of an XCD finish their items
+        // at evenly spread times after a few windows, their positions inside the current window spread uniformly and the
+        // L2 sharing is gone again (measured at 1e9 rows: 65x the code bytes fetched instead of 75x).  So the XCD's items
+        // go in rounds of `xcd_round` (one per resident workgroup), and an item starts only when all but `xcd_slack`
+        // items of the earlier rounds are finished: the pack re-forms every round (numbers: scan_launch).  work_counter[8 + x] counts XCD x's finished items; earlier items never wait for
+        // later ones, so the waits cannot form a cycle, and the spin is bounded anyway.
+        if (ctrl->pad[0] != 0xffffffffu) atomicAdd(p.work_counter + 8u + ctrl->pad[0], 1u);     // the item just finished
+        ctrl->pad[0] = 0xffffffffu;
+        uint32_t it = 0xffffffffu;
+        for (uint32_t y = 0; y < 8u && it == 0xffffffffu; ++y) {
+          const uint32_t x = (xcd + y) & 7u;
+          const uint32_t nwin = x < p.nslices ? (p.nslices - x + 7u) / 8u : 0u;       // windows s = x, x + 8, ...
+          const uint32_t cnt_x = nwin * p.ngroups;
+          if (cnt_x == 0u) continue;
+          const uint32_t j = atomicAdd(p.work_counter + x, 1u);
+          if (j < cnt_x) {
+            it = ((j / p.ngroups) * 8u + x) * p.ngroups + (j % p.ngroups);             // = slice * ngroups + group
+            ctrl->pad[0] = x;
+            const uint32_t before = (j / p.xcd_round) * p.xcd_round;                   // items of the earlier rounds
+            const uint32_t need = before > p.xcd_slack ? before - p.xcd_slack : 0u;
+            for (uint32_t spin = 0; spin < (1u << 18); ++spin) {
+              if (__hip_atomic_load(p.work_counter + 8u + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+              __builtin_amdgcn_s_sleep(64);
+            }
+          }
+        }
+        ctrl->item = it;
+      }
+    }
     __syncthreads();
     const uint32_t item = ctrl->item;
     if (item >= nitems) break;
@@ -1627,11 +1673,28 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   const int tail_ns = tuning("SCAN_TAIL_SLICES", 0);           // experiments: slices of the tail groups only
   if (tail_ns > 0 && tail > 0) ns = std::min<int64_t>(tail_ns, max_slices);
   if (force_slices > 0) { ns = force_slices; whole = 0; }   // tests: every group sliced
+  // Big bases (code array >= SCAN_XCD_MIN_MB, far beyond the 8 x 4 MiB of L2): short row windows, handed out per XCD
+  // (adc_scan_kernel: xcd_mode).  A window is SCAN_WINDOW_MB of codes: small enough that the workgroups of an XCD
+  // that started it together are still within L2 reach of each other at its end (their speeds differ by a few percent),
+  // large enough that the per-item work (tables, threshold sample, final select + sort) stays around one percent.  Bounds: the per-slice
+  // key lists (nq * ns * K * 8 bytes) stay below 1 GiB and a query's merge below 2^20 keys.
+  pl.xcd = false;
+  if (force_slices <= 0 && tail_ns <= 0 && tuning("SCAN_XCD", 1) &&
+      (int64_t)n * M >= ((int64_t)(tuning("SCAN_XCD_MIN_MB", 0) > 0 ? tuning("SCAN_XCD_MIN_MB", 0) : 128) << 20)) {
+    int64_t wrows = ((int64_t)(tuning("SCAN_WINDOW_MB", 0) > 0 ? tuning("SCAN_WINDOW_MB", 0) : 32) << 20) / M;
+    wrows = std::max<int64_t>(wrows, min_rows);
+    int64_t nw = (n + wrows - 1) / wrows;
+    const int64_t cap_part = ((int64_t)1 << 30) / std::max<int64_t>(1, nq * (int64_t)K * 8);
+    const int64_t cap_merge = ((int64_t)1 << 20) / std::max(1, K);
+    nw = std::min(nw, std::min(cap_part, cap_merge));
+    if (nw >= 16) { ns = nw; whole = 0; pl.xcd = true; }
+  }
   if (ns == 1) whole = pl.ngroups;
   int64_t rps = (n + ns - 1) / ns;
   rps = (rps + Cfg::BLK - 1) / Cfg::BLK * Cfg::BLK;
   ns = (n + rps - 1) / rps;
   if (ns == 1) whole = pl.ngroups;
+  if (ns < 16) pl.xcd = false;
   pl.nslices = (uint32_t)ns;
   pl.rows_per_slice = (uint32_t)rps;
   pl.whole = (uint32_t)whole;
@@ -1744,7 +1807,18 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.lut_mode = lut_mode; p.row_bias = row_bias;
   p.id_offset = id_offset; p.id_base = id_base;
   p.nslices = pl.nslices; p.rows_per_slice = pl.rows_per_slice; p.ngroups = pl.ngroups; p.whole = pl.whole;
-  p.cap = pl.cap; p.trigger = pl.trigger; p.p2 = pl.p2; p.scratch_keys = pl.scratch_keys;
+  p.xcd_mode = pl.xcd ? 1u : 0u;
+  {
+    // pacing round = the workgroups resident on one XCD (they take one item each), slack = half a round.  Measured at
+    // 1e9 rows x 8 bytes, 1024 queries, k = 100 (round 2's plan: 191.7 ms, 599 GB fetched per launch = 75x the code bytes):
+    //   round = a window's 128 items: slack 0 / 8 / 24: 195.8 / 194.7 / 195.1 ms, 6.5x / 7.1x / 7.0x; slack 32: 185.9 ms, 19x
+    //   round = 64 items:             slack 0 / 16 / 32: 199.8 / 195.8 / 189.0 ms, 6.0x / 7.0x / 10.7x      <- shipped: 64 / 32
+    //   no pacing: 185.8 ms, 65x (the pack dissolves after a few windows; on a 1.25e8-row shard, 4 windows per XCD: 12x)
+    const int rd = tuning("SCAN_XCD_ROUND", 0);
+    p.xcd_round = rd > 0 ? (uint32_t)rd : std::max(1u, pl.grid / 8u);
+    const int sl = tuning("SCAN_XCD_SLACK", -1);
+    p.xcd_slack = sl >= 0 ? (uint32_t)sl : p.xcd_round / 2u;
+  }
   p.sample = pl.sample;
   p.sample_rt = (uint32_t)tuning("SCAN_SAMPLE_RT", 4096);
   if (tuning("SCAN_SAMPLE", 0) > 0) p.sample_rt = pl.sample;      // an explicit SCAN_SAMPLE rules both
@@ -1782,7 +1856,7 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   }
   p.stats = tuning("SCAN_STATS", 0) ? reinterpret_cast<unsigned long long *>(work_counter + 16) : nullptr;
   p.dists = dists; p.ids = ids; p.keys = keys; p.part = part;
-  RQ_HIP(hipMemsetAsync(work_counter, 0, p.stats ? 256 : sizeof(uint32_t), stream));
+  RQ_HIP(hipMemsetAsync(work_counter, 0, p.stats ? 256 : 16 * sizeof(uint32_t), stream));   // [0..7] tickets, [8..15] finished items, per XCD
   switch (m) {
     case 2: return launch_scan<2>(p, pl, stream);
     case 4: return launch_scan<4>(p, pl, stream);

@@ -94,6 +94,15 @@ def test_scan_planner_decisions():
     assert p["qg"] == 8 and p["grid"] == 256 and p["whole"] == 1250
     assert _lib.scan_plan(1_000_000, 1_000, 32, 128, 100)["qg"] == 4
     assert _lib.scan_plan(1_000_000, 1_000, 12, 96, 100) == _lib.scan_plan(1_000_000, 1_000, 16, 96, 100)
-    # SIFT1B shard: 1.25e8 rows, 1024 queries -> 128 groups, 4 slices
+    # SIFT1B shard: 1.25e8 rows, 1024 queries -> 128 groups over 32 MB row windows (round 2: 4 slices)
     p = _lib.scan_plan(125_000_000, 1024, 8, 128, 100)
-    assert (p["groups"], p["slices"]) == (128, 4)
+    assert (p["groups"], p["slices"], p["xcd"]) == (128, 30, 1)
+
+
+def test_xcd_window_plan_is_the_default_for_big_bases():
+    from rayuela_jl_amd import _lib
+    p = _lib.scan_plan(1_000_000_000, 1024, 8, 128, 100)              # BASELINE config 5's workload on one GPU
+    assert p["xcd"] == 1 and p["whole"] == 0 and p["slices"] >= 128 and p["rows_per_slice"] * 8 <= 40 << 20, p
+    p = _lib.scan_plan(125_000_000, 1024, 8, 128, 100)                # ... and one GPU's shard of it on 8 GPUs
+    assert p["xcd"] == 1 and 16 <= p["slices"] <= 64, p
+    assert _lib.scan_plan(1_000_000, 10_000, 8, 128, 1000)["xcd"] == 0   # SIFT1M shape: whole-base items

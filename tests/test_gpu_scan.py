@@ -375,3 +375,32 @@ def test_capacity_cut_after_second_estimate(rq, oracle, filt, z):
     finally:
         for k_, v in {"SCAN_SLACK": 0, "SCAN_SLICES": 0, "SCAN_STATS": 0, "SCAN_FILTER": 1, "SCAN_RETUNE_Z": 6}.items():
             rq.set_tuning(k_, v)
+
+
+@pytest.mark.parametrize("m,sub,K,nq", [(8, 4, 100, 100), (8, 4, 1000, 24), (16, 2, 100, 40), (8, 4, 3000, 16)])
+def test_xcd_window_plan_on_a_small_base(rq, oracle, m, sub, K, nq):
+    """Big bases are scanned in short row windows handed out per XCD, with per-XCD pacing (plan_for / the item loop of
+    adc_scan_kernel).  SCAN_XCD_MIN_MB = 1 and 1 MB windows switch that plan on for a base the oracle can check:
+    ragged last window, query groups that do not fill a round, large-k merge of the window lists, strict and no pacing."""
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import _lib
+    rng = np.random.default_rng(31 + m + K)
+    n = 3_000_017
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=5)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    try:
+        rq.set_tuning("SCAN_XCD_MIN_MB", 1)
+        rq.set_tuning("SCAN_WINDOW_MB", 1)
+        plan = _lib.scan_plan(n, nq, m, m * sub, K)
+        assert plan["xcd"] == 1 and plan["whole"] == 0 and plan["slices"] >= 16, plan
+        for slack in (-1, 0, 1 << 20):
+            rq.set_tuning("SCAN_XCD_SLACK", slack)
+            d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+            assert np.array_equal(i0, i1) and _eq_bits(d0, d1), (m, K, slack)
+    finally:
+        rq.set_tuning("SCAN_XCD_MIN_MB", 0)
+        rq.set_tuning("SCAN_WINDOW_MB", 0)
+        rq.set_tuning("SCAN_XCD_SLACK", -1)
+    assert _lib.scan_plan(n, nq, m, m * sub, K)["xcd"] == 0            # 24-48 MB of codes: the ordinary plan
