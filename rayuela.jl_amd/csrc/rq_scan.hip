@@ -1809,16 +1809,23 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.nslices = pl.nslices; p.rows_per_slice = pl.rows_per_slice; p.ngroups = pl.ngroups; p.whole = pl.whole;
   p.xcd_mode = pl.xcd ? 1u : 0u;
   {
-    // pacing round = the workgroups resident on one XCD (they take one item each), slack = half a round.  Measured at
-    // 1e9 rows x 8 bytes, 1024 queries, k = 100 (round 2's plan: 191.7 ms, 599 GB fetched per launch = 75x the code bytes):
-    //   round = a window's 128 items: slack 0 / 8 / 24: 195.8 / 194.7 / 195.1 ms, 6.5x / 7.1x / 7.0x; slack 32: 185.9 ms, 19x
-    //   round = 64 items:             slack 0 / 16 / 32: 199.8 / 195.8 / 189.0 ms, 6.0x / 7.0x / 10.7x      <- shipped: 64 / 32
-    //   no pacing: 185.8 ms, 65x (the pack dissolves after a few windows; on a 1.25e8-row shard, 4 windows per XCD: 12x)
+    // pacing round = the items of whole windows, at least as many as the XCD has resident workgroups (fewer would leave
+    // workgroups idle); slack = a quarter of a round.  Measured at 1e9 rows x 8 bytes, 1024 queries, k = 100 (128 items per
+    // window, 64 workgroups per XCD; round 2's plan: 191.7 ms, 599 GB fetched per launch = 75x the code bytes) and on the
+    // 1.25e8-row shard that one of 8 GPUs holds (round 2: 23.85 ms, 60x):
+    //   round 128, slack 0 / 8 / 24: 195.8 / 194.7 / 195.1 ms, 6.5x / 7.1x / 7.0x;   slack 32: 185.9 ms, 19x   <- shipped
+    //   round  64, slack 0 / 16 / 32: 199.8 / 195.8 / 189.0 ms, 6.0x / 7.0x / 10.7x
+    //   no pacing: 185.8 ms, 65x (the pack dissolves after a few windows)
+    //   shard: round 128 / slack 32: 23.5 ms, 8.9x;  round 64 / slack 32: 24.5 ms, 7.9x;  slack 0: 24.3 ms, 6.7x
+    // Tighter pacing fetches less and costs more idle time than the L2 hits give back; the shipped point is the one that is
+    // faster than round 2 at both sizes.
+    const uint32_t per_xcd = std::max(1u, pl.grid / 8u);
     const int rd = tuning("SCAN_XCD_ROUND", 0);
-    p.xcd_round = rd > 0 ? (uint32_t)rd : std::max(1u, pl.grid / 8u);
+    p.xcd_round = rd > 0 ? (uint32_t)rd : pl.ngroups * ((per_xcd + pl.ngroups - 1u) / pl.ngroups);
     const int sl = tuning("SCAN_XCD_SLACK", -1);
-    p.xcd_slack = sl >= 0 ? (uint32_t)sl : p.xcd_round / 2u;
+    p.xcd_slack = sl >= 0 ? (uint32_t)sl : p.xcd_round / 4u;
   }
+  p.cap = pl.cap; p.trigger = pl.trigger; p.p2 = pl.p2; p.scratch_keys = pl.scratch_keys;
   p.sample = pl.sample;
   p.sample_rt = (uint32_t)tuning("SCAN_SAMPLE_RT", 4096);
   if (tuning("SCAN_SAMPLE", 0) > 0) p.sample_rt = pl.sample;      // an explicit SCAN_SAMPLE rules both
