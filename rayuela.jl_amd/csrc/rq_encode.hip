@@ -394,6 +394,369 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_direct_kernel(EncParams
 }
 
 // ------------------------------------------------------------------------------------------
+// encode_pq_split_kernel -- the same codes, bit for bit, at several times the f32-MFMA rate.
+//
+// The direct kernel above is bound by the f32 matrix rate (64 cycles per 32x32x2 step) plus a VALU epilogue that cannot
+// overlap it.  But the ARGMIN does not need every distance in canonical arithmetic -- only the winner (and whatever
+// could tie with it) does.  So, per (32 vectors, sub-quantizer):
+//
+//  1. FILTER on the bf16 matrix cores (16x the f32 rate).  x and -2c are split into bf16 pieces, x = xh + xl (+ <= 2^-16|x|),
+//     and   W_k = |c_k|^2 - 2 <c_k, x>  ~  sa_k + sum_s (-2c)h xh + (-2c)l xh + (-2c)h xl
+//     comes out of 3 (sub <= 8: 2) v_mfma_f32_32x32x16_bf16 per 32-centroid tile, the accumulator pre-loaded with the
+//     f32 norms sa_k (so the whole "sa - 2g" is MFMA work; |x|^2 is constant per vector and plays no part in the order).
+//     Error analysis (sub <= 16; S = sum_s |x_s c_ks| <= (sa_k + sb)/2, sb = |x|^2):
+//        dropped terms  2 (xl cl + xh ec + xl ec + ex c)   <= 6.2 * 2^-16 S        <= 2^-14.4 (sa_k + sb)
+//        f32 accumulation of <= 49 terms inside the MFMA    <= 49 * 2^-23 (sa + 2S) <= 2^-16.3 (sa_k + sb)
+//        canonical u_k (fmaf chains, two roundings) vs the real value               <= 2^-18.7 (sa_k + sb)
+//     so |(W_k + sb) - u_k| <= e_k := 2^-14 (sa_k + sb), clamp included (a clamped u_k has real value <= its own error).
+//  2. If k* is the canonical argmin then W_k* <= W_k + e_k* + e_k for every k, so k* -- and every k that ties with it --
+//     satisfies  W_k <= min_k W + DELTA,  DELTA = 3 * 2^-14 (max_k sa_k + sb)   (1.5x the bound, for the f32 roundings of
+//     the threshold itself).  Per lane the kernel keeps the running minimum b1, a copy of the 16 W values of the tile
+//     that holds it, and a bit mask of the tiles that came within DELTA of the running minimum at the time (a superset of
+//     the tiles within DELTA of the final one).
+//  3. REFINE: the candidates {W_k <= b1 + DELTA} -- 1.02 per vector on SIFT-like, 1.005 on Deep-like data -- get the
+//     canonical evaluation (oracle/rq_oracle.c: fmaf chains s = 0..sub-1 from +0, v = max(fl(fl(sa + sb) - 2g), 0)) on the
+//     VALU, and the smallest (v, index) pair wins: exactly the first-index argmin of the reference.  Tiles flagged in the
+//     mask are re-run through the matrix cores at the end (their W values are not kept), lanes whose bound is not usable
+//     (non-finite or vanishing norms) evaluate all their centroids exactly.
+// Nothing approximate reaches the output: the filter only decides WHICH centroids get the exact evaluation.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// bf16 round-to-nearest-even of a finite f32 (inf stays inf); returns the 16 payload bits
+__device__ __forceinline__ uint32_t bf16_bits(float x) {
+  const uint32_t u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_val(uint32_t b) { return __uint_as_float(b << 16); }
+
+struct SplitCfg {
+  static constexpr float DELTA_REL = 3.0f * 6.103515625e-05f;     // 3 * 2^-14
+  static constexpr float TINY = 8.673617379884035e-19f;            // 2^-60: below it bf16 flush-to-zero could matter
+};
+
+template <int SUB>
+struct SplitShape {
+  static_assert(SUB >= 2 && SUB <= 16 && SUB % 2 == 0, "split encode: even sub-space widths up to 16");
+  static constexpr bool PACK = SUB <= 8;          // hi and lo pieces of -2c share one K = 16 fragment
+  static constexpr int NPIECE = PACK ? 1 : 2;     // 16-byte A fragments per (tile, lane)
+};
+
+// canonical evaluation of centroid k of sub-quantizer `cb` for the sub-vector at xrow (oracle/rq_oracle.c:264-328) and
+// the lexicographic (v, index) update.  The sub-vector is re-read here (L1/L2: this lane streamed it a moment ago) instead
+// of being held in 16 registers across the filter's tile loop.
+template <int SUB>
+__device__ __forceinline__ void split_exact(const float *__restrict__ cb, int k, const float *__restrict__ xrow,
+                                            float &bv, int &bk) {
+  const f32x2 *c2 = reinterpret_cast<const f32x2 *>(cb + (size_t)k * SUB);
+  const f32x2 *x2 = reinterpret_cast<const f32x2 *>(xrow);
+  f32x2 c[SUB / 2], x[SUB / 2];
+#pragma unroll
+  for (int s2 = 0; s2 < SUB / 2; ++s2) { c[s2] = c2[s2]; x[s2] = x2[s2]; }
+  float g = 0.0f, sa = 0.0f, sb = 0.0f;
+#pragma unroll
+  for (int s2 = 0; s2 < SUB / 2; ++s2) {
+    g = __builtin_fmaf(c[s2].x, x[s2].x, g);
+    sa = __builtin_fmaf(c[s2].x, c[s2].x, sa);
+    sb = __builtin_fmaf(x[s2].x, x[s2].x, sb);
+    g = __builtin_fmaf(c[s2].y, x[s2].y, g);
+    sa = __builtin_fmaf(c[s2].y, c[s2].y, sa);
+    sb = __builtin_fmaf(x[s2].y, x[s2].y, sb);
+  }
+  const float t = sa + sb;
+  const float u = __builtin_fmaf(-2.0f, g, t);
+  const float v = __builtin_fmaxf(u, 0.0f);
+  if (v < bv || (v == bv && k < bk)) { bv = v; bk = k; }
+}
+
+// bit r of the result: v[r] <= thr  (v_cmp + v_addc per value: the carry shifts into the mask).  Only for values that
+// were produced by ordinary VALU instructions (see the note at the tile re-run below).
+__device__ __forceinline__ uint32_t mask_leq16(const f32x16 &v, float thr) {
+  uint32_t cm = 0;
+#pragma unroll
+  for (int r = 15; r >= 0; --r)
+    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(cm) : "v"(v[r]), "v"(thr) : "vcc");
+  return cm;
+}
+
+template <int SUB, int NT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams p) {
+  using Shape = SplitShape<SUB>;
+  constexpr bool PACK = Shape::PACK;
+  constexpr int NPIECE = Shape::NPIECE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int m = p.m, h = p.h, d = p.d;
+  const int i0 = p.i0, mg = p.i1 - p.i0;
+  uint4 *cbA = reinterpret_cast<uint4 *>(smem);                                   // [mg][NT][NPIECE][64] bf16x8 A fragments of -2c
+  float *saL = reinterpret_cast<float *>(cbA + (size_t)mg * NT * NPIECE * 64);    // [mg][NT][2][16] |c|^2, C/D-fragment order
+  float *saMax = saL + (size_t)mg * NT * 32;                                      // [mg] max_k |c_k|^2 (finite entries)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+
+  // ---- prologue: -2c split into bf16 pieces, in the A-fragment order of v_mfma_f32_32x32x16_bf16 (lane l: centroid
+  // l & 31, K elements 8 (l >> 5) .. + 7).  PACK: K elements 0-7 = hi pieces, 8-15 = lo pieces of dimensions 0-7. ----
+  for (int idx = tid; idx < mg * NT * NPIECE * 64; idx += NWAVES * 64) {
+    const int l = idx & 63;
+    int rest = idx >> 6;
+    const int piece = rest % NPIECE; rest /= NPIECE;
+    const int t = rest % NT;
+    const int il = rest / NT;
+    const int cen = t * 32 + (l & 31);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int sx = PACK ? e : 8 * (l >> 5) + e;            // dimension of this K element
+      const bool lo = PACK ? (l >> 5) != 0 : piece != 0;      // which bf16 piece
+      uint32_t bits = 0;
+      if (cen < h && sx < SUB) {
+        const float v = -2.0f * p.C[((size_t)(i0 + il) * h + cen) * SUB + sx];
+        const uint32_t hb = bf16_bits(v);
+        bits = lo ? bf16_bits(v - bf16_val(hb)) : hb;
+      }
+      w[e >> 1] |= bits << (16 * (e & 1));
+    }
+    cbA[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  for (int idx = tid; idx < mg * NT * 32; idx += NWAVES * 64) {
+    const int c32 = idx & 31;
+    const int t = (idx >> 5) % NT;
+    const int il = (idx >> 5) / NT;
+    const int cen = t * 32 + c32;
+    float sa = __uint_as_float(0x7f800000u);
+    if (cen < h) {
+      const float *c = p.C + ((size_t)(i0 + il) * h + cen) * SUB;
+      sa = 0.0f;
+#pragma unroll
+      for (int sx = 0; sx < SUB; ++sx) sa = __builtin_fmaf(c[sx], c[sx], sa);
+    }
+    const int hh = (c32 >> 2) & 1;
+    const int r = (c32 & 3) + 4 * (c32 >> 3);
+    saL[((size_t)(il * NT + t) * 2 + hh) * 16 + r] = sa;
+  }
+  __syncthreads();
+  for (int il = wave; il < mg; il += NWAVES) {       // max of the real centroids' norms, one wavefront per sub-quantizer
+    float mx = 0.0f;
+    for (int e = lane; e < NT * 32; e += 64) {
+      const float v = saL[(size_t)il * NT * 32 + e];
+      const int t = e >> 5, hh = (e >> 4) & 1, r = e & 15;
+      const int cen = t * 32 + 4 * hh + 8 * (r >> 2) + (r & 3);
+      if (cen < h) mx = __builtin_fmaxf(mx, v) + (v != v ? v : 0.0f);    // a NaN norm poisons the bound -> exact path
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float o = __shfl_xor(mx, off);
+      mx = (o != o || mx != mx) ? __uint_as_float(0x7fc00000u) : __builtin_fmaxf(mx, o);
+    }
+    if (lane == 0) saMax[il] = mx;
+  }
+  __syncthreads();
+
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t total_waves = (int64_t)gridDim.x * NWAVES;
+  const int64_t tile0 = (int64_t)blockIdx.x * NWAVES + wave;
+  f32x2 xn[SUB / 2];   // the sub-vector in flight (next (tile, sub-quantizer))
+  auto gload = [&](int64_t tile, int il) {
+    int64_t gr = tile * 32 + j;
+    if (gr >= p.n) gr = p.n - 1;
+    const f32x2 *src = reinterpret_cast<const f32x2 *>(p.X + gr * d + (size_t)(i0 + il) * SUB);
+#pragma unroll
+    for (int u = 0; u < SUB / 2; ++u) xn[u] = src[u];
+  };
+  if (tile0 < ntiles) gload(tile0, 0);
+
+  for (int64_t tile = tile0; tile < ntiles; tile += total_waves) {
+    const int64_t row0 = tile * 32;
+    uint64_t cw[4] = {0, 0, 0, 0};
+#pragma unroll 1
+    for (int il = 0; il < mg; ++il) {
+      const int i = i0 + il;
+      // |x|^2 (any summation order will do here: it only scales the filter's margin) and the B fragments: this lane's
+      // 8 K elements of x, split into bf16 pieces (v_cvt_pk_bf16_f32 rounds to nearest even)
+      f32x2 sel[4];
+      f32x2 sq = {0.0f, 0.0f};
+#pragma unroll
+      for (int u = 0; u < SUB / 2; ++u) sq = __builtin_elementwise_fma(xn[u], xn[u], sq);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if constexpr (PACK) sel[u] = u < SUB / 2 ? xn[u] : f32x2{0.0f, 0.0f};                      // both halves: dimensions 0-7
+        else sel[u] = hi ? (4 + u < SUB / 2 ? xn[4 + u < SUB / 2 ? 4 + u : 0] : f32x2{0.0f, 0.0f}) : xn[u];
+      }
+      uint32_t bh[4], bl[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#ifndef RQ_SPLIT_SWCVT
+        const bf16x2_t hb = __builtin_convertvector(sel[u], bf16x2_t);
+        const f32x2 rest = sel[u] - __builtin_convertvector(hb, f32x2);
+        bh[u] = __builtin_bit_cast(uint32_t, hb);
+        bl[u] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rest, bf16x2_t));
+#else
+        const uint32_t h0 = bf16_bits(sel[u].x), h1 = bf16_bits(sel[u].y);
+        bh[u] = h0 | (h1 << 16);
+        bl[u] = bf16_bits(sel[u].x - bf16_val(h0)) | (bf16_bits(sel[u].y - bf16_val(h1)) << 16);
+#endif
+      }
+      if (PACK && hi) { bl[0] = bl[1] = bl[2] = bl[3] = 0; }                // second MFMA: [xl | 0] against [ch | cl]
+      const bf16x8_t Bh = __builtin_bit_cast(bf16x8_t, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+      const bf16x8_t Bl = __builtin_bit_cast(bf16x8_t, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+      const float sb = sq.x + sq.y;
+      // the next sub-vector travels while this one is filtered (the refine step re-reads this one)
+      const int64_t tile_cur = tile;
+      if (il + 1 < mg) gload(tile, il + 1);
+      else if (tile + total_waves < ntiles) gload(tile + total_waves, 0);
+      const float smax = saMax[il];
+      const float ssum = smax + sb;
+      const float delta = SplitCfg::DELTA_REL * ssum;
+      // the bound needs finite, non-vanishing magnitudes; otherwise this lane evaluates all its centroids exactly
+      const bool slow = !(delta < __uint_as_float(0x7f800000u)) || !(ssum >= SplitCfg::TINY);
+
+      float b1 = __uint_as_float(0x7f800000u);   // running minimum of W over this lane's centroids
+      uint32_t t1bit = 1u;                       // 1 << (tile that holds it)
+      uint32_t extra = 0u;                       // tiles that came within delta of the running minimum
+      f32x16 ub;                                 // the 16 W values of the best tile
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ub[r] = 0.0f;
+      const uint4 *cb_i = cbA + (size_t)il * NT * NPIECE * 64 + lane;
+      const float4 *sa_i = reinterpret_cast<const float4 *>(saL + ((size_t)il * NT * 2 + hi) * 16);
+      auto tile_w = [&](int t) -> f32x16 {
+        const float4 *s4 = sa_i + (size_t)t * 8;
+        f32x16 acc;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float4 v = s4[g4];
+          acc[g4 * 4 + 0] = v.x; acc[g4 * 4 + 1] = v.y; acc[g4 * 4 + 2] = v.z; acc[g4 * 4 + 3] = v.w;
+        }
+        const bf16x8_t A0 = __builtin_bit_cast(bf16x8_t, cb_i[(size_t)t * NPIECE * 64]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bl, acc, 0, 0, 0);
+        if constexpr (!PACK) {
+          const bf16x8_t A1 = __builtin_bit_cast(bf16x8_t, cb_i[(size_t)t * NPIECE * 64 + 64]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bh, acc, 0, 0, 0);
+        }
+        return acc;
+      };
+      auto tile_min = [&](const f32x16 &a) -> float {
+        float m1 = __builtin_fminf(__builtin_fminf(a[0], a[1]), a[2]);
+        float m2 = __builtin_fminf(__builtin_fminf(a[3], a[4]), a[5]);
+        float m3 = __builtin_fminf(__builtin_fminf(a[6], a[7]), a[8]);
+        float m4 = __builtin_fminf(__builtin_fminf(a[9], a[10]), a[11]);
+        float m5 = __builtin_fminf(__builtin_fminf(a[12], a[13]), a[14]);
+        float mm = __builtin_fminf(__builtin_fminf(m1, m2), m3);
+        mm = __builtin_fminf(__builtin_fminf(mm, m4), m5);
+        return __builtin_fminf(mm, a[15]);
+      };
+      auto tile_filter = [&](const f32x16 &a, int t) {
+        const float mm = tile_min(a);
+        const bool imp = mm < b1;
+        const bool near = __builtin_fabsf(mm - b1) <= delta;       // (+inf - x: false; NaN: false)
+        extra |= near ? (imp ? t1bit : (1u << t)) : 0u;
+        if (imp) {
+          b1 = mm;
+          t1bit = 1u << t;
+          ub = a;
+        }
+      };
+      if constexpr (NWAVES >= 16) {
+        // four wavefronts per SIMD cover each other's MFMA latency: one accumulator set (128-register budget)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x16 acc = tile_w(t);
+          tile_filter(acc, t);
+        }
+      } else {
+        f32x16 accA = tile_w(0), accB;
+#pragma unroll
+        for (int t = 0; t < NT; t += 2) {
+          if (t + 1 < NT) accB = tile_w(t + 1);
+          tile_filter(accA, t);
+          if (t + 2 < NT) accA = tile_w(t + 2);
+          if (t + 1 < NT) tile_filter(accB, t + 1);
+        }
+      }
+
+      // ---- refine: canonical evaluation of the candidates --------------------------------------------------------
+      const float *cb = p.C + (size_t)i * h * SUB;
+      int64_t gr_cur = tile_cur * 32 + j;
+      if (gr_cur >= p.n) gr_cur = p.n - 1;
+      const float *xrow = p.X + gr_cur * d + (size_t)i * SUB;
+      float bv = __uint_as_float(0x7f800000u);
+      int bk = 0;
+      const float bo = __shfl_xor(b1, 32);                         // the other half of this vector's centroids
+      const float thr = __builtin_fminf(b1, bo) + delta;
+      const bool contend = b1 <= thr;
+      const int cbase = 4 * hi;                                    // centroid of (tile t, register r): 32 t + 4 hi + 8 (r >> 2) + (r & 3)
+      {
+        uint32_t cm = mask_leq16(ub, thr);
+        if (!contend || slow) cm = 0;
+        const int t1 = 31 - __builtin_clz(t1bit);
+        while (__ballot(cm != 0u)) {
+          if (cm != 0u) {
+            const int r = __builtin_ctz(cm);
+            cm &= cm - 1u;
+            const int k = t1 * 32 + cbase + 8 * (r >> 2) + (r & 3);
+            if (k < h) split_exact<SUB>(cb, k, xrow, bv, bk);
+          }
+        }
+      }
+      // tiles that came within delta of the running minimum: their W values were not kept -- once more through the
+      // matrix cores, wave-uniform tile by tile (the best tile itself is covered by the copy above)
+      uint32_t todo = (contend && !slow) ? (extra & ~t1bit) : 0u;
+      for (;;) {
+        const uint64_t any = __ballot(todo != 0u);
+        if (!any) break;
+        uint32_t all = todo;                                       // OR over the wavefront
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) all |= (uint32_t)__shfl_xor((int)all, off);
+        const int T = __builtin_ctz(__builtin_amdgcn_readfirstlane(all));
+        const f32x16 acc = tile_w(T);
+        // (plain C here: the hazard recogniser does not look inside inline asm, and an asm compare issued straight after
+        // the MFMA read stale accumulator registers now and then -- 2 to 12 wrong codes per 1e7, different ones every run)
+        uint32_t cm = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cm |= (acc[r] <= thr) ? (1u << r) : 0u;
+        if (!((todo >> T) & 1u)) cm = 0;
+        todo &= ~(1u << T);
+        while (__ballot(cm != 0u)) {
+          if (cm != 0u) {
+            const int r = __builtin_ctz(cm);
+            cm &= cm - 1u;
+            const int k = T * 32 + cbase + 8 * (r >> 2) + (r & 3);
+            if (k < h) split_exact<SUB>(cb, k, xrow, bv, bk);
+          }
+        }
+      }
+      // lanes without a usable bound: every centroid of this lane, exactly
+      if (__ballot(slow)) {
+        if (slow) {
+#pragma unroll 1
+          for (int kk = 0; kk < NT * 16; ++kk) {
+            const int k = (kk >> 4) * 32 + cbase + 8 * ((kk & 15) >> 2) + (kk & 3);
+            if (k < h) split_exact<SUB>(cb, k, xrow, bv, bk);
+          }
+        }
+      }
+      // the two half-waves hold disjoint centroid subsets of the same vector
+      const float ov = __shfl_xor(bv, 32);
+      const int ok = __shfl_xor(bk, 32);
+      if (ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if ((i >> 3) == w) cw[w] |= (uint64_t)(uint32_t)bk << (8 * (i & 7));
+    }
+    if (hi == 0 && row0 + j < p.n) {
+      uint8_t *o = p.codes + (size_t)(row0 + j) * m;
+      if ((m & 7) == 0 && mg == m) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          if (w * 8 < m) reinterpret_cast<uint64_t *>(o)[w] = cw[w];
+      } else {
+        for (int i = i0; i < p.i1; ++i) o[i] = (uint8_t)(cw[i >> 3] >> (8 * (i & 7)));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Wide sub-spaces (sub > 64 that are not exactly 96 / 128 wide, or whose codebook does not fit LDS:
 // PQ on GIST-960 / MNIST-784, RVQ / k-means assignment at any d).  The work is one flat sequence of
 // chunks (tile group, sub-quantizer, KC k-steps of the sub-space).  While the MFMAs of a chunk run,
@@ -839,6 +1202,28 @@ static int launch_encode(EncParams p, int num_cu, hipStream_t stream) {
   return RQ_OK;
 }
 
+template <int SUB, int NT, int NWAVES>
+static int launch_encode_split(EncParams p, int num_cu, hipStream_t stream) {
+  p.NT = NT;
+  constexpr int NPIECE = SplitShape<SUB>::NPIECE;
+  const size_t per_sub = (size_t)NT * NPIECE * 64 * 16 + (size_t)NT * 32 * sizeof(float) + sizeof(float);
+  const size_t budget = 160 * 1024 - 64;
+  const int gmax = (int)std::min<size_t>(budget / per_sub, (size_t)p.m);
+  if (gmax < 1) return fail(RQ_EUNSUPPORTED, "split encode: one sub-codebook needs %zu B of LDS", per_sub);
+  auto kern = encode_pq_split_kernel<SUB, NT, NWAVES>;
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int grid = (int)std::min<int64_t>(num_cu, (ntiles + NWAVES - 1) / NWAVES);
+  for (int i0 = 0; i0 < p.m; i0 += gmax) {
+    p.i0 = i0;
+    p.i1 = std::min(p.m, i0 + gmax);
+    const size_t lds = per_sub * (size_t)(p.i1 - p.i0) + 64;
+    RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, p);
+    RQ_HIP(hipGetLastError());
+  }
+  return RQ_OK;
+}
+
 int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m, int h,
                   int num_cu, hipStream_t stream) {
   if (n <= 0) return RQ_OK;
@@ -860,6 +1245,26 @@ int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int
   const int ks = (maxsub + 1) / 2;
   const int nw = tuning("ENC_WAVES", 16);
   const int nt = (h + 31) / 32;
+  // even sub-space widths up to 16 (BASELINE's 16 and 6): bf16 matrix-core filter + exact re-evaluation of the candidates
+  if (tuning("ENC_SPLIT", 1) && (d % m == 0) && (d / m) % 2 == 0 && d / m <= 16 && (((uintptr_t)X & 7) == 0)) {
+    const int sw = tuning("ENC_SPLIT_WAVES", 0);
+#define RQ_SPLIT_NT(SUBV, NW)                                                        \
+  do {                                                                               \
+    if (nt <= 1) return launch_encode_split<SUBV, 1, NW>(p, num_cu, stream);           \
+    if (nt <= 2) return launch_encode_split<SUBV, 2, NW>(p, num_cu, stream);           \
+    if (nt <= 4) return launch_encode_split<SUBV, 4, NW>(p, num_cu, stream);           \
+    return launch_encode_split<SUBV, 8, NW>(p, num_cu, stream);                        \
+  } while (0)
+#define RQ_SPLIT_CASE(SUBV)                                                          \
+  if (d / m == SUBV) {                                                               \
+    if (sw == 8) RQ_SPLIT_NT(SUBV, 8);                                               \
+    RQ_SPLIT_NT(SUBV, 16);                                                           \
+  }
+    RQ_SPLIT_CASE(2) RQ_SPLIT_CASE(4) RQ_SPLIT_CASE(6) RQ_SPLIT_CASE(8)
+    RQ_SPLIT_CASE(10) RQ_SPLIT_CASE(12) RQ_SPLIT_CASE(14) RQ_SPLIT_CASE(16)
+#undef RQ_SPLIT_CASE
+#undef RQ_SPLIT_NT
+  }
 #define RQ_ENC_NT(KSV, NW, DIR)                                             \
   do {                                                                     \
     if (nt <= 1) return launch_encode<KSV, 1, NW, DIR>(p, num_cu, stream);  \

@@ -4,7 +4,7 @@ R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="encode --iters 3"
+ARGS="encode --iters 3 ${ENC_ARGS}"
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/p1 -o p -- python $R/tools/perf.py $ARGS > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/p2 -o p -- python $R/tools/perf.py $ARGS > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/p3 -o p -- python $R/tools/perf.py $ARGS > /dev/null 2>&1
