@@ -421,6 +421,13 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_direct_kernel(EncParams
 //     (non-finite or vanishing norms) evaluate all their centroids exactly.
 // Nothing approximate reaches the output: the filter only decides WHICH centroids get the exact evaluation.
 // ------------------------------------------------------------------------------------------
+// lanes 32-63 of a  <->  lanes 0-31 of b   (v_permlane32_swap_b32)
+__device__ __forceinline__ void swap32(float &a, float &b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
@@ -431,6 +438,9 @@ __device__ __forceinline__ uint32_t bf16_bits(float x) {
 }
 __device__ __forceinline__ float bf16_val(uint32_t b) { return __uint_as_float(b << 16); }
 
+#ifndef RQ_SPLIT_SINGLE_ACC
+#define RQ_SPLIT_SINGLE_ACC 0
+#endif
 struct SplitCfg {
   static constexpr float DELTA_REL = 3.0f * 6.103515625e-05f;     // 3 * 2^-14
   static constexpr float TINY = 8.673617379884035e-19f;            // 2^-60: below it bf16 flush-to-zero could matter
@@ -443,27 +453,25 @@ struct SplitShape {
   static constexpr int NPIECE = PACK ? 1 : 2;     // 16-byte A fragments per (tile, lane)
 };
 
-// canonical evaluation of centroid k of sub-quantizer `cb` for the sub-vector at xrow (oracle/rq_oracle.c:264-328) and
-// the lexicographic (v, index) update.  The sub-vector is re-read here (L1/L2: this lane streamed it a moment ago) instead
-// of being held in 16 registers across the filter's tile loop.
+// canonical evaluation of centroid k of sub-quantizer `cb` (oracle/rq_oracle.c:264-328): g = fmaf chain s = 0..sub-1 from
+// +0, sa = |c_k|^2 (the same chain, computed once in the prologue: sa_k), v = max(fl(fl(sa + sb) - 2g), 0); then the
+// lexicographic (v, index) update.
 template <int SUB>
-__device__ __forceinline__ void split_exact(const float *__restrict__ cb, int k, const float *__restrict__ xrow,
+__device__ __forceinline__ void split_exact(const float *__restrict__ cb, int k, const float (&x)[SUB], float sb, float sa,
                                             float &bv, int &bk) {
-  const f32x2 *c2 = reinterpret_cast<const f32x2 *>(cb + (size_t)k * SUB);
-  const f32x2 *x2 = reinterpret_cast<const f32x2 *>(xrow);
-  f32x2 c[SUB / 2], x[SUB / 2];
+  float c[SUB];
+  if constexpr (SUB % 4 == 0) {
+    const float4 *c4 = reinterpret_cast<const float4 *>(cb + (size_t)k * SUB);
 #pragma unroll
-  for (int s2 = 0; s2 < SUB / 2; ++s2) { c[s2] = c2[s2]; x[s2] = x2[s2]; }
-  float g = 0.0f, sa = 0.0f, sb = 0.0f;
+    for (int s4 = 0; s4 < SUB / 4; ++s4) { const float4 v = c4[s4]; c[4 * s4] = v.x; c[4 * s4 + 1] = v.y; c[4 * s4 + 2] = v.z; c[4 * s4 + 3] = v.w; }
+  } else {
+    const f32x2 *c2 = reinterpret_cast<const f32x2 *>(cb + (size_t)k * SUB);
 #pragma unroll
-  for (int s2 = 0; s2 < SUB / 2; ++s2) {
-    g = __builtin_fmaf(c[s2].x, x[s2].x, g);
-    sa = __builtin_fmaf(c[s2].x, c[s2].x, sa);
-    sb = __builtin_fmaf(x[s2].x, x[s2].x, sb);
-    g = __builtin_fmaf(c[s2].y, x[s2].y, g);
-    sa = __builtin_fmaf(c[s2].y, c[s2].y, sa);
-    sb = __builtin_fmaf(x[s2].y, x[s2].y, sb);
+    for (int s2 = 0; s2 < SUB / 2; ++s2) { const f32x2 v = c2[s2]; c[2 * s2] = v.x; c[2 * s2 + 1] = v.y; }
   }
+  float g = 0.0f;
+#pragma unroll
+  for (int sx = 0; sx < SUB; ++sx) g = __builtin_fmaf(c[sx], x[sx], g);
   const float t = sa + sb;
   const float u = __builtin_fmaf(-2.0f, g, t);
   const float v = __builtin_fmaxf(u, 0.0f);
@@ -555,13 +563,30 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams 
   const int64_t ntiles = (p.n + 31) / 32;
   const int64_t total_waves = (int64_t)gridDim.x * NWAVES;
   const int64_t tile0 = (int64_t)blockIdx.x * NWAVES + wave;
-  f32x2 xn[SUB / 2];   // the sub-vector in flight (next (tile, sub-quantizer))
+  // The lane's 8 K elements of the sub-vector in flight (next (tile, sub-quantizer)): dimensions 8 hi .. 8 hi + 7 (PACK:
+  // dimensions 0 .. 7 in both halves) -- 32 contiguous bytes per lane, two 16-byte loads where the rows allow it.  (Loading
+  // the whole sub-vector 8 bytes at a time, as the f32 kernel does, costs 8 wave-wide loads of 32 cache lines each per
+  // sub-quantizer; at this kernel's pace the texture-address unit became the bound: 0.47 ms for loads + MFMAs alone.)
+  constexpr int NPAIR = PACK ? SUB / 2 : 4;         // f32x2 slots per lane
+  const int my_pairs = PACK ? SUB / 2 : (hi ? (SUB - 8) / 2 : 4);
+  const bool vec4 = (d % 4 == 0) && (((uintptr_t)p.X & 15) == 0) && (SUB % 4 == 0);
+  f32x2 xn[NPAIR];
   auto gload = [&](int64_t tile, int il) {
     int64_t gr = tile * 32 + j;
     if (gr >= p.n) gr = p.n - 1;
-    const f32x2 *src = reinterpret_cast<const f32x2 *>(p.X + gr * d + (size_t)(i0 + il) * SUB);
+    const float *src = p.X + gr * d + (size_t)(i0 + il) * SUB + (PACK ? 0 : 8 * hi);
+    if (vec4) {
 #pragma unroll
-    for (int u = 0; u < SUB / 2; ++u) xn[u] = src[u];
+      for (int u = 0; u < NPAIR; u += 2) {
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (u < my_pairs) v = *reinterpret_cast<const float4 *>(src + 2 * u);
+        xn[u] = f32x2{v.x, v.y};
+        if (u + 1 < NPAIR) xn[u + 1] = f32x2{v.z, v.w};
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NPAIR; ++u) xn[u] = u < my_pairs ? *reinterpret_cast<const f32x2 *>(src + 2 * u) : f32x2{0.0f, 0.0f};
+    }
   };
   if (tile0 < ntiles) gload(tile0, 0);
 
@@ -576,12 +601,9 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams 
       f32x2 sel[4];
       f32x2 sq = {0.0f, 0.0f};
 #pragma unroll
-      for (int u = 0; u < SUB / 2; ++u) sq = __builtin_elementwise_fma(xn[u], xn[u], sq);
+      for (int u = 0; u < NPAIR; ++u) sq = __builtin_elementwise_fma(xn[u], xn[u], sq);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if constexpr (PACK) sel[u] = u < SUB / 2 ? xn[u] : f32x2{0.0f, 0.0f};                      // both halves: dimensions 0-7
-        else sel[u] = hi ? (4 + u < SUB / 2 ? xn[4 + u < SUB / 2 ? 4 + u : 0] : f32x2{0.0f, 0.0f}) : xn[u];
-      }
+      for (int u = 0; u < 4; ++u) sel[u] = u < NPAIR ? xn[u < NPAIR ? u : 0] : f32x2{0.0f, 0.0f};
       uint32_t bh[4], bl[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -599,9 +621,12 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams 
       if (PACK && hi) { bl[0] = bl[1] = bl[2] = bl[3] = 0; }                // second MFMA: [xl | 0] against [ch | cl]
       const bf16x8_t Bh = __builtin_bit_cast(bf16x8_t, make_uint4(bh[0], bh[1], bh[2], bh[3]));
       const bf16x8_t Bl = __builtin_bit_cast(bf16x8_t, make_uint4(bl[0], bl[1], bl[2], bl[3]));
-      const float sb = sq.x + sq.y;
-      // the next sub-vector travels while this one is filtered (the refine step re-reads this one)
-      const int64_t tile_cur = tile;
+      float sb = sq.x + sq.y;
+      if constexpr (!PACK) sb += __shfl_xor(sb, 32);       // the other half-wave holds dimensions 8..15
+      f32x2 xc[NPAIR];                                     // this lane's share of the sub-vector, kept for the refine step
+#pragma unroll
+      for (int u = 0; u < NPAIR; ++u) xc[u] = xn[u];
+      // the next sub-vector travels while this one is filtered
       if (il + 1 < mg) gload(tile, il + 1);
       else if (tile + total_waves < ntiles) gload(tile + total_waves, 0);
       const float smax = saMax[il];
@@ -626,6 +651,7 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams 
           const float4 v = s4[g4];
           acc[g4 * 4 + 0] = v.x; acc[g4 * 4 + 1] = v.y; acc[g4 * 4 + 2] = v.z; acc[g4 * 4 + 3] = v.w;
         }
+#if !defined(RQ_SPLIT_ABL) || RQ_SPLIT_ABL != 3
         const bf16x8_t A0 = __builtin_bit_cast(bf16x8_t, cb_i[(size_t)t * NPIECE * 64]);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bl, acc, 0, 0, 0);
@@ -633,6 +659,9 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams 
           const bf16x8_t A1 = __builtin_bit_cast(bf16x8_t, cb_i[(size_t)t * NPIECE * 64 + 64]);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bh, acc, 0, 0, 0);
         }
+#else
+        acc[0] += __uint_as_float(bh[0] ^ bl[1]);
+#endif
         return acc;
       };
       auto tile_min = [&](const f32x16 &a) -> float {
@@ -646,6 +675,9 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams 
         return __builtin_fminf(mm, a[15]);
       };
       auto tile_filter = [&](const f32x16 &a, int t) {
+#if defined(RQ_SPLIT_ABL) && RQ_SPLIT_ABL == 4
+        b1 = __builtin_fminf(b1, a[t & 15]); return;
+#endif
         const float mm = tile_min(a);
         const bool imp = mm < b1;
         const bool near = __builtin_fabsf(mm - b1) <= delta;       // (+inf - x: false; NaN: false)
@@ -653,10 +685,18 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams 
         if (imp) {
           b1 = mm;
           t1bit = 1u << t;
-          ub = a;
+          // eight 64-bit moves under the exec mask.  (Written as `ub = a` the compiler if-converts the copy into 16-18
+          // v_cndmask per tile -- a third of the loop's VALU time.  The asm reads accumulator registers that tile_min's
+          // compiler-scheduled reads have already waited for, so no MFMA hazard is left open here.)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            f32x2 src = {a[r], a[r + 1]}, dst;
+            asm volatile("v_mov_b64 %0, %1" : "=v"(dst) : "v"(src));
+            ub[r] = dst.x; ub[r + 1] = dst.y;
+          }
         }
       };
-      if constexpr (NWAVES >= 16) {
+      if constexpr (NWAVES >= 16 && RQ_SPLIT_SINGLE_ACC) {
         // four wavefronts per SIMD cover each other's MFMA latency: one accumulator set (128-register budget)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -676,54 +716,83 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams 
 
       // ---- refine: canonical evaluation of the candidates --------------------------------------------------------
       const float *cb = p.C + (size_t)i * h * SUB;
-      int64_t gr_cur = tile_cur * 32 + j;
-      if (gr_cur >= p.n) gr_cur = p.n - 1;
-      const float *xrow = p.X + gr_cur * d + (size_t)i * SUB;
       float bv = __uint_as_float(0x7f800000u);
       int bk = 0;
-      const float bo = __shfl_xor(b1, 32);                         // the other half of this vector's centroids
+      float bo_a = b1, bo_b = b1;                                  // the other half of this vector's centroids
+      swap32(bo_a, bo_b);
+      const float bo = hi ? bo_a : bo_b;
       const float thr = __builtin_fminf(b1, bo) + delta;
       const bool contend = b1 <= thr;
       const int cbase = 4 * hi;                                    // centroid of (tile t, register r): 32 t + 4 hi + 8 (r >> 2) + (r & 3)
-      {
-        uint32_t cm = mask_leq16(ub, thr);
-        if (!contend || slow) cm = 0;
-        const int t1 = 31 - __builtin_clz(t1bit);
-        while (__ballot(cm != 0u)) {
-          if (cm != 0u) {
-            const int r = __builtin_ctz(cm);
-            cm &= cm - 1u;
-            const int k = t1 * 32 + cbase + 8 * (r >> 2) + (r & 3);
-            if (k < h) split_exact<SUB>(cb, k, xrow, bv, bk);
-          }
+#if defined(RQ_SPLIT_ABL) && RQ_SPLIT_ABL >= 2
+      uint32_t cm = 0;
+      bk = 31 - __builtin_clz(t1bit); bv = b1;
+#else
+      uint32_t cm = mask_leq16(ub, thr);
+#endif
+      if (!contend || slow) cm = 0;
+      const int t1 = 31 - __builtin_clz(t1bit);
+#if defined(RQ_SPLIT_ABL) && RQ_SPLIT_ABL >= 1
+      if (cm) { bk = t1 * 32 + __builtin_ctz(cm); bv = b1; }
+      cm = 0; extra = 0;
+#endif
+      // the whole sub-vector in every lane: the other half-wave's 8 dimensions come over by v_permlane32_swap; then
+      // the canonical |x|^2 (chain s = 0..sub-1 from +0)
+      float x[SUB];
+      if constexpr (PACK) {
+#pragma unroll
+        for (int u = 0; u < SUB / 2; ++u) { x[2 * u] = xc[u].x; x[2 * u + 1] = xc[u].y; }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float lo0 = xc[u].x, hi0 = xc[u].x, lo1 = xc[u].y, hi1 = xc[u].y;
+          swap32(lo0, hi0);       // lo0: dimension 2u of the vector in all lanes; hi0: dimension 8 + 2u
+          swap32(lo1, hi1);
+          x[2 * u] = lo0; x[2 * u + 1] = lo1;
+          if (8 + 2 * u < SUB) { x[8 + 2 * u] = hi0; x[8 + 2 * u + 1] = hi1; }
+        }
+      }
+      float sbx = 0.0f;
+#pragma unroll
+      for (int sx = 0; sx < SUB; ++sx) sbx = __builtin_fmaf(x[sx], x[sx], sbx);
+      // |c_k|^2 of centroid k from the C/D-ordered norm table of the prologue
+      const float *sa_il = saL + (size_t)il * NT * 32;
+      auto sa_of = [&](int k) -> float {
+        const int c32 = k & 31;
+        return sa_il[((k >> 5) * 2 + ((c32 >> 2) & 1)) * 16 + (c32 & 3) + 4 * (c32 >> 3)];
+      };
+      while (__ballot(cm != 0u)) {
+        if (cm != 0u) {
+          const int r = __builtin_ctz(cm);
+          cm &= cm - 1u;
+          const int k = t1 * 32 + cbase + 8 * (r >> 2) + (r & 3);
+          if (k < h) split_exact<SUB>(cb, k, x, sbx, sa_of(k), bv, bk);
         }
       }
       // tiles that came within delta of the running minimum: their W values were not kept -- once more through the
       // matrix cores, wave-uniform tile by tile (the best tile itself is covered by the copy above)
       uint32_t todo = (contend && !slow) ? (extra & ~t1bit) : 0u;
-      for (;;) {
-        const uint64_t any = __ballot(todo != 0u);
-        if (!any) break;
-        uint32_t all = todo;                                       // OR over the wavefront
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) all |= (uint32_t)__shfl_xor((int)all, off);
-        const int T = __builtin_ctz(__builtin_amdgcn_readfirstlane(all));
+      if (__ballot(todo != 0u)) {                                  // (no lane of the wavefront in ~60 % of the cases)
+#pragma unroll 1
+      for (int T = 0; T < NT; ++T) {
+        if (!__ballot((todo >> T) & 1u)) continue;
         const f32x16 acc = tile_w(T);
         // (plain C here: the hazard recogniser does not look inside inline asm, and an asm compare issued straight after
         // the MFMA read stale accumulator registers now and then -- 2 to 12 wrong codes per 1e7, different ones every run)
-        uint32_t cm = 0;
+        uint32_t cm2 = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cm |= (acc[r] <= thr) ? (1u << r) : 0u;
-        if (!((todo >> T) & 1u)) cm = 0;
+        for (int r = 0; r < 16; ++r) cm2 |= (acc[r] <= thr) ? (1u << r) : 0u;
+        if (!((todo >> T) & 1u)) cm2 = 0;
         todo &= ~(1u << T);
-        while (__ballot(cm != 0u)) {
-          if (cm != 0u) {
-            const int r = __builtin_ctz(cm);
-            cm &= cm - 1u;
+        while (__ballot(cm2 != 0u)) {
+          if (cm2 != 0u) {
+            const int r = __builtin_ctz(cm2);
+            cm2 &= cm2 - 1u;
             const int k = T * 32 + cbase + 8 * (r >> 2) + (r & 3);
-            if (k < h) split_exact<SUB>(cb, k, xrow, bv, bk);
+            if (k < h) split_exact<SUB>(cb, k, x, sbx, sa_of(k), bv, bk);
           }
         }
+      }
       }
       // lanes without a usable bound: every centroid of this lane, exactly
       if (__ballot(slow)) {
@@ -731,13 +800,16 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams 
 #pragma unroll 1
           for (int kk = 0; kk < NT * 16; ++kk) {
             const int k = (kk >> 4) * 32 + cbase + 8 * ((kk & 15) >> 2) + (kk & 3);
-            if (k < h) split_exact<SUB>(cb, k, xrow, bv, bk);
+            if (k < h) split_exact<SUB>(cb, k, x, sbx, sa_of(k), bv, bk);
           }
         }
       }
       // the two half-waves hold disjoint centroid subsets of the same vector
-      const float ov = __shfl_xor(bv, 32);
-      const int ok = __shfl_xor(bk, 32);
+      float ov_a = bv, ov_b = bv, ok_a = __int_as_float(bk), ok_b = __int_as_float(bk);
+      swap32(ov_a, ov_b);
+      swap32(ok_a, ok_b);
+      const float ov = hi ? ov_a : ov_b;
+      const int ok = __float_as_int(hi ? ok_a : ok_b);
       if (ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
 #pragma unroll
       for (int w = 0; w < 4; ++w)
@@ -1076,13 +1148,6 @@ __global__ __launch_bounds__(NWAVES * 64) void rotate_wide_kernel(RotParams p) {
   }
 }
 
-// lanes 32-63 of a  <->  lanes 0-31 of b   (v_permlane32_swap_b32)
-__device__ __forceinline__ void swap32(float &a, float &b) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  a = __uint_as_float(r[0]);
-  b = __uint_as_float(r[1]);
-}
-
 // Rotation, fast path for d % 8 == 0 (KK = d/2 compile time): the 32 x d tile of X never touches
 // LDS.  Lane (j, hi) loads the 16-byte pieces X[j][8q + 4hi .. +3]; two v_permlane32_swap per piece
 // pair turn them into the B fragments of k-steps 4q..4q+3 (lanes 0-31 the even, 32-63 the odd
@@ -1258,6 +1323,7 @@ int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int
 #define RQ_SPLIT_CASE(SUBV)                                                          \
   if (d / m == SUBV) {                                                               \
     if (sw == 8) RQ_SPLIT_NT(SUBV, 8);                                               \
+    if (sw == 12 || (sw == 0 && SUBV > 8)) RQ_SPLIT_NT(SUBV, 12);                    \
     RQ_SPLIT_NT(SUBV, 16);                                                           \
   }
     RQ_SPLIT_CASE(2) RQ_SPLIT_CASE(4) RQ_SPLIT_CASE(6) RQ_SPLIT_CASE(8)

@@ -4,7 +4,7 @@ f32-MFMA kernel (ENC_SPLIT=0), for the SIFT1M and Deep1M shapes."""
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import rayuela_jl_amd as rq
 import rayuela_jl_amd.synth as synth
 import rayuela_jl_amd.synth_torch as st
@@ -42,7 +42,7 @@ for kind in sys.argv[1:] or ["sift", "deep"]:
     t0 = bench(lambda: rqd.encode_pq(X, Ccat, m, h, out=out))
     print("%s f32-MFMA kernel          %.4f ms" % (kind, t0))
     rq.set_tuning("ENC_SPLIT", 1)
-    for w in (16, 8):
+    for w in (16, 12, 8):
         rq.set_tuning("ENC_SPLIT_WAVES", w)
         got = rqd.encode_pq(X, Ccat, m, h)
         torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import rayuela_jl_amd as rq
 import rayuela_jl_amd.synth as synth
 import rayuela_jl_amd.synth_torch as st

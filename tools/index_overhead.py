@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import rayuela_jl_amd as rq                      # noqa: E402
 import rayuela_jl_amd.synth as synth             # noqa: E402
 
