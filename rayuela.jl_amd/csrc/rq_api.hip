@@ -495,7 +495,14 @@ static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const
   DevBuf dcodes, dcent, dq, dr, drq, dd, di_;
   const size_t cb = (size_t)n * m, ce = (size_t)m * 256 * (d / m) * 4, qb = (size_t)nq * d * 4;
   RQ_TRY(dcodes.alloc(cb)); RQ_TRY(dcent.alloc(ce)); RQ_TRY(dq.alloc(qb));
-  const bool direct = tuning("HOST_DIRECT", 1) && host_pool_owns(dists, (size_t)nq * k * 4) && host_pool_owns(ids, (size_t)nq * k * 4);
+  // Results in the library's page-locked arrays: the kernel can store them over PCIe itself (one launch, no copy back:
+  // 3.6 vs 3.8 ms at k = 1000).  Kernel stores cross PCIe at ~36 GB/s, the copy engine at ~45: from HOST_DIRECT_MAX_MB
+  // (256) of results on -- k = 10000: 800 MB -- chunked scans with copy-engine transfers behind them win (22.2 -> 20.0 ms;
+  // the floor is 800 MB / ~52 GB/s = 15.4 ms of PCIe plus the first chunk's scan).
+  const size_t res_bytes = (size_t)nq * k * 8;
+  const size_t direct_max = (size_t)(tuning("HOST_DIRECT_MAX_MB", 0) > 0 ? tuning("HOST_DIRECT_MAX_MB", 0) : 256) << 20;
+  const bool direct = tuning("HOST_DIRECT", 1) && res_bytes <= direct_max && host_pool_owns(dists, (size_t)nq * k * 4) &&
+                      host_pool_owns(ids, (size_t)nq * k * 4);
   if (!direct) { RQ_TRY(dd.alloc((size_t)nq * k * 4)); RQ_TRY(di_.alloc((size_t)nq * k * 4)); }
   Timer t1;
   RQ_HIP(hipMemcpy(dcodes.p, codes, cb, hipMemcpyHostToDevice));
@@ -540,7 +547,14 @@ static int host_linscan_aq(float *dists, uint32_t *ids, const uint8_t *codes, co
   DevBuf dcodes, dcb, dq, dn, dr, drq, dd, di_;
   const size_t cb = (size_t)n * m, ce = (size_t)m * 256 * d * 4, qb = (size_t)nq * d * 4;
   RQ_TRY(dcodes.alloc(cb)); RQ_TRY(dcb.alloc(ce)); RQ_TRY(dq.alloc(qb));
-  const bool direct = tuning("HOST_DIRECT", 1) && host_pool_owns(dists, (size_t)nq * k * 4) && host_pool_owns(ids, (size_t)nq * k * 4);
+  // Results in the library's page-locked arrays: the kernel can store them over PCIe itself (one launch, no copy back:
+  // 3.6 vs 3.8 ms at k = 1000).  Kernel stores cross PCIe at ~36 GB/s, the copy engine at ~45: from HOST_DIRECT_MAX_MB
+  // (256) of results on -- k = 10000: 800 MB -- chunked scans with copy-engine transfers behind them win (22.2 -> 20.0 ms;
+  // the floor is 800 MB / ~52 GB/s = 15.4 ms of PCIe plus the first chunk's scan).
+  const size_t res_bytes = (size_t)nq * k * 8;
+  const size_t direct_max = (size_t)(tuning("HOST_DIRECT_MAX_MB", 0) > 0 ? tuning("HOST_DIRECT_MAX_MB", 0) : 256) << 20;
+  const bool direct = tuning("HOST_DIRECT", 1) && res_bytes <= direct_max && host_pool_owns(dists, (size_t)nq * k * 4) &&
+                      host_pool_owns(ids, (size_t)nq * k * 4);
   if (!direct) { RQ_TRY(dd.alloc((size_t)nq * k * 4)); RQ_TRY(di_.alloc((size_t)nq * k * 4)); }
   Timer t1;
   RQ_HIP(hipMemcpy(dcodes.p, codes, cb, hipMemcpyHostToDevice));

@@ -163,3 +163,88 @@ def test_resident_dataset_encodes_match_the_host_calls(rq, oracle):
         assert np.array_equal(ds.quantize(C, R=R), rq.quantize_opq(X, R, C))
         assert np.array_equal(ds.quantize(C2, one_based=False), oracle.encode_pq(X, synth.cat_codebooks(C2), 8, 64))
         assert np.array_equal(ds.quantize(C), rq.quantize_pq(X, C))        # X itself is untouched by the OPQ call
+
+
+# ---- encode_pq_split_kernel: bf16 matrix-core filter + exact re-evaluation of the candidates ----------------------------
+def _enc_both(rq, oracle, X, C, m, h):
+    """codes of the split kernel (default for even sub-space widths <= 16), of the f32-MFMA kernel and of the oracle"""
+    Ccat = np.concatenate([np.ascontiguousarray(c, dtype=np.float32).reshape(-1) for c in C])
+    ref = oracle.encode_pq(X, Ccat, m, h)
+    got = rq.quantize_pq_u8(X, C)
+    rq.set_tuning("ENC_SPLIT", 0)
+    try:
+        old = rq.quantize_pq_u8(X, C)
+    finally:
+        rq.set_tuning("ENC_SPLIT", 1)
+    return got, old, ref
+
+
+@pytest.mark.parametrize("sub", [2, 4, 6, 8, 10, 12, 14, 16])
+@pytest.mark.parametrize("h", [256, 200, 33])
+def test_split_encode_every_width_and_codebook_size(rq, oracle, sub, h):
+    rng = np.random.default_rng(100 * sub + h)
+    m, n = 4, 4_099                        # ragged last tile
+    X = rng.standard_normal((n, m * sub)).astype(np.float32) * 3
+    C = [rng.standard_normal((h, sub)).astype(np.float32) * 3 for _ in range(m)]
+    got, old, ref = _enc_both(rq, oracle, X, C, m, h)
+    assert np.array_equal(got, ref) and np.array_equal(old, ref)
+
+
+@pytest.mark.parametrize("waves", [8, 12, 16])
+@pytest.mark.parametrize("case", ["ties", "dups", "exact_hits", "tiny", "huge", "mixed_scale", "negative_w"])
+def test_split_encode_hostile_inputs(rq, oracle, case, waves):
+    """What the filter's margin has to survive: massive exact ties (small-integer data: several centroids at the very
+    same distance, in different 32-centroid tiles -> tiles re-run at the end, first index must win), duplicated
+    centroids, vectors that ARE centroids (clamped zeros), magnitudes where the bound is unusable (every centroid is then
+    evaluated exactly), wide dynamic range inside one sub-space."""
+    rng = np.random.default_rng({"ties": 1, "dups": 2, "exact_hits": 3, "tiny": 4, "huge": 5, "mixed_scale": 6, "negative_w": 7}[case])
+    m, sub, h, n = 8, 16, 256, 6_000
+    if case == "ties":
+        X = rng.integers(0, 3, (n, m * sub)).astype(np.float32)
+        C = [rng.integers(0, 3, (h, sub)).astype(np.float32) for _ in range(m)]
+    elif case == "dups":
+        X = rng.standard_normal((n, m * sub)).astype(np.float32)
+        C = []
+        for _ in range(m):
+            c = rng.standard_normal((h, sub)).astype(np.float32)
+            c[rng.permutation(h)[:h // 2]] = c[rng.integers(0, h, h // 2)]       # half of the rows are copies of other rows
+            C.append(c)
+    elif case == "exact_hits":
+        C = [rng.standard_normal((h, sub)).astype(np.float32) * 50 for _ in range(m)]
+        X = np.concatenate([C[i][rng.integers(0, h, n)] for i in range(m)], axis=1).astype(np.float32)
+    elif case == "tiny":
+        X = (rng.standard_normal((n, m * sub)) * 1e-14).astype(np.float32)
+        C = [(rng.standard_normal((h, sub)) * 1e-14).astype(np.float32) for _ in range(m)]
+    elif case == "huge":
+        X = (rng.standard_normal((n, m * sub)) * 1e15).astype(np.float32)
+        C = [(rng.standard_normal((h, sub)) * 1e15).astype(np.float32) for _ in range(m)]
+    elif case == "mixed_scale":
+        scale = np.exp(rng.uniform(-12, 12, (1, m * sub))).astype(np.float32)
+        X = rng.standard_normal((n, m * sub)).astype(np.float32) * scale
+        C = [rng.standard_normal((h, sub)).astype(np.float32) * scale[:, i * sub:(i + 1) * sub] for i in range(m)]
+    else:       # far-away data: |c|^2 - 2<c, x> strongly negative, huge |x|^2 against small differences between centroids
+        base = rng.standard_normal((1, m * sub)).astype(np.float32) * 1000
+        X = base + rng.standard_normal((n, m * sub)).astype(np.float32)
+        C = [base[:, i * sub:(i + 1) * sub] + rng.standard_normal((h, sub)).astype(np.float32) for i in range(m)]
+    rq.set_tuning("ENC_SPLIT_WAVES", waves)
+    try:
+        got, old, ref = _enc_both(rq, oracle, np.ascontiguousarray(X), C, m, h)
+    finally:
+        rq.set_tuning("ENC_SPLIT_WAVES", 0)
+    assert np.array_equal(old, ref), case
+    assert np.array_equal(got, ref), (case, int((got != ref).sum()))
+
+
+def test_split_encode_deep_shape_hostile(rq, oracle):
+    """sub = 6 (two MFMAs per tile, hi and lo pieces packed into one K = 16 fragment), m = 16, ties and near-ties"""
+    rng = np.random.default_rng(61)
+    m, sub, h, n = 16, 6, 256, 5_000
+    for scale, integer in ((1.0, False), (1.0, True), (1e-13, False)):
+        if integer:
+            X = rng.integers(0, 4, (n, m * sub)).astype(np.float32)
+            C = [rng.integers(0, 4, (h, sub)).astype(np.float32) for _ in range(m)]
+        else:
+            X = (rng.standard_normal((n, m * sub)) * scale).astype(np.float32)
+            C = [(rng.standard_normal((h, sub)) * scale).astype(np.float32) for _ in range(m)]
+        got, old, ref = _enc_both(rq, oracle, X, C, m, h)
+        assert np.array_equal(old, ref) and np.array_equal(got, ref), (scale, integer, int((got != ref).sum()))
