@@ -36,849 +36,16 @@
 #include "rq_internal.h"
 #include "rq_topk.h"
 
+#include "rq_scan_tables.h"
+#include "rq_scan_filter.h"
+#include "rq_scan_select.h"
+
 namespace rq {
-
-#ifndef RQ_SCAN_THREADS
-#define RQ_SCAN_THREADS 512
-#endif
-constexpr int SCAN_THREADS = RQ_SCAN_THREADS;       // 1024: one workgroup per CU; 512: two
-constexpr int SCAN_WGS_PER_CU = 1024 / SCAN_THREADS;
-
-// v_writelane_b32 (no clang builtin in ROCm 7.2): lane `L` of `old` <- wave-uniform `val`
-template <class T>
-__device__ __forceinline__ uint32_t writelane_u32(uint32_t old, T val, int L) {
-  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(L));
-  return old;
-}
-
-// LUT entry of QPG queries
-template <int QPG> struct LutVec;
-template <> struct LutVec<4> {
-  using type = float4;
-  static __device__ __forceinline__ type make(const float *a) { return make_float4(a[0], a[1], a[2], a[3]); }
-  static __device__ __forceinline__ float get(const type &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
-};
-template <> struct LutVec<2> {
-  using type = float2;
-  static __device__ __forceinline__ type make(const float *a) { return make_float2(a[0], a[1]); }
-  static __device__ __forceinline__ float get(const type &v, int i) { return i == 0 ? v.x : v.y; }
-};
-
-#ifndef RQ_SCAN_QG8_MAX_M
-#define RQ_SCAN_QG8_MAX_M 16
-#endif
-// (RQ_SCAN_QG16_MAX_M=8: 16 queries per 16-byte gather at m = 8, one 1024-thread workgroup per CU.  Correct -- the GPU
-// suite passes -- and slower: k = 1 2.25 against 2.01 ms, k = 1000 3.28 against 2.46.  A 16-byte entry costs four adds, so
-// the VALU work per (row, query) does not drop, and 16 accumulators + 32 registers of entries spill 115 registers.)
-#ifndef RQ_SCAN_QG16_MAX_M
-#define RQ_SCAN_QG16_MAX_M 0
-#endif
-#ifndef RQ_MAX_SHARE
-#define RQ_MAX_SHARE 60u
-#endif
-#ifndef RQ_UCH_WIDE_BIAS
-#define RQ_UCH_WIDE_BIAS 4
-#endif
-template <int M>
-struct ScanCfg {
-  // queries per LDS gather: a float4 entry (ds_read_b128) up to m = 32; m = 64 only fits the 160 KiB of
-  // LDS with float2 entries (ds_read_b64, 2 queries per gather)
-  static constexpr int QPG = (M <= 32) ? 4 : 2;
-  static constexpr int QG = (M == 8 && RQ_SCAN_QG16_MAX_M >= 8) ? 16 : (M <= RQ_SCAN_QG8_MAX_M) ? 8 : (M <= 32) ? 4 : 2;   // queries per group
-  static constexpr int NQUAD = QG / QPG;                         // gathers per code byte
-  // rows per thread per sub-step: ~32 gathers' worth, and a whole number of 16-byte code loads
-  static constexpr int RPT = (32 / (M * NQUAD)) > (M < 16 ? 16 / M : 1) ? 32 / (M * NQUAD) : (M < 16 ? 16 / M : 1);
-  // threads per workgroup: two 512-thread workgroups per CU, or ONE of 1024 where a group's tables take more than half of
-  // the LDS (m = 16: 96 KiB of f32 tables + 32 KiB of byte tables; m = 32, 64: 112 KiB of f32 tables) -- the same 16
-  // wavefronts per CU either way (m = 32 exact scan 27.1 -> 24.6 ms against one 512-thread workgroup per CU)
-  static constexpr int THREADS = (M * QG >= 128) ? 1024 : SCAN_THREADS;
-  static constexpr int SUB = THREADS * RPT;    // rows per sub-step (one 16/32-byte load per lane)
-#ifndef RQ_SCAN_U8
-#define RQ_SCAN_U8 8
-#endif
-#ifndef RQ_SCAN_U16
-#define RQ_SCAN_U16 4
-#endif
-  static constexpr int U = (M <= 8) ? RQ_SCAN_U8 : (M <= 16) ? RQ_SCAN_U16 : (M <= 32) ? 2 : 1;  // sub-steps per block: loads of a block fly together
-  static constexpr int BLK = SUB * U;               // rows per workgroup block
-  // blocks between two capacity votes (the only barrier of the streaming loop): one vote per ~32768 rows.  Measured at
-  // SIFT1M shape, votes every 1 / 2 / 4 / 8 blocks: k = 1 2.13 / 2.05 / 2.00 / 1.99 ms, k = 1000 2.62 / 2.62 / 2.46 / 2.44;
-  // the candidate buffers grow by 2 * VP * BLK keys (a slow wavefront may still be appending the previous period's rows)
-#ifdef RQ_SCAN_VP
-  static constexpr int VP = RQ_SCAN_VP;
-#else
-  static constexpr int VP = (32768 / BLK) < 1 ? 1 : (32768 / BLK) > 8 ? 8 : (32768 / BLK);
-#endif
-  static constexpr int LUT_BYTES = M * QG * 1024;   // full table; the LDS part is LUT_LDS_BYTES below
-  // The LDS gather pipe is the kernel's bound (~11-12 cycles per 64-lane ds_read_b128 with random
-  // slots).  The vector-memory path can gather the same 16 bytes from an L1-resident table in ~29
-  // cycles per wavefront (tools/micro/gather_l1.hip) and runs beside the LDS, so the LAST KG
-  // sub-quantizers (~25 % of the gathers, <= 16 KiB of table) are looked up through L1 instead.
-#ifndef RQ_SCAN_KG_DISABLE
-#ifndef RQ_SCAN_KG8
-#define RQ_SCAN_KG8 2
-#endif
-  static constexpr int KG = (M == 8) ? (QG == 16 ? 4 : RQ_SCAN_KG8) : (M == 16) ? 4 : (M == 32) ? 4 : (M == 4) ? 1 : 0;   // M = 64: all in LDS
-#else
-  static constexpr int KG = 0;
-#endif
-  static constexpr int KL = M - KG;                 // sub-quantizers [0, KL) gather from LDS
-  static constexpr int GTAB_F4 = KG * NQUAD * 256;  // entries (float4 for QPG = 4) of the global (L1) table
-  static constexpr int LUT_LDS_BYTES = KL * QG * 1024;
-  // integer pre-filter (see build_qtab): one byte per (sub-quantizer, code, query); tiled for M = 8 and 16
-  static constexpr bool HAS_FILT = (M == 8 || M == 16) && SCAN_THREADS == 512;     // (the default build)
-  // byte accumulator sets: 8 sub-quantizers each; m = 8 in FINE mode: two sets of 4 with 6-bit entries (half the step)
-  static constexpr int NACC = HAS_FILT ? (M == 8 ? 2 : M / 8) : 1;
-  static constexpr int kpa(bool fine) { return (M == 8 && fine) ? 4 : 8; }   // sub-quantizers per accumulator set
-  static constexpr int QTAB_BYTES = HAS_FILT ? (M + 1) * 256 * QG : 0;   // + 1: the row-norm table of LSQ scans
-  // scratch behind the staged queries: the threshold sample's [QG][THREADS] minima, later the filter table
-  static constexpr int AUX_BYTES = (QG * THREADS * 4 > QTAB_BYTES) ? QG * THREADS * 4 : QTAB_BYTES;
-  static_assert(RPT >= 1, "M too large for this tiling");
-};
-
-template <int QG>
-struct ScanCtrl {
-  float tau[QG];
-  uint32_t cnt[QG];
-  uint32_t sel[QG];     // which half of the candidate ping-pong buffer is current
-  uint32_t item;
-  uint32_t selmask;     // bit q == sel[q] (one LDS word the hot loop reads per block)
-  uint32_t pad[2];
-  // integer pre-filter (FILT kernels): per-(sub-quantizer, query) table minima and the per-query scale
-  float fmin[16][QG];
-  float fmax[16][QG];   // LSQ scans: per-(sub-quantizer, query) max |entry| (absolute rounding margins)
-  float finv[QG];
-  uint32_t fpush;       // rows the pre-filter let through in the item's first block (it is switched off if too many)
-  SelState<QG> st;      // st.hist doubles as the per-wavefront queues of rows waiting for the exact evaluation
-};
-
-struct ScanParams {
-  const uint8_t *codes;     // [n][M]
-  const float *centers;     // [M][256][sub]
-  const float *queries;     // [nq][d]
-  uint32_t n, nq;
-  int sub, d, K;
-  int m_real;               // sub-quantizers that exist; tables k >= m_real are all-zero padding
-  int lut_mode;             // 0 PQ sub-space (c-q)^2 | 1 LSQ -2<q,c> full-dim | 2 CQ (q-c)^2 full-dim
-  const float *row_bias;    // LSQ: dbnorms[n], added after the table sum; else nullptr
-  const uint8_t *norm_bytes;  // LSQ pre-filter: row norms quantised to 256 lower edges, [n]
-  const float *norm_info;     // ... {nmin, nstep, max |.|} of the quantised quantity: norm[row] - sum_k |c_k[b_k]|^2
-  const float *cnorm;         // ... |c_k[r]|^2, [M][256]: folded into the filter's tables (see build_qtab)
-  uint32_t id_offset;
-  int id_base;
-  uint32_t nslices, rows_per_slice, ngroups;
-  uint32_t whole;           // query groups [0, whole) are ONE item over all rows (answer written directly);
-                            // groups [whole, ngroups) are cut into nslices row slices (key lists -> merge)
-  uint32_t xcd_mode;        // 1: big base -- row windows are handed out per XCD (work_counter[0..7]), see the item loop
-  uint32_t xcd_slack;       // ... an item may start while at most this many items of the XCD's earlier rounds still run
-  uint32_t xcd_round;       // ... items per pacing round (a window's items, or the XCD's resident workgroups)
-  uint32_t cap;             // candidate buffer capacity per query (keys)
-  uint32_t trigger;         // compact when cnt > trigger  (cap - 2*VP*BLK >= trigger >= K)
-  uint32_t p2;              // next_pow2(K)
-  uint32_t scratch_keys;    // LDS sort scratch capacity in keys
-  uint32_t sample;          // rows sampled per slice to initialise tau (0 = off)
-  uint32_t sample_rt;       // ... for slices that get the second estimate (a looser first tau only rules 1/8 of the rows)
-  uint32_t srank_mul;       // target survivors per slice = srank_mul * K (3; 0 forces the fallback, tests)
-  int retune_z;             // second threshold estimate after 1/8 of the rows: rank = mean + z sigma (6; 0 = off; < 0: tests)
-  int retune_min_k;         // ... only for K >= this
-  int retune_div;           // ... after rows / retune_div rows (8)
-  uint32_t *work_counter;
-  float4 *gtab;               // [gridDim][GTAB_F4] L1-gathered part of the LUT
-  unsigned long long *stats;  // optional [8]: cycles in lut, sample, stream, cuts, final cut, sort; #cuts; #fallbacks
-  uint64_t *cand;           // [gridDim][QG][2][cap]
-  uint16_t *bkt;            // [gridDim][cap] bucket ids of the large-K sample sort
-  int filter;               // 1: 8-bit lower-bound pre-filter in front of the exact evaluation (FILT kernels)
-  int bigk;                 // K > SCAN_SS_MIN_K: finish with samplesort_topk instead of cut + LDS bitonic
-  // outputs of whole items: dists/ids [nq][K], or packed keys [nq][K] when keys != nullptr;
-  // of sliced items: part [(query - whole*QG)][nslices][K] packed keys
-  float *dists;
-  uint32_t *ids;
-  uint64_t *keys;
-  uint64_t *part;
-};
-
-// ------------------------------------------------------------------------------------------
-// LUT construction, one (k, r) entry at a time for all QG queries of the group; compiled with
-// -ffp-contract=off so every product, square and add stays a separately rounded f32 operation
-// like the reference's x86-64 builds.
-//   mode 0  deps/src/linscan_aqd.cpp:66-74                 T = sum_s (c[s] - q[k*sub+s])^2, s < sub
-//   mode 1  deps/src/linscan_aqd_pairwise_byte.cpp:42-49   T = T - (2*q[s])*c[s],            s < d
-//   mode 2  deps/src/linscan_aqd_pairwise_byte.cpp:126-133 T = T + (q[s]-c[s])^2,            s < d
-// ------------------------------------------------------------------------------------------
-template <int M>
-__device__ __forceinline__ void build_lut(float *lut, float4 *gtab, const float *qstage,
-                                          const float *centers, int sub, int d, int mode, int m_real, int tid) {
-  using Cfg = ScanCfg<M>;
-  constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD;
-  const int cdim = mode == 0 ? sub : d;
-  for (int e = tid; e < M * 256; e += ScanCfg<M>::THREADS) {
-    const int k = e >> 8, r = e & 255;
-    const float *c = centers + (size_t)e * cdim;
-    const int qoff = mode == 0 ? k * sub : 0;
-    float acc[QG];
-#pragma unroll
-    for (int q = 0; q < QG; ++q) acc[q] = 0.0f;
-    if (k >= m_real) {
-      // padding sub-quantizer (m rounded up to a supported tile width): T = 0, and x + 0.0f == x
-    } else {
-      // one table entry per thread, its codebook row streamed 16 bytes at a time (full-dimensional rows
-      // are 512 B apart between lanes: scalar loads would touch 64 cache lines per instruction, 4x as often)
-      auto step = [&](float cs, int s) {
-        if (mode == 1) {
-#pragma unroll
-          for (int q = 0; q < QG; ++q) {
-            const float two_q = 2.0f * qstage[q * d + s];
-            const float prod = two_q * cs;
-            acc[q] = acc[q] - prod;
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < QG; ++q) {
-            const float diff = cs - qstage[q * d + qoff + s];   // (q-c)^2 has the same bits
-            const float sq = diff * diff;
-            acc[q] = acc[q] + sq;
-          }
-        }
-      };
-      if ((cdim & 3) == 0 && ((uintptr_t)centers & 15) == 0) {
-        const float4 *c4 = reinterpret_cast<const float4 *>(c);
-#pragma unroll 2
-        for (int s4 = 0; s4 < cdim / 4; ++s4) {
-          const float4 cv = c4[s4];
-          step(cv.x, 4 * s4 + 0);
-          step(cv.y, 4 * s4 + 1);
-          step(cv.z, 4 * s4 + 2);
-          step(cv.w, 4 * s4 + 3);
-        }
-      } else {
-        for (int s = 0; s < cdim; ++s) step(c[s], s);
-      }
-    }
-    using LV = LutVec<Cfg::QPG>;
-    using Vec = typename LV::type;
-#pragma unroll
-    for (int quad = 0; quad < NQUAD; ++quad) {
-      const Vec v = LV::make(&acc[quad * Cfg::QPG]);
-      if (k < Cfg::KL) reinterpret_cast<Vec *>(lut)[(k * NQUAD + quad) * 256 + r] = v;
-      else reinterpret_cast<Vec *>(gtab)[((k - Cfg::KL) * NQUAD + quad) * 256 + r] = v;
-    }
-  }
-}
-
-// ADC distances of row r of the packed byte string w for the QG queries of the group:
-// acc_q = ((T_q[0][b0] + T_q[1][b1]) + ...)  -- deps/src/linscan_aqd.cpp:85-87, sequential f32.
-template <int M>
-__device__ __forceinline__ void row_dists(const uint32_t *w, int r, const float4 *lut4,
-                                          const float4 *__restrict__ gtab4, float (&acc)[ScanCfg<M>::QG]) {
-  using Cfg = ScanCfg<M>;
-  using LV = LutVec<Cfg::QPG>;
-  using Vec = typename LV::type;
-  constexpr int NQUAD = Cfg::NQUAD, KL = Cfg::KL, QPG = Cfg::QPG;
-  const Vec *lutv = reinterpret_cast<const Vec *>(lut4);
-  const Vec *__restrict__ gtab = reinterpret_cast<const Vec *>(gtab4);
-  // issue the L1 gathers of the last sub-quantizers first: their latency hides under the LDS ones
-  Vec tg[(Cfg::KG > 0 ? Cfg::KG : 1) * NQUAD];
-  auto load_tg = [&]() {
-#pragma unroll
-    for (int k = KL; k < M; ++k) {
-      const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
-#pragma unroll
-      for (int quad = 0; quad < NQUAD; ++quad) tg[(k - KL) * NQUAD + quad] = gtab[((k - KL) * NQUAD + quad) * 256 + byte];
-    }
-  };
-  constexpr bool WIDE = M * NQUAD >= 32;     // a row of 32 gathers is summed in two halves (see below)
-  if constexpr (!WIDE) load_tg();
-#pragma unroll
-  for (int k = 0; k < M; ++k) {
-    // at most 16 gathers (64 registers of table entries) in flight: a row of 32 (m = 16, 8 queries) is summed in two
-    // halves -- the scheduler otherwise hoists all 32 and spills their results (LSQ variant: 160 spilled registers)
-    if constexpr (WIDE) {
-      if (k * NQUAD == 16) {
-        __builtin_amdgcn_sched_barrier(0);
-        load_tg();                             // the L1 part belongs to the second half (KL >= M / 2)
-      }
-    }
-    const uint32_t byte = (w[(r * M + k) >> 2] >> (8 * ((r * M + k) & 3))) & 0xffu;
-#pragma unroll
-    for (int quad = 0; quad < NQUAD; ++quad) {
-      const Vec t = k < KL ? lutv[(k * NQUAD + quad) * 256 + byte] : tg[(k - KL) * NQUAD + quad];
-#pragma unroll
-      for (int c = 0; c < QPG; ++c) {
-        if (k == 0) acc[quad * QPG + c] = LV::get(t, c);
-        else acc[quad * QPG + c] = acc[quad * QPG + c] + LV::get(t, c);
-      }
-    }
-  }
-}
-
-// one row's M code bytes into w[0 .. M/4) (packed like the hot loop's byte string, r = 0)
-template <int M>
-__device__ __forceinline__ void load_row(uint32_t *w, const uint8_t *codes, uint32_t row) {
-  if constexpr (M % 4 == 0) {
-#pragma unroll
-    for (int i = 0; i < M / 4; ++i) w[i] = reinterpret_cast<const uint32_t *>(codes + (size_t)row * M)[i];
-  } else {
-#pragma unroll
-    for (int i = 0; i < (M + 3) / 4; ++i) w[i] = 0;
-#pragma unroll
-    for (int k = 0; k < M; ++k) w[k >> 2] |= (uint32_t)codes[(size_t)row * M + k] << (8 * (k & 3));
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// Survivors of one wave-row-step: lane `lane` holds the exact distances acc[q] of ONE row (key id `kid`) to the
-// QG queries; rows with acc[q] <= tau[q] are appended to query q's candidate buffer (INCLUSIVE: tau is a sampled
-// distance, and on heavily duplicated codes hundreds of rows share the K-th neighbour's distance exactly -- with a strict
-// test they all drop out and the slice has to be redone exactly; 3 % of the groups on 1024-cluster data).  ONE LDS atomic for all QG
-// queries: lane q reserves popc(mk[q]) slots of query q.
-// ------------------------------------------------------------------------------------------
-template <int QG>
-__device__ __forceinline__ void emit_survivors(const float (&acc)[QG], const float (&tau)[QG], bool valid, uint32_t kid,
-                                               uint32_t selmask, ScanCtrl<QG> *ctrl, uint64_t *cand_wg, uint32_t cap,
-                                               int lane) {
-  uint64_t mk[QG];
-  uint64_t any = 0;
-#pragma unroll
-  for (int q = 0; q < QG; ++q) {
-    mk[q] = __ballot(valid && (acc[q] <= tau[q]));
-    any |= mk[q];
-  }
-  if (any) {
-    uint32_t want = 0;
-#pragma unroll
-    for (int q = 0; q < QG; ++q)
-      want = writelane_u32(want, (uint32_t)__popcll(mk[q]), q);
-    uint32_t got = 0;
-    if (lane < QG && want) got = atomicAdd(&ctrl->cnt[lane], want);
-#pragma unroll
-    for (int q = 0; q < QG; ++q) {
-      if (mk[q]) {
-        const uint32_t basep = __builtin_amdgcn_readlane(got, q);
-        if ((mk[q] >> lane) & 1ull) {
-          const uint32_t pos = basep + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32),
-                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
-          uint64_t *buf = cand_wg + ((size_t)q * 2 + ((selmask >> q) & 1u)) * cap;
-          buf[pos] = make_key(acc[q], kid);
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Integer pre-filter (M = 8 tiles, LUT modes with entries >= 0).
-//
-// 63 % of the LDS cycles of the exact loop are bank-conflict replays of 16-byte gathers, and only ~0.3 % of
-// the (row, query) pairs survive the threshold.  So the hot loop first evaluates a LOWER BOUND of every
-// distance from a table of one BYTE per (sub-quantizer, code, query) -- ONE 8-byte gather serves the 8 queries
-// of the group, and one v_add_u32 accumulates 4 of them -- and only rows whose bound can still beat tau for
-// some query are queued (row id, per wavefront) for the exact f32 evaluation above, 64 queued rows at a time.
-//
-//   entry  e_q[k][r] = min( floor( (T_q[k][r] - min_r T_q[k][.]) * inv_q ), CLAMP ),   CLAMP * (sub-quantizers per byte sum) <= 255
-//   inv_q  a little BELOW  THR / (tau_q (1 + 2^-18) - sum_k min_k (1 - 2^-19))
-//   pass   sum_k e_q[k][b_k] <= THR            (no byte sum can wrap)
-//
-// Soundness (every row with f32 distance d < tau passes): the real sum S of the M <= 16 table entries is within
-// 15 * 2^-24 relative of the sequential f32 sum d (all entries >= 0), so S < tau (1 + 0.9e-6); the margins in
-// inv_q dominate every rounding of its own computation and of (T - min) * inv (accounting in build_qtab), so the
-// computed entry never exceeds the real (T - min) * THR / range with range >= S - sum_k min_k, the real sum of
-// those is <= THR, and the integer sum of their floors is <= THR.  Clamping only lowers entries.
-// The filter therefore passes a SUPERSET of {d <= tau} (the margins are strict); the exact evaluation decides, so results
-// do not change.
-// ------------------------------------------------------------------------------------------
-// Byte accumulators.  M = 8, FINE kernels (chosen for k >= 8192): TWO sets of 4 sub-quantizers with 6-bit entries (4 * 63 <= 255) and
-// THR8 = 191 -- half the quantisation step of one set of 8 with 5-bit entries and THR 95, same relative clamp (1/3 of
-// the range): 27 % fewer rows reach the exact evaluation (first block at SIFT1M shape: 7.0 -> 5.1 % of the rows at
-// K = 1000, 25.8 -> 19.9 % at K = 10000; K = 10000 7.38 -> 6.79 ms, K <= 1000 within 1 %; THR 159 / 223 / 255 are level
-// or worse: beyond 191 the clamp bites).  A + B <= THR is tested on the per-byte AVERAGE, which needs no wider
-// fields: floor((A + B) / 2) = (A & B) + (((A ^ B) >> 1) & 0x7f..) <= (THR - 1) / 2 for odd THR.
-// M = 16: two sets of 8 (8 * 31 <= 255), compared against THR16 = 159 through their per-byte average (<= 79).
-constexpr uint32_t FILT_CLAMP = 31;
-constexpr uint32_t filt_thr8(bool fine) { return fine ? 191u : 95u; }
-constexpr uint32_t filt_clamp8(bool fine) { return fine ? 63u : 31u; }
-constexpr uint32_t FILT_THR16 = 159;
-
-// (byte k of w) << SH in ONE VALU instruction (SDWA operand select; the compiler emits v_bfe_u32 + v_lshl_add_u32)
-template <int K, int SH>
-__device__ __forceinline__ uint32_t byte_shl(uint32_t w, uint32_t sh_reg) {
-  uint32_t r;
-  if constexpr (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(sh_reg), "v"(w));
-  else if constexpr (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(sh_reg), "v"(w));
-  else if constexpr (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(sh_reg), "v"(w));
-  else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(sh_reg), "v"(w));
-  return r;
-}
-
-// load from an ABSOLUTE LDS byte address (no symbol involved: constant parts fold into the instruction's offset field)
-template <class T> __device__ __forceinline__ T lds_abs_load(uint32_t addr);
-template <> __device__ __forceinline__ uint2 lds_abs_load<uint2>(uint32_t addr) {
-  typedef const unsigned long long __attribute__((address_space(3))) lds_u64_t;
-  const unsigned long long v = *(lds_u64_t *)(uintptr_t)addr;
-  return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-}
-template <> __device__ __forceinline__ uint4 lds_abs_load<uint4>(uint32_t addr) {
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  typedef const u32x4 __attribute__((address_space(3))) lds_u128_t;
-  const u32x4 v = *(lds_u128_t *)(uintptr_t)addr;
-  return make_uint4(v.x, v.y, v.z, v.w);
-}
-template <> __device__ __forceinline__ uint32_t lds_abs_load<uint32_t>(uint32_t addr) {
-  typedef const uint32_t __attribute__((address_space(3))) lds_u32_t;
-  return *(lds_u32_t *)(uintptr_t)addr;
-}
-
-// dword j of a byte-table entry (4 queries per dword)
-__device__ __forceinline__ uint32_t fv_word(const uint32_t &v, int) { return v; }
-__device__ __forceinline__ uint32_t fv_word(const uint2 &v, int j) { return j == 0 ? v.x : v.y; }
-__device__ __forceinline__ uint32_t fv_word(const uint4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
-
-template <int M> struct FiltVec;               // table entry: one byte per query of the group
-template <> struct FiltVec<8> { using type = std::conditional<ScanCfg<8>::QG == 16, uint4, uint2>::type; };   // ds_read_b128 / b64
-template <> struct FiltVec<16> { using type = std::conditional<ScanCfg<16>::QG == 8, uint2, uint32_t>::type; };
-
-// per-entry clamp of the byte tables: (entries per byte sum) * clamp <= 255.  LSQ scans add the row-norm entry to the
-// LAST byte sum: 5 entries of <= 51 at m = 8 (two sets of 4 and 4 + 1), 9 of <= 28 at m = 16 (sets of 8 and 8 + 1)
-template <int M, bool FINE, bool LSQ>
-constexpr uint32_t filt_clamp() { return LSQ ? (M == 8 ? 51u : 28u) : (M == 8 ? filt_clamp8(FINE) : FILT_CLAMP); }
-
-// row norm -> its quantisation cell's LOWER edge, with exactly these two rounded operations (the quantiser checks its
-// choice against the same expression, so EDGE(byte of a row) <= the row's norm holds in exact arithmetic)
-__device__ __forceinline__ float norm_edge(float nmin, float nstep, uint32_t b) {
-  const float t = (float)b * nstep;
-  return nmin + t;
-}
-
-template <int M, bool FINE, bool LSQ = false>
-__device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const float4 *lut4, const float4 *gtab4,
-                                           uint32_t *qtab, int tid, const float *norm_info = nullptr,
-                                           const float *cnorm = nullptr) {
-  using Cfg = ScanCfg<M>;
-  constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD, KL = Cfg::KL;
-  static_assert(Cfg::QPG == 4, "pre-filter tiling: float4 table entries");
-  constexpr float THR = (float)(M == 8 ? filt_thr8(FINE) : FILT_THR16);
-  const int wave = tid >> 6, lane = tid & 63;
-  auto entry = [&](int kk, int quad, int r) -> float4 {
-    float4 v = kk < KL ? lut4[(kk * NQUAD + quad) * 256 + r] : gtab4[((kk - KL) * NQUAD + quad) * 256 + r];
-    if constexpr (LSQ) {
-      // LSQ: T = -2 <q, c> and the row adds |x_hat|^2.  Bounding the two separately is useless (the centroid with the
-      // largest <q, c> also has a large norm: 76 % of the rows stayed alive); so the filter works on
-      //   T'_k[r] = T_k[r] + |c_k[r]|^2      and      rho(row) = norm(row) - sum_k |c_k[b_k]|^2   (the cross terms),
-      // whose sum is the same distance in exact arithmetic.  rho is what the row byte quantises.
-      const float cn = cnorm[kk * 256 + r];
-      v.x = v.x + cn; v.y = v.y + cn; v.z = v.z + cn; v.w = v.w + cn;
-    }
-    return v;
-  };
-  // 1. minima of the 256 entries of (k, q): one wavefront per sub-quantizer, lane handles r = lane, lane + 64, ...
-  for (int k = wave; k < M; k += ScanCfg<M>::THREADS / 64) {
-    float mn[QG], mx[LSQ ? QG : 1];
-#pragma unroll
-    for (int q = 0; q < QG; ++q) mn[q] = __uint_as_float(0x7f800000u);
-    if constexpr (LSQ) {
-#pragma unroll
-      for (int q = 0; q < QG; ++q) mx[q] = 0.0f;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int quad = 0; quad < NQUAD; ++quad) {
-        const float4 v = entry(k, quad, lane + 64 * i);
-        mn[quad * 4 + 0] = fminf(mn[quad * 4 + 0], v.x);
-        mn[quad * 4 + 1] = fminf(mn[quad * 4 + 1], v.y);
-        mn[quad * 4 + 2] = fminf(mn[quad * 4 + 2], v.z);
-        mn[quad * 4 + 3] = fminf(mn[quad * 4 + 3], v.w);
-        if constexpr (LSQ) {
-          mx[quad * 4 + 0] = fmaxf(mx[quad * 4 + 0], fabsf(v.x));
-          mx[quad * 4 + 1] = fmaxf(mx[quad * 4 + 1], fabsf(v.y));
-          mx[quad * 4 + 2] = fmaxf(mx[quad * 4 + 2], fabsf(v.z));
-          mx[quad * 4 + 3] = fmaxf(mx[quad * 4 + 3], fabsf(v.w));
-        }
-      }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-      for (int q = 0; q < QG; ++q) mn[q] = fminf(mn[q], __shfl_xor(mn[q], off));
-      if constexpr (LSQ) {
-#pragma unroll
-        for (int q = 0; q < QG; ++q) mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], off));
-      }
-    }
-    float mc = 0.0f;      // LSQ: max_r |c_k[r]|^2 -- the ORIGINAL magnitudes are bounded by |T| <= |T'| + |c|^2, |norm| <= |rho| + sum |c|^2
-    if constexpr (LSQ) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) mc = fmaxf(mc, cnorm[k * 256 + lane + 64 * i]);
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) mc = fmaxf(mc, __shfl_xor(mc, off));
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < QG; ++q) ctrl->fmin[k][q] = mn[q];
-      if constexpr (LSQ) {
-#pragma unroll
-        for (int q = 0; q < QG; ++q) ctrl->fmax[k][q] = mx[q] + 2.0f * mc;
-      }
-    }
-  }
-  __syncthreads();
-  float nmin = 0.0f, nstep = 0.0f;
-  if constexpr (LSQ) { nmin = norm_info[0]; nstep = norm_info[1]; }
-  if constexpr (LSQ) {
-    // LSQ tables are signed (-2 <q, c>) and every row adds its norm.  Shifted by their minima the entries are >= 0 again;
-    // the norm enters as one more table, indexed by the row's norm BYTE, whose entry is the cell's lower edge -- a lower
-    // bound of it.  Rounding is accounted for ABSOLUTELY: with A >= sum_k max|T_k| + max|norm| (original magnitudes,
-    // bounded through the folded ones: fmax = max|T'| + 2 max|c|^2), the sequential f32
-    // distance of a row (M + 1 <= 17 terms) is within 17u A < 2^-19.9 A of the real sum, so is the f32 sum of the minima,
-    // and (tau - base) itself rounds by 2^-24 |tau - base|.  The margin 2^-16 A + 2^-18 |tau - base| covers the three
-    // seven times over; A is a few ranges, so it costs < 1e-3 of a filter step.
-    if (tid < QG) {
-      float base = nmin, A = fabsf(norm_info[2]);
-      for (int kk = 0; kk < M; ++kk) { base = base + ctrl->fmin[kk][tid]; A = A + ctrl->fmax[kk][tid]; }
-      const float tau = ctrl->tau[tid];
-      const float gap = tau - base;
-      const float range = gap + (A * 1.52587890625e-5f + fabsf(gap) * 3.814697265625e-6f);
-      float inv = 0.0f;     // 0: the filter passes everything for this query
-      if (tau < __uint_as_float(0x7f800000u) && range > 0.0f && A < __uint_as_float(0x7f800000u)) {
-        const float step = range / THR;
-        const float cand = (1.0f / step) * (1.0f - 1.9073486328125e-6f);
-        if (step > 0.0f && cand < __uint_as_float(0x7f800000u)) inv = cand;
-      }
-      ctrl->finv[tid] = inv;
-    }
-  } else
-
-  if (tid < QG) {
-    float base = 0.0f;
-    for (int kk = 0; kk < M; ++kk) base = base + ctrl->fmin[kk][tid];
-    const float tau = ctrl->tau[tid];
-    // Margins: 2^-18 on tau, 2^-19 on the minima and on 1/step.  What they have to cover (u = 2^-24): the sequential
-    // f32 sum of M <= 16 non-negative terms is within 15u/(1-15u) < 0.9e-6 of the real sum -- for the row's distance
-    // (so S < tau (1 + 0.9e-6) whenever d < tau) and for `base` against the real sum of the minima -- plus one rounding
-    // for each of the two products, the subtraction, the division, the reciprocal and its product (< 7u = 0.42e-6 in
-    // all).  2^-18 = 3.8e-6 and 2^-19 = 1.9e-6 leave a factor of two everywhere; their cost is nil (one filter step
-    // is range / THR, i.e. 1e-2 of the range).
-    const float range = tau * (1.0f + 3.814697265625e-6f) - base * (1.0f - 1.9073486328125e-6f);
-    float inv = 0.0f;     // 0: every entry quantises to 0, i.e. the filter passes everything for this query
-    if (tau < __uint_as_float(0x7f800000u) && range > 0.0f && base >= 0.0f) {
-      const float step = range / THR;
-      const float cand = (1.0f / step) * (1.0f - 1.9073486328125e-6f);
-      if (step > 0.0f && cand < __uint_as_float(0x7f800000u)) inv = cand;
-    }
-    ctrl->finv[tid] = inv;
-  }
-  __syncthreads();
-  // 2. one byte per (k, r, query): QG bytes per entry
-  for (int e = tid; e < M * 256; e += ScanCfg<M>::THREADS) {
-    const int kk = e >> 8, r = e & 255;
-#pragma unroll
-    for (int quad = 0; quad < NQUAD; ++quad) {
-      const float4 v = entry(kk, quad, r);
-      const float t[4] = {v.x, v.y, v.z, v.w};
-      uint32_t w = 0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float diff = t[c] - ctrl->fmin[kk][quad * 4 + c];
-        const float x = diff * ctrl->finv[quad * 4 + c];
-        w |= (uint32_t)fminf(fmaxf(x, 0.0f), (float)filt_clamp<M, FINE, LSQ>()) << (8 * c);   // float -> uint truncates = floor (x >= 0)
-      }
-      qtab[e * NQUAD + quad] = w;
-    }
-  }
-  if constexpr (LSQ) {
-    // 3. the row-norm table: entry r = the lower edge of cell r above the smallest norm, in the query's steps
-    for (int r = tid; r < 256; r += ScanCfg<M>::THREADS) {
-      const float diff = norm_edge(nmin, nstep, (uint32_t)r) - nmin;
-#pragma unroll
-      for (int quad = 0; quad < NQUAD; ++quad) {
-        uint32_t w = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float x = diff * ctrl->finv[quad * 4 + c];
-          w |= (uint32_t)fminf(fmaxf(x, 0.0f), (float)filt_clamp<M, FINE, LSQ>()) << (8 * c);
-        }
-        qtab[(M * 256 + r) * NQUAD + quad] = w;
-      }
-    }
-  }
-}
-
-// "Can this row still beat a threshold?" from the byte sums of the group's queries.
-//   M = 8 : a[0], a[1] (and a[2], a[3] for the second set; then s = their per-byte average, T = (THR - 1) / 2) hold 8 byte
-//           sums s <= 252.  ((s | 0x80) - (T+1)) has bit 7 set iff (s & 0x7f) > T, and any s >= 0x80 is > T as well; no
-//           borrow crosses a byte because (s | 0x80) >= T + 1.
-//   M = 16: two sets of 4 byte sums; per query A + B <= THR16  <=>  their per-byte average <= (THR16 - 1) / 2, same trick.
-template <int M, bool FINE>
-__device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC * ScanCfg<M>::NQUAD]) {
-  if constexpr (M == 8) {
-    // NQUAD dwords of 4 byte sums per set; FINE: two sets (k < 4, k >= 4), compared through their per-byte average
-    constexpr int NQ = ScanCfg<M>::NQUAD;
-    constexpr uint32_t H = 0x80808080u;
-    constexpr uint32_t TC = (FINE ? (filt_thr8(true) - 1u) / 2u + 1u : filt_thr8(false) + 1u) * 0x01010101u;
-    uint32_t all = H;
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-      uint32_t v = a[j];
-      if constexpr (FINE) v = (a[j] & a[NQ + j]) + (((a[j] ^ a[NQ + j]) >> 1) & 0x7f7f7f7fu);
-      all &= ((v | H) - TC) | v;
-    }
-    return (all & H) != H;
-  } else if constexpr (ScanCfg<M>::NQUAD == 2) {
-    // two sets (k < 8, k >= 8) of 8 byte sums, each <= 248: A + B <= THR  <=>  floor((A + B) / 2) <= (THR - 1) / 2 for
-    // odd THR, and the per-byte average needs no wider fields: (A & B) + (((A ^ B) >> 1) & 0x7f..)
-    static_assert(FILT_THR16 % 2 == 1 && (FILT_THR16 - 1) / 2 < 128, "average trick");
-    constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR16 - 1u) / 2u + 1u) * 0x01010101u;
-    const uint32_t v0 = (a[0] & a[2]) + (((a[0] ^ a[2]) >> 1) & 0x7f7f7f7fu);
-    const uint32_t v1 = (a[1] & a[3]) + (((a[1] ^ a[3]) >> 1) & 0x7f7f7f7fu);
-    const uint32_t g0 = ((v0 | H) - TC) | v0, g1 = ((v1 | H) - TC) | v1;
-    return (g0 & g1 & H) != H;
-  } else {
-    // two sets of 4 byte sums, each <= 248: the per-byte average again (no 16-bit widening: 10 instead of 15 VALU)
-    static_assert(FILT_THR16 % 2 == 1 && (FILT_THR16 - 1) / 2 < 128, "average trick");
-    constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR16 - 1u) / 2u + 1u) * 0x01010101u;
-    const uint32_t v = (a[0] & a[1]) + (((a[0] ^ a[1]) >> 1) & 0x7f7f7f7fu);
-    return ((((v | H) - TC) | v) & H) != H;
-  }
-}
-
-// Exact evaluation of `count` (<= 64, wave-uniform) queued rows by the calling wavefront: lane i takes queue[i].
-template <int M, bool BIAS>
-__device__ __noinline__ void refine_rows(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, const uint8_t *codes,
-                                         const float *row_bias, uint32_t id_offset, uint32_t cap, const float4 *lut4,
-                                         const float4 *gtab, const uint32_t *queue, uint32_t count) {
-  constexpr int QG = ScanCfg<M>::QG;
-  const int lane = threadIdx.x & 63;
-  const bool valid = (uint32_t)lane < count;
-  const uint32_t row = queue[valid ? lane : 0];
-  uint32_t w1[(M + 3) / 4];
-  load_row<M>(w1, codes, row);
-  float acc[QG];
-  row_dists<M>(w1, 0, lut4, gtab, acc);
-  if (BIAS) {
-    const float bias = row_bias[row];
-#pragma unroll
-    for (int q = 0; q < QG; ++q) acc[q] = acc[q] + bias;
-  }
-  float tau[QG];
-#pragma unroll
-  for (int q = 0; q < QG; ++q) tau[q] = ctrl->tau[q];
-  const uint32_t selmask = __builtin_amdgcn_readfirstlane(ctrl->selmask);
-  emit_survivors<QG>(acc, tau, valid, row + id_offset, selmask, ctrl, cand_wg, cap, lane);
-}
-
-// The same queue, evaluated per (row, query) PAIR: of the QG queries of an alive row typically one or two passed the
-// byte bound (the bound is per query, so only those can beat their tau).  Lane i recomputes the byte sums of its row
-// (M gathers from the byte tables, the filter's own arithmetic), and the wavefront then walks the alive queries in
-// rounds: in round j every lane that still has one takes its next alive query q, gathers the M f32 entries
-// T_q[k][b_k] (4-byte gathers), sums them in the reference's order and appends the key if it beats tau_q (one LDS
-// atomic per survivor).  Against refine_rows (M * QG / 4 16-byte gathers per row, QG compares and ballots) this is
-// ~M 4-byte gathers per alive pair.  Soundness: a pair the bound rules out has d >= tau_q (build_qtab), so skipping
-// it cannot change the candidate set below tau.
-#ifndef RQ_REFINE_PAIRS
-#define RQ_REFINE_PAIRS 1
-#endif
-__device__ __forceinline__ uint32_t high_bits4(uint32_t x) {   // bits 7, 15, 23, 31 of x -> bits 0..3
-  return (((x >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xfu;
-}
-
-template <int M, bool FINE>
-__device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<M>::NACC * ScanCfg<M>::NQUAD]) {
-  using Cfg = ScanCfg<M>;
-  if constexpr (M == 8) {
-    constexpr int NQ = Cfg::NQUAD;
-    constexpr uint32_t H = 0x80808080u;
-    constexpr uint32_t TC = (FINE ? (filt_thr8(true) - 1u) / 2u + 1u : filt_thr8(false) + 1u) * 0x01010101u;
-    uint32_t bits = 0;
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-      uint32_t v = a[j];
-      if constexpr (FINE) v = (a[j] & a[NQ + j]) + (((a[j] ^ a[NQ + j]) >> 1) & 0x7f7f7f7fu);
-      bits |= high_bits4(~(((v | H) - TC) | v)) << (4 * j);
-    }
-    return bits;
-  } else if constexpr (Cfg::NQUAD == 2) {
-    constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR16 - 1u) / 2u + 1u) * 0x01010101u;
-    const uint32_t v0 = (a[0] & a[2]) + (((a[0] ^ a[2]) >> 1) & 0x7f7f7f7fu);
-    const uint32_t v1 = (a[1] & a[3]) + (((a[1] ^ a[3]) >> 1) & 0x7f7f7f7fu);
-    const uint32_t g0 = ((v0 | H) - TC) | v0, g1 = ((v1 | H) - TC) | v1;
-    return (high_bits4(~g0) | (high_bits4(~g1) << 4));
-  } else {
-    constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR16 - 1u) / 2u + 1u) * 0x01010101u;
-    const uint32_t v = (a[0] & a[1]) + (((a[0] ^ a[1]) >> 1) & 0x7f7f7f7fu);
-    return high_bits4(~(((v | H) - TC) | v));
-  }
-}
-
-template <int M, bool BIAS, bool FINE>
-__device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, const uint8_t *codes,
-                                          const float *row_bias, uint32_t id_offset, uint32_t cap, const float4 *lut4,
-                                          const float4 *gtab, const uint32_t *qtab, const uint32_t *queue, uint32_t count,
-                                          const uint8_t *norm_bytes) {
-  using Cfg = ScanCfg<M>;
-  constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD, KL = Cfg::KL;
-  static_assert(Cfg::QPG == 4, "pair refinement: float4 table entries");
-  using FV = typename FiltVec<M>::type;
-  const int lane = threadIdx.x & 63;
-  const bool valid = (uint32_t)lane < count;
-  const uint32_t row = queue[valid ? lane : 0];
-  uint32_t w1[(M + 3) / 4];
-  load_row<M>(w1, codes, row);
-  // byte sums of the row, exactly as the hot loop forms them
-  uint32_t a[Cfg::NACC * NQUAD];
-#pragma unroll
-  for (int i = 0; i < Cfg::NACC * NQUAD; ++i) a[i] = 0;
-  const FV *qt = reinterpret_cast<const FV *>(qtab);
-#pragma unroll
-  for (int k = 0; k < M; ++k) {
-    const uint32_t byte = (w1[k >> 2] >> (8 * (k & 3))) & 0xffu;
-    const FV e = qt[k * 256 + byte];
-#pragma unroll
-    for (int j = 0; j < NQUAD; ++j) a[(k / Cfg::kpa(FINE)) * NQUAD + j] += fv_word(e, j);
-  }
-  if constexpr (BIAS) {        // LSQ: the row-norm entry belongs to the last byte sum, as in the hot loop
-    const FV e = qt[M * 256 + norm_bytes[row]];
-#pragma unroll
-    for (int j = 0; j < NQUAD; ++j) a[(Cfg::NACC - 1) * NQUAD + j] += fv_word(e, j);
-  }
-  uint32_t alive = valid ? filt_alive_bits<M, FINE>(a) : 0u;
-  const uint32_t selmask = __builtin_amdgcn_readfirstlane(ctrl->selmask);
-  const float bias = BIAS ? row_bias[row] : 0.0f;
-  const float *lutf = reinterpret_cast<const float *>(lut4);
-  const float *__restrict__ gtf = reinterpret_cast<const float *>(gtab);
-  while (__ballot(alive != 0u)) {
-    if (alive != 0u) {
-      const uint32_t q = (uint32_t)__builtin_ctz(alive);
-      alive &= alive - 1u;
-      const uint32_t qoff = (q >> 2) * 1024u + (q & 3u);       // float index of (quad, component) inside a k block
-      float tg[Cfg::KG > 0 ? Cfg::KG : 1];
-#pragma unroll
-      for (int k = KL; k < M; ++k) {
-        const uint32_t byte = (w1[k >> 2] >> (8 * (k & 3))) & 0xffu;
-        tg[k - KL] = gtf[(uint32_t)(k - KL) * NQUAD * 1024u + qoff + byte * 4u];
-      }
-      float acc = 0.0f;
-#pragma unroll
-      for (int k = 0; k < M; ++k) {
-        const uint32_t byte = (w1[k >> 2] >> (8 * (k & 3))) & 0xffu;
-        const float t = k < KL ? lutf[(uint32_t)k * NQUAD * 1024u + qoff + byte * 4u] : tg[k - KL];
-        acc = (k == 0) ? t : acc + t;        // deps/src/linscan_aqd.cpp:85-87, sequential f32
-      }
-      if (BIAS) acc = acc + bias;
-      if (acc <= ctrl->tau[q]) {
-        const uint32_t pos = atomicAdd(&ctrl->cnt[q], 1u);
-        uint64_t *buf = cand_wg + ((size_t)q * 2 + ((selmask >> q) & 1u)) * cap;
-        buf[pos] = make_key(acc, row + id_offset);
-      }
-    }
-  }
-}
-
-template <int M, bool BIAS, bool FILT, bool FINE>
-__device__ __forceinline__ void refine_queue(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, const uint8_t *codes,
-                                             const float *row_bias, uint32_t id_offset, uint32_t cap, const float4 *lut4,
-                                             const float4 *gtab, const uint32_t *qtab, const uint32_t *queue, uint32_t count,
-                                             const uint8_t *norm_bytes) {
-  if constexpr (FILT && ScanCfg<M>::HAS_FILT && RQ_REFINE_PAIRS)
-    refine_pairs<M, BIAS, FINE>(ctrl, cand_wg, codes, row_bias, id_offset, cap, lut4, gtab, qtab, queue, count, norm_bytes);
-  else
-    refine_rows<M, BIAS>(ctrl, cand_wg, codes, row_bias, id_offset, cap, lut4, gtab, queue, count);
-}
-#define RQ_REFINE(c, cw, cd, rb, io, cp, l4, gt, qu, n) refine_queue<M, BIAS, FILT, FINE>(c, cw, cd, rb, io, cp, l4, gt, qtab, qu, n, p.norm_bytes)
-
-// Cut the candidate buffers of the flagged queries back to exactly K keys and refresh tau.
-template <int M>
-__device__ __forceinline__ void compact_group(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg,
-                                              const ScanParams &p, bool need, int g, int gi, uint32_t &vseq) {
-  constexpr int QG = ScanCfg<M>::QG;
-  constexpr int TPG = ScanCfg<M>::THREADS / QG;
-  const uint32_t cnt = ctrl->cnt[g];
-  const uint32_t sel = ctrl->sel[g];
-  const uint64_t *src = cand_wg + ((size_t)g * 2 + sel) * p.cap;
-  uint64_t *dst = cand_wg + ((size_t)g * 2 + (sel ^ 1u)) * p.cap;
-  radix_select<QG, TPG>(&ctrl->st, src, cnt, (uint32_t)p.K, need, g, gi, vseq);
-  const uint64_t tau_key = ctrl->st.prefix[g];
-  compact_leq<QG, TPG>(&ctrl->st, src, dst, cnt, tau_key, need, g, gi);
-  if (need && gi == 0) {
-    ctrl->cnt[g] = ctrl->st.newcnt[g];  // == K (keys are unique)
-    ctrl->sel[g] = sel ^ 1u;
-    atomicXor(&ctrl->selmask, 1u << g);
-    ctrl->tau[g] = key_dist(tau_key);
-  }
-  __syncthreads();
-}
-
-// Second threshold estimate, once per item after the first `f` of the slice's rows: the candidates collected so far
-// are an exact sample of that fraction, so the number of them below the true K-th distance is Binomial(K, f); tau
-// becomes the distance of the candidate of rank  K f + z sqrt(K f (1 - f)) + 2  (z = 6), which lets ~K + z sqrt(K/f)
-// rows through the whole slice instead of the first estimate's 1.5-2.5 K: fewer exact re-evaluations, appends and
-// keys to cut at the end.  The candidates ABOVE the new tau are dropped on the spot (one compaction pass over the few
-// hundred keys collected so far): they can only matter if fewer than K rows beat the new tau, and in that case the
-// end-of-slice check (cnt < K) redoes the slice exactly anyway.  So the invariant of the streaming loop holds before and
-// after: the buffer is exactly the set of rows seen so far with dist <= tau -- which is what makes a later capacity cut
-// (K smallest keys, tau = the K-th) exact.  (Round 2 kept the stale candidates and a correction count instead; a
-// capacity cut after the estimate could then keep stale keys above the new tau and silently lose rows in between --
-// ADVICE r2; flagging such cuts for the exact redo instead made 6 % of the items of a 1e9-row scan fall back.)
-template <int M>
-__device__ __noinline__ uint32_t retune_tau(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, uint32_t cap, uint32_t r2,
-                                            uint32_t vseq) {
-  constexpr int QG = ScanCfg<M>::QG;
-  constexpr int TPG = ScanCfg<M>::THREADS / QG;
-  const int g = threadIdx.x / TPG, gi = threadIdx.x % TPG;
-  const uint32_t cnt = ctrl->cnt[g];
-  const uint32_t sel = ctrl->sel[g];
-  const bool act = cnt > r2 && r2 >= 1;
-  const uint64_t *src = cand_wg + ((size_t)g * 2 + sel) * cap;
-  uint64_t *dst = cand_wg + ((size_t)g * 2 + (sel ^ 1u)) * cap;
-  radix_select<QG, TPG>(&ctrl->st, src, cnt, r2, act, g, gi, vseq);
-  const uint32_t td = (uint32_t)(ctrl->st.prefix[g] >> 32);     // ordered bits of the r2-th smallest distance
-  const bool tighten = act && ord2f(td) < ctrl->tau[g];          // (tau is rewritten behind compact_leq's barriers)
-  // keep every key whose DISTANCE is <= the new tau (all ids): the inclusive rule of emit_survivors
-  compact_leq<QG, TPG>(&ctrl->st, src, dst, cnt, ((uint64_t)td << 32) | 0xFFFFFFFFull, tighten, g, gi);
-  if (tighten && gi == 0) {
-    ctrl->tau[g] = ord2f(td);
-    ctrl->cnt[g] = ctrl->st.newcnt[g];
-    ctrl->sel[g] = sel ^ 1u;
-    atomicXor(&ctrl->selmask, 1u << g);
-  }
-  __syncthreads();
-  return vseq;
-}
 
 // phase accounting (diagnostics only; p.stats == nullptr in normal runs)
 #define RQ_STAT_T() ((p.stats && threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull)
 #define RQ_STAT_ADD(slot, t0) do { if (p.stats && threadIdx.x == 0) atomicAdd(&p.stats[slot], (unsigned long long)clock64() - (t0)); } while (0)
 #define RQ_STAT_INC(slot) do { if (p.stats && threadIdx.x == 0) atomicAdd(&p.stats[slot], 1ull); } while (0)
-
-// Large-K finish of one work item (out of line: keeps the streaming loop's register allocation
-// independent of it).  cnt/sel: the item's per-query candidate counts and current buffer halves.
-template <int NT>
-__device__ __noinline__ void finish_bigk(const uint32_t *cnt_q, const uint32_t *sel_q, uint32_t QG, uint64_t *cand_wg,
-                                         uint16_t *bkt, uint32_t cap, uint32_t K, uint32_t q0, uint32_t nq,
-                                         uint64_t *keys_base, uint32_t key_stride, float *dists, uint32_t *ids,
-                                         uint32_t id_base, unsigned char *lds, unsigned long long *stats) {
-  const uint32_t tid = threadIdx.x;
-#pragma unroll 1
-  for (uint32_t q = 0; q < QG; ++q) {
-    const uint32_t qq = q0 + q;
-    if (qq >= nq) break;
-    const uint32_t cnt = cnt_q[q], sel = sel_q[q];
-    const uint64_t *src = cand_wg + ((size_t)q * 2 + sel) * cap;
-    uint64_t *dst = cand_wg + ((size_t)q * 2 + (sel ^ 1u)) * cap;
-    const uint32_t n_out = min(K, cnt);
-    if (keys_base) {
-      uint64_t *o = keys_base + (size_t)qq * key_stride;
-      for (uint32_t i = n_out + tid; i < K; i += NT) o[i] = KEY_MAX;   // short slice
-      samplesort_topk<NT>(src, dst, bkt, cnt, n_out, lds, [o](uint32_t r, uint64_t key) { o[r] = key; }, stats);
-    } else {
-      float *od = dists + (size_t)qq * K;
-      uint32_t *oi = ids + (size_t)qq * K;
-      samplesort_topk<NT>(src, dst, bkt, cnt, n_out, lds, [od, oi, id_base](uint32_t r, uint64_t key) {
-        od[r] = key_dist(key);
-        oi[r] = key_id(key) + id_base;
-      }, stats);
-    }
-  }
-}
 
 template <int M, bool BIAS, bool FILT, bool FINE = false>
 __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanParams p) {
@@ -1149,7 +316,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
         if (filt_on && base == r_begin + (uint32_t)Cfg::VP * BLK) {
           // (60 % since the exact evaluation is per pair: at Deep1M shape, k = 10000, 29 % of the first block's rows are alive
           // and the filter still wins -- 10.2 ms against 14.9 with the old 12 / 30 % limits)
-          constexpr uint32_t MAX_SHARE_PCT = RQ_MAX_SHARE;
+          constexpr uint32_t MAX_SHARE_PCT = FILT_MAX_SHARE_PCT;
           if (__builtin_amdgcn_readfirstlane(ctrl->fpush) * 100u > (uint32_t)BLK * MAX_SHARE_PCT) {
             while (qtail) {
               const uint32_t take = min(qtail, 64u);
@@ -1167,7 +334,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
 
       // (norm-adding kernels with 32 gathers per row: one sub-step at a time -- with all U code words live next to a row's
       // 64 + 32 registers of table entries the allocator spilled the code words themselves, 160 registers in all)
-      constexpr int UCH = (BIAS && M * Cfg::NQUAD >= 32 && RQ_UCH_WIDE_BIAS < Cfg::U) ? RQ_UCH_WIDE_BIAS : Cfg::U;
+      constexpr int UCH = (BIAS && M * Cfg::NQUAD >= 32 && 4 < Cfg::U) ? 4 : Cfg::U;
 #pragma unroll 1
       for (int uc = 0; uc < Cfg::U; uc += UCH) {
       // the thread's rows of this block: U sub-steps of RPT rows, each one packed little-endian
@@ -1241,7 +408,8 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
           // all RPT * M gathers of the sub-step are issued before the first sum (16 x ds_read_b64 / 32 x ds_read_b32)
           using FV = typename FiltVec<M>::type;
           const FV *qt = reinterpret_cast<const FV *>(qtab);
-          const uint32_t shreg = sizeof(FV) == 16 ? 4u : sizeof(FV) == 8 ? 3u : 2u;
+          static_assert(sizeof(FV) == 8, "byte tables: 8 queries per ds_read_b64");
+          const uint32_t shreg = 3u;
           // gathers in flight together: 16 (M = 8: both rows of the sub-step; M = 16: one row -- 32 of them with
           // their 32 addresses spill registers in this loop)
           constexpr int RB = (RPT * M * (int)sizeof(FV) > 128) ? 1 : RPT;      // rows per gather batch: <= 32 registers of entries
@@ -1254,7 +422,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
 #pragma unroll
             for (int k = 0; k < M; ++k) {
               // address = byte * sizeof(FV) (one SDWA shift) + compile-time offset of table k (in the instruction)
-              constexpr int SH = sizeof(FV) == 16 ? 4 : sizeof(FV) == 8 ? 3 : 2;
+              constexpr int SH = 3;
               const uint32_t w32 = w[(r * M + k) >> 2];
               uint32_t boff;
               switch ((r * M + k) & 3) {
@@ -1269,7 +437,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
               e[r][k] = lds_abs_load<FV>(boff + (uint32_t)(CTRL_BYTES + k * 256 * sizeof(FV)));
             }
             if constexpr (BIAS) {      // the row-norm table, indexed by the row's norm byte
-              constexpr int SHN = sizeof(FV) == 16 ? 4 : sizeof(FV) == 8 ? 3 : 2;
+              constexpr int SHN = 3;
               uint32_t boff;
               switch (r & 3) {
                 case 0: boff = byte_shl<0, SHN>(nbw[u], shreg); break;
