@@ -330,7 +330,8 @@ def main():
             enc_roof["bf16_mfma"] = {"issued_TFLOPs": round(bf_flops / (enc_ms_step * 1e-3) / 1e12, 1), "peak": 2500.0,
                                      "frac": round(bf_flops / (enc_ms_step * 1e-3) / 1e12 / 2500.0, 4)}
         if use_R:
-            enc_roof["note"] = "includes the R'X rotation kernel (2*d*d flop/vector more, not counted in achieved)"
+            enc_roof["note"] = (enc_roof.get("note", "") + "; time includes the R'X rotation kernel (2*d*d f32-MFMA flop per vector more, "
+                                "not counted in achieved)").lstrip("; ")
         encode = {"metric": "encode vectors/sec (%s)" % ("quantize_opq" if use_R else "quantize_pq"),
                   "value": round(n / (enc_ms_step * 1e-3), 1), "unit": "vectors/s", "ms_per_step": round(enc_ms_step, 4),
                   "roofline": enc_roof}
