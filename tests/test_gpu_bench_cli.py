@@ -78,3 +78,29 @@ def test_world_size_mismatch_is_an_error_not_a_silent_single_gpu_run():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, timeout=300,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert p.returncode == 2 and "WORLD_SIZE" in p.stderr
+
+
+def test_default_command_shape_single_gpu_contract():
+    """`python bench.py --steps K --warmup W` at N = 1 (the driver's BENCH run, shrunk): ONE JSON line carrying the contract's
+    fields plus `roofline` and `cpu_baseline`, the GPU answer equal to the compiled reference (or the oracle port) bit for
+    bit, codes equal to the oracle's."""
+    line = _run(["--rows", "200000", "--nq", "512", "--k", "100", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["dtype"] == "f32"
+    assert line["data"] == "synthetic" and line["vs_baseline"] is None and "workload" in line["config"]
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] in ("lds", "hbm", "mfma") and 0 < roof["frac"] and roof["kernel_ms"] > 0
+    cpu = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] in ("reference", "port") and cpu["gpu_matches_cpu_bit_exact"] is True
+    assert cpu["encode"]["codes_match"] is True
+    enc = line["encode"]
+    assert enc["value"] > 0 and enc["roofline"]["kernel"] == "encode_pq_split_kernel"
+    assert line["checks"]["ascending"] and line["checks"]["ids_unique_per_query"]
+    assert line["host_path"]["same_answer_as_resident"] is True
+    assert line["recall"]["r@1"] > 0.2

@@ -71,3 +71,24 @@ def test_small_results_stay_in_numpy_memory(rq):
     from rayuela_jl_amd import _lib
     x = _lib.result_empty((100, 10), np.float32)
     assert x.flags.owndata
+
+
+def test_large_results_take_the_chunked_copy_path(rq):
+    """Results above HOST_DIRECT_MAX_MB are not stored over PCIe by the kernel but copied chunk by chunk behind the scans
+    (k = 10000: 800 MB per 1e4 queries).  Forced here with a 1 MB limit; the answer is the same either way."""
+    import rayuela_jl_amd.synth as synth
+    rng = np.random.default_rng(8)
+    m, sub, n, nq, K = 8, 4, 60_000, 9_000, 128           # 9000 queries >= 2 host chunks of 4096; 4.6 MB per result array: page-locked
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    C = [centers[i] for i in range(m)]
+    Q = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    B = synth.random_codes(n, m, seed=3)
+    d0, i0 = rq.linscan_pq(B, Q, C, 8 * m, K)
+    rq.set_tuning("HOST_DIRECT_MAX_MB", 1)
+    try:
+        d1, i1 = rq.linscan_pq(B, Q, C, 8 * m, K)
+        ts = rq.last_timing()
+    finally:
+        rq.set_tuning("HOST_DIRECT_MAX_MB", 0)
+    assert np.array_equal(i0, i1) and np.array_equal(d0.view(np.uint32), d1.view(np.uint32))
+    assert ts["d2h_ms"] > 0.0          # copies happened (the direct path reports 0)
