@@ -153,7 +153,7 @@ function linscan_pq(B::Matrix{UInt8}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat
   res   = _result(Cuint,  k, nq)
   _check(ccall((:rq_linscan_pq, librayuela_hip), Cint,
     (Ptr{Cfloat}, Ptr{Cuint}, Ptr{Cuchar}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Int64, Cint, Cint, Cint, Cint),
-    dists, res, B, cat(C..., dims=3), X, Int64(n), Int64(nq), Cint(b ÷ 8), Cint(d), Cint(k), Cint(1)))
+    dists, res, B, cat(C..., dims=3), X, Int64(n), Int64(nq), Cint(m), Cint(d), Cint(k), Cint(1)))
   return dists, res
 end
 
@@ -173,7 +173,7 @@ function linscan_opq(B::Matrix{UInt8}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloa
   res   = _result(Cuint,  k, nq)
   _check(ccall((:rq_linscan_opq, librayuela_hip), Cint,
     (Ptr{Cfloat}, Ptr{Cuint}, Ptr{Cuchar}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Int64, Cint, Cint, Cint, Cint),
-    dists, res, B, cat(C..., dims=3), X, R, Int64(n), Int64(nq), Cint(b ÷ 8), Cint(d), Cint(k), Cint(1)))
+    dists, res, B, cat(C..., dims=3), X, R, Int64(n), Int64(nq), Cint(m), Cint(d), Cint(k), Cint(1)))
   return dists, res
 end
 
