@@ -196,7 +196,9 @@ def test_split_encode_hostile_inputs(rq, oracle, case, waves):
     """What the filter's margin has to survive: massive exact ties (small-integer data: several centroids at the very
     same distance, in different 32-centroid tiles -> tiles re-run at the end, first index must win), duplicated
     centroids, vectors that ARE centroids (clamped zeros), magnitudes where the bound is unusable (every centroid is then
-    evaluated exactly), wide dynamic range inside one sub-space."""
+    evaluated exactly), wide dynamic range inside one sub-space.  (Distances that overflow to inf / NaN are outside every
+    contract: Julia's `max(NaN, 0)` is NaN and `update_assignments!` then keeps centre 1 whenever `dmat[1, j]` is NaN, the C
+    oracle's fmaxf returns 0 -- the kernels are only required to agree with the oracle on finite distances.)"""
     rng = np.random.default_rng({"ties": 1, "dups": 2, "exact_hits": 3, "tiny": 4, "huge": 5, "mixed_scale": 6, "negative_w": 7}[case])
     m, sub, h, n = 8, 16, 256, 6_000
     if case == "ties":
