@@ -157,6 +157,134 @@ __global__ __launch_bounds__(NT) void filt_nib_kernel(const uint8_t *__restrict_
   if (lane == 0) atomicAdd(alive_out, alive_total);
 }
 
+// Cascade: level A = the nibble filter above for 16 queries; rows it lets through wait in a per-wave queue and get level B,
+// 64 rows at a time: the byte tables of BOTH 8-query groups (2 x 8 ds_read_b64 per row), alive test per group, survivors
+// counted (the exact evaluation would take them from there).  thrA tunes the share of rows that reach level B.
+template <int NT>
+__global__ __launch_bounds__(NT) void filt_casc_kernel(const uint8_t *__restrict__ codes, const uint2 *__restrict__ tabs, const uint2 *__restrict__ ntabs, uint32_t n,
+                                                       uint32_t ngroups, uint32_t nslices, uint32_t rows_per_slice,
+                                                       uint32_t thrA, uint32_t thrB, unsigned long long *alive_out, uint32_t *counter) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint2 *qn = reinterpret_cast<uint2 *>(smem);                       // [8][256] nibble entries (16 queries)
+  uint2 *qb = qn + 8 * 256;                                          // [2][8][256] byte entries (8 queries each)
+  uint32_t *queue = reinterpret_cast<uint32_t *>(qb + 2 * 8 * 256);  // [NT/64][256] row ids
+  __shared__ uint32_t s_item;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t *myq = queue + __builtin_amdgcn_readfirstlane(wave * 256);
+  unsigned long long alive_total = 0, reachedB = 0;
+  const uint32_t nitems = ngroups * nslices;
+  auto levelB = [&](uint32_t row, bool valid) -> uint32_t {
+    const uint2 cw = valid ? *reinterpret_cast<const uint2 *>(codes + (size_t)row * 8) : make_uint2(0, 0);
+    const uint32_t w[2] = {cw.x, cw.y};
+    uint32_t hits = 0;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      uint2 e[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = qb[(g * 8 + k) * 256 + ((w[k >> 2] >> (8 * (k & 3))) & 0xffu)];
+      uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { a0 += e[k].x; a1 += e[k].y; }
+      constexpr uint32_t H = 0x80808080u;
+      const uint32_t TC = (thrB + 1u) * 0x01010101u;
+      const uint32_t g0 = ((a0 | H) - TC) | a0, g1 = ((a1 | H) - TC) | a1;
+      hits += (valid && ((g0 & g1 & H) != H)) ? 1u : 0u;
+    }
+    return hits;
+  };
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_item = atomicAdd(counter, 1u);
+    __syncthreads();
+    const uint32_t item = s_item;
+    if (item >= nitems) break;
+    const uint32_t group = item % ngroups, slice = item / ngroups;
+    for (int i = tid; i < 8 * 256; i += NT) qn[i] = ntabs[(size_t)group * 8 * 256 + i];
+    for (int i = tid; i < 2 * 8 * 256; i += NT) qb[i] = tabs[((size_t)group * 2 * 8 * 256 + i) % ((size_t)ngroups * 8 * 256)];
+    __syncthreads();
+    const uint32_t r_begin = slice * rows_per_slice, r_end = min(n, r_begin + rows_per_slice);
+    uint32_t qtail = 0;
+    constexpr int U = 2;
+    for (uint32_t base = r_begin; base < r_end; base += NT * 2 * U) {
+      uint4 wu[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t row0 = base + u * NT * 2 + tid * 2;
+        wu[u] = row0 + 2 <= r_end ? *reinterpret_cast<const uint4 *>(codes + (size_t)row0 * 8) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t w[4] = {wu[u].x, wu[u].y, wu[u].z, wu[u].w};
+        const uint32_t row0 = base + u * NT * 2 + tid * 2;
+        uint2 e[2][8];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) e[r][k] = qn[k * 256 + ((w[(r * 8 + k) >> 2] >> (8 * ((r * 8 + k) & 3))) & 0xffu)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          uint32_t b[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) {
+            const uint32_t px = e[r][k].x + e[r][k + 1].x, py = e[r][k].y + e[r][k + 1].y;
+            b[0] += px & 0x0f0f0f0fu; b[1] += (px >> 4) & 0x0f0f0f0fu;
+            b[2] += py & 0x0f0f0f0fu; b[3] += (py >> 4) & 0x0f0f0f0fu;
+          }
+          constexpr uint32_t H = 0x80808080u;
+          const uint32_t TC = (thrA + 1u) * 0x01010101u;
+          uint32_t g = H;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) g &= ((b[i] | H) - TC) | b[i];
+          const bool cand = ((g & H) != H) && (row0 + r < r_end);
+          const uint64_t mq = __ballot(cand);
+          if (mq) {
+            if (cand) myq[qtail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u))] = row0 + r;
+            qtail += (uint32_t)__popcll(mq);
+          }
+        }
+        while (qtail >= 64u) {          // level B for 64 queued rows
+          qtail -= 64u;
+          alive_total += levelB(myq[qtail + lane], true);
+          reachedB += 1;
+        }
+      }
+    }
+    if (qtail) { alive_total += levelB(myq[lane < qtail ? lane : 0], lane < qtail); reachedB += (lane < qtail) ? 1 : 0; qtail = 0; }
+  }
+  atomicAdd(alive_out, alive_total);
+  atomicAdd(alive_out + 1, reachedB);
+}
+
+template <int NT>
+static void run_casc(const uint8_t *codes, const uint2 *tabs, const uint2 *ntabs, uint32_t n, uint32_t nq, uint32_t thrA, uint32_t thrB, int wgs_per_cu) {
+  const uint32_t ngroups = nq / 16;
+  const uint32_t grid = 256 * wgs_per_cu;
+  uint32_t nslices = ngroups >= grid ? 1 : (grid + ngroups - 1) / ngroups;
+  uint32_t rps = (n + nslices - 1) / nslices;
+  rps = (rps + NT * 4 - 1) / (NT * 4) * (NT * 4);
+  nslices = (n + rps - 1) / rps;
+  unsigned long long *alive; uint32_t *counter;
+  hipMalloc(&alive, 16); hipMalloc(&counter, 4);
+  const size_t lds = (size_t)3 * 8 * 256 * 8 + (size_t)(NT / 64) * 256 * 4;
+  hipFuncSetAttribute(reinterpret_cast<const void *>(filt_casc_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9;
+  unsigned long long al[2] = {0, 0};
+  for (int rep = 0; rep < 4; ++rep) {
+    hipMemset(alive, 0, 16); hipMemset(counter, 0, 4);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((filt_casc_kernel<NT>), dim3(grid), dim3(NT), lds, 0, codes, tabs, ntabs, n, ngroups, nslices, rps, thrA, thrB, alive, counter);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+    hipMemcpy(al, alive, 16, hipMemcpyDeviceToHost);
+  }
+  printf("CASCADE NT=%4d WGs/CU=%d thrA=%u: %.3f ms for 1e10 (row, query) pairs; rows reaching level B %.2f%%, (row, 8-query group) alive after B %.3f%%  err=%s\n",
+         NT, wgs_per_cu, thrA, best, 100.0 * (double)al[1] * (NT >= 0 ? 1.0 : 1.0) / ((double)n * (nq / 16)) * 1.0, 100.0 * (double)al[0] / ((double)n * (nq / 8)),
+         hipGetErrorString(hipGetLastError()));
+}
+
 template <int NT>
 static void run_nib(const uint8_t *codes, const uint2 *tabs, uint32_t n, uint32_t nq, uint32_t thr, int wgs_per_cu) {
   const uint32_t ngroups = nq / 16;
@@ -223,6 +351,9 @@ int main() {
   hipMalloc(&codes, hc.size()); hipMalloc(&tabs, ht.size());
   hipMemcpy(codes, hc.data(), hc.size(), hipMemcpyHostToDevice);
   hipMemcpy(tabs, ht.data(), ht.size(), hipMemcpyHostToDevice);
+  std::vector<uint8_t> hn((size_t)(nq / 16) * 8 * 256 * 8);
+  for (auto &t : hn) t = (uint8_t)(((rand() >> 8) % 8) | (((rand() >> 8) % 8) << 4));   // nibble entries 0..7
+  uint2 *ntabs; hipMalloc(&ntabs, hn.size()); hipMemcpy(ntabs, hn.data(), hn.size(), hipMemcpyHostToDevice);
   const uint32_t thr = 62;   // ~ a few % of (row, set) pairs alive
   run<512, 8>(codes, tabs, n, nq, thr, 2);
   run<512, 8>(codes, tabs, n, nq, thr, 4);
@@ -233,6 +364,7 @@ int main() {
   run<512, 32>(codes, tabs, n, nq, thr, 2);
   run<1024, 32>(codes, tabs, n, nq, thr, 2);
   run<1024, 32>(codes, tabs, n, nq, thr, 1);
+  for (uint32_t tA : {9u, 11u, 13u, 15u, 17u}) { run_casc<512>(codes, tabs, ntabs, n, nq, tA, 62, 2); run_casc<512>(codes, tabs, ntabs, n, nq, tA, 62, 4); run_casc<1024>(codes, tabs, ntabs, n, nq, tA, 62, 1); }
   run_nib<512>(codes, tabs, n, nq, 40, 2);
   run_nib<512>(codes, tabs, n, nq, 40, 4);
   run_nib<1024>(codes, tabs, n, nq, 40, 2);
