@@ -107,8 +107,8 @@ def load_traffic(kernel_key):
     """HBM/fabric bytes per launch of `kernel_key` from the NEWEST committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE, separate runs; FETCH doubled per MI355X_MICROARCH.md section HBM).  Only the newest round's file counts:
     a shape that was not re-measured after the kernels changed reports null, never an older round's bytes
-    (tools/profile_round3.sh + tools/collect_profiles.py rewrite the file)."""
-    for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+    (tools/profile_round4.sh + tools/collect_profiles.py rewrite the file)."""
+    for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -267,6 +267,8 @@ def main():
         out = (torch.empty((nq, K), dtype=torch.float32, device=device),
                torch.empty((nq, K), dtype=torch.int32, device=device))
 
+        # the headline call: raw resident codes in, like linscan_pq's B -- the library orders a scratch copy of the base
+        # INSIDE the call when that pays (nq >= 2048: csrc/rq_order.hip), so that time is part of every timed step
         def scan():
             res["r"] = rqd.linscan(codes, centers, Qs, K, out=out)
     else:
@@ -282,14 +284,41 @@ def main():
     if a.inproc:
         scan_ms = scan_wall      # the library's own streams do the work: host wall clock is the step time
 
-    # the scan kernel alone on this rank's shard (roofline): HIP events on the stream it is launched on
+    # the scan kernel alone on this rank's shard (roofline): HIP events on the stream it is launched on.  The base is put in
+    # bank-aware row order ONCE here (rq_dev_order_rows: what an index handle does at load time), so the launches below are
+    # the scan kernel and nothing else -- the same kernel on the same ordered rows as inside the headline call.
     kern_ms = None
+    order_info = None
     if not a.inproc:
         kl = min(K, n_local)
         kout = torch.empty((nq, kl), dtype=torch.int64, device=device)
-        kern_total, _ = timed(lambda: rqd.linscan(codes, centers, Qs, kl, id_offset=r0, want_keys=True, out=kout),
-                              max(2, min(a.steps, 10)), 1, barrier)
-        kern_ms = kern_total / max(2, min(a.steps, 10))
+        ks = max(2, min(a.steps, 10))
+        ordered = rqd.order_rows(codes) if os.environ.get("RQ_SCAN_ORDER", "1") != "0" else codes
+        kern_total, _ = timed(lambda: rqd.linscan(ordered, centers, Qs, kl, id_offset=r0, want_keys=True, out=kout), ks, 1, barrier)
+        kern_ms = kern_total / ks
+        if world == 1 and ordered is not codes:
+            # the three ways to run the same scan, same answer bit for bit (checked below):
+            #   in_call   = the headline (`value`): arrival-order codes in, ordering inside every call
+            #   prepared  = the base ordered once (index handle / rq_dev_order_rows), searches pay nothing for it
+            #   arrival   = ordering switched off (round 3's path)
+            o2 = (torch.empty((nq, K), dtype=torch.float32, device=device), torch.empty((nq, K), dtype=torch.int32, device=device))
+            prep_ms, _ = timed(lambda: rqd.linscan(ordered, centers, Qs, K, out=o2), a.steps, a.warmup, barrier)
+            same_prep = bool(torch.equal(o2[0].view(torch.int32), res["r"][0].view(torch.int32)) and torch.equal(o2[1], res["r"][1]))
+            ord_ms, _ = timed(lambda: rqd.order_rows(codes), 3, 1, barrier)
+            rq.set_tuning("SCAN_ORDER", 0)
+            arr_ms, _ = timed(lambda: rqd.linscan(codes, centers, Qs, K, out=o2), a.steps, a.warmup, barrier)
+            rq.set_tuning("SCAN_ORDER", 1)
+            same_arr = bool(torch.equal(o2[0].view(torch.int32), res["r"][0].view(torch.int32)) and torch.equal(o2[1], res["r"][1]))
+            order_info = {
+                "what": "bank-aware row order of the base (csrc/rq_order.hip): rows sorted by the top 3 bits of their leading code "
+                        "bytes so that the 32 lanes of an LDS table gather hit distinct bank columns; ids stay original row numbers",
+                "in_call_ms_per_step": round(scan_ms / a.steps, 4),
+                "prepared_ms_per_step": round(prep_ms / a.steps, 4), "prepared_value": round(nq / (prep_ms / a.steps * 1e-3), 1),
+                "order_rows_ms_once": round(ord_ms / 3, 4),
+                "arrival_order_ms_per_step": round(arr_ms / a.steps, 4), "arrival_order_value": round(nq / (arr_ms / a.steps * 1e-3), 1),
+                "answers_identical": bool(same_prep and same_arr)}
+            del o2
+        del ordered
 
     vals = [scan_ms, enc_ms or 0.0, scan_wall, kern_ms or 0.0]
     if world > 1:
@@ -506,13 +535,15 @@ def main():
             codes = None
             torch.cuda.empty_cache()
             whole = rqd.synth_codes(n, m, synth.SEED_BASE, row0=0, device=device)
+            whole_o = rqd.order_rows(whole)          # like the shards of the N-GPU run: ordered once, outside the timed steps
+            del whole
             o1 = (torch.empty((nq, K), dtype=torch.float32, device=device), torch.empty((nq, K), dtype=torch.int32, device=device))
-            t_ms, _ = timed(lambda: rqd.linscan(whole, centers, Qs, K, out=o1), 2, 1, lambda: None)
+            t_ms, _ = timed(lambda: rqd.linscan(whole_o, centers, Qs, K, out=o1), 2, 1, lambda: None)
             same = bool(np.array_equal(o1[1].cpu().numpy().view(np.uint32), ri_h) and
                         np.array_equal(o1[0].cpu().numpy().view(np.uint32), rd_h.view(np.uint32)))
             ref1 = {"n_gpus": 1, "ms_per_step": round(t_ms / 2, 3), "value": round(nq / (t_ms / 2 * 1e-3), 1),
                     "answer_identical_to_the_sharded_run": same}
-            del whole
+            del whole_o
         except Exception as e:   # noqa: BLE001 -- an anchor, not the measurement
             ref1 = {"error": repr(e)[:200]}
 
@@ -524,13 +555,21 @@ def main():
         try:
             nA, nqA, kA = 1_000_000_000, 1024, 100
             whole = rqd.synth_codes(nA, m, synth.SEED_BASE, row0=0, device=device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            whole_o = rqd.order_rows(whole)          # what the ranks of an N-GPU run do with their shards, once
+            e1.record()
+            torch.cuda.synchronize()
+            del whole
+            whole = whole_o
             qA = Qs[:nqA].contiguous()
             oA = (torch.empty((nqA, kA), dtype=torch.float32, device=device), torch.empty((nqA, kA), dtype=torch.int32, device=device))
             t_ms, _ = timed(lambda: rqd.linscan(whole, centers, qA, kA, out=oA), 2, 1, lambda: None)
             anchor = {"workload": "SIFT1B-shape base (synthetic uint8 codes) m=8 h=256 ADC linscan: what `--gpus N` (N > 1) shards",
                       "n_base_total": nA, "nq": nqA, "k": kA, "n_gpus": 1, "ms_per_step": round(t_ms / 2, 3),
-                      "value": round(nqA / (t_ms / 2 * 1e-3), 1), "unit": "queries/s"}
-            del whole, oA
+                      "value": round(nqA / (t_ms / 2 * 1e-3), 1), "unit": "queries/s",
+                      "base_ordered_once_ms": round(e0.elapsed_time(e1), 2)}
+            del whole, whole_o, oA
             torch.cuda.empty_cache()
         except Exception as e:   # noqa: BLE001 -- an anchor, not the measurement
             anchor = {"error": repr(e)[:200]}
@@ -560,6 +599,7 @@ def main():
         "recall": recall,
         "checks": checks,
         "host_path": host,
+        "row_order": order_info if world == 1 else ({"index_prepare_ms": round(ix.order_ms, 3)} if (world > 1 and ix.order_ms is not None) else None),
         "same_workload_1gpu": ref1,
         "scale_anchor_1gpu": anchor,
         "wall_ms_per_step": round(scan_wall / a.steps, 4),

@@ -160,6 +160,26 @@ int rq_dev_adc_lut(float *lut, const float *centers, const float *queries, int64
 int rq_dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes,
                    const float *centers, const float *queries, int64_t n, int64_t nq, int m,
                    int d, int k, uint32_t id_offset, int id_base, void *stream);
+/* Bank-aware row order of a resident base (round 4, csrc/rq_order.hip).  No reference counterpart: the reference scans
+ * rows in arrival order (deps/src/linscan_aqd.cpp:78-89); the result of the scan -- the k smallest (dist, id) pairs, :91-97
+ * -- does not depend on the order rows are visited in, so this is a data-layout choice in HBM, invisible in the answer.
+ * The scan's table gathers are LDS-bank-conflict bound; rows sorted by the top 3 bits of their leading code bytes make
+ * the 32 lanes of a gather hit 32 distinct bank columns (SIFT1M shape: 2.45 -> 2.1 ms at k = 1000, more on larger bases).
+ *   rq_dev_linscan           orders a scratch copy itself when that pays (tuning SCAN_ORDER = 1: from ORDER_MIN_NQ = 2048
+ *                            queries and ORDER_MIN_ROWS = 65536 rows on; ~40 us per 1e6 rows, inside the call's time)
+ *   rq_index_set_codes[_synth]  order every shard once, at load time (tuning INDEX_ORDER = 1)
+ *   rq_dev_order_rows        the same for callers that keep device-resident codes: `ordered` (rq_order_bytes(n, m) bytes,
+ *                            16-byte aligned) receives the permuted rows, padded to rq_scan_row_width(m) bytes each, and
+ *                            perm [n] (position -> original row); *codes_out / *perm_out point into it (*perm_out = NULL
+ *                            for a base too small to order)
+ *   rq_dev_linscan_ordered   rq_dev_linscan over such a pair: ids / keys carry ORIGINAL row numbers (+ id_offset)   */
+int rq_scan_row_width(int m);
+int64_t rq_order_bytes(int64_t n, int m);
+int rq_dev_order_rows(void *ordered, const uint8_t **codes_out, const uint32_t **perm_out, const uint8_t *codes,
+                      int64_t n, int m, void *stream);
+int rq_dev_linscan_ordered(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes_ordered,
+                           const uint32_t *perm, const float *centers, const float *queries, int64_t n,
+                           int64_t nq, int m, int d, int k, uint32_t id_offset, int id_base, void *stream);
 /* Merge P sorted key lists per query: keys_in [nq][P][k] -> dists/ids [nq][k] (and/or
  * keys_out [nq][k]).  Total order on (dist,id) makes the result identical to a single scan. */
 int rq_dev_merge_topk(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t *keys_in,

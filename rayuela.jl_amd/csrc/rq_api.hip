@@ -345,10 +345,37 @@ struct Timer {
   }
 };
 
+// ---- bank-aware row order of a resident base (rq_order.hip) ---------------------------------------------
+bool order_pays(int64_t n, int64_t nq) {
+  const int mode = tuning("SCAN_ORDER", 1);
+  if (mode <= 0 || n < tuning("ORDER_MIN_ROWS", 65536)) return false;
+  return mode > 1 || nq >= tuning("ORDER_MIN_NQ", 2048);
+}
+
+size_t order_base_bytes(int64_t n, int mp) { return (((size_t)n * mp + 255) & ~(size_t)255) + (size_t)n * 4; }
+
+// codes [n][mp] (already padded to a tiled width) -> *out_codes [n][mp] in bank-aware order + *out_perm [n], both inside
+// `dst` (order_base_bytes).  The key scratch comes from the (device, stream) workspace.
+int order_base(const uint8_t **out_codes, const uint32_t **out_perm, void *dst, const uint8_t *codes, int64_t n, int mp,
+               hipStream_t stream) {
+  int nb[8];
+  const int bits = order_key_bits(n, mp, nb);
+  if (bits <= 0) return RQ_OK;          // tiny base: stays as it is (*out_perm untouched = nullptr)
+  void *tmp = nullptr;
+  RQ_TRY(workspace(WS_ORDER_TMP, order_scratch_bytes(n, bits), &tmp, stream));
+  int rpt = 1, gran = 512;
+  scan_order_tiling(mp, &rpt, &gran);
+  uint32_t *pm = reinterpret_cast<uint32_t *>((uint8_t *)dst + (order_base_bytes(n, mp) - (size_t)n * 4));
+  RQ_TRY(order_rows_launch((uint8_t *)dst, pm, codes, n, mp, tmp, rpt, gran, stream));
+  *out_codes = (const uint8_t *)dst;
+  *out_perm = pm;
+  return RQ_OK;
+}
+
 // ---- shared implementation of the scan on device pointers --------------------------------------------
 int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes, const float *centers,
                 const float *queries, int64_t n, int64_t nq, int m, int d, int k, uint32_t id_offset,
-                int id_base, hipStream_t stream, int lut_mode, const float *row_bias) {
+                int id_base, hipStream_t stream, int lut_mode, const float *row_bias, const uint32_t *perm) {
   if (nq <= 0) return RQ_OK;
   if (n < 1 || n >= (1LL << 31)) return fail(RQ_EINVAL, "n=%lld must be in [1, 2^31)", (long long)n);
   if (lut_mode < LUT_PQ || lut_mode > LUT_CQ) return fail(RQ_EINVAL, "lut_mode=%d", lut_mode);
@@ -365,13 +392,22 @@ int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *code
   DeviceLock launch_lock;   // workspace lookup + counter reset + launches of this device: one thread at a time
   const int mp = scan_padded_m(m);
   if (mp < 0) return fail(RQ_EUNSUPPORTED, "the ADC scan kernels cover 1 <= m <= 64 sub-quantizers; got m=%d", m);
-  if (mp != m) {
+  if (mp != m && !perm) {
     // row width not one of the tiled ones: zero-pad the rows (padding tables are all zero, so the
     // sequential sum is unchanged bit for bit)
     void *padded = nullptr;
     RQ_TRY(workspace(WS_PAD, (size_t)n * mp, &padded, stream));
     RQ_TRY(pad_codes_launch((uint8_t *)padded, codes, n, m, mp, stream));
     codes = (const uint8_t *)padded;
+  }
+  // Bank-aware row order (rq_order.hip).  `perm` given: `codes` is an ordered base already, rows padded to mp bytes
+  // (order_base: index handles, rq_dev_order_rows, the host-pointer calls).  Otherwise the call orders a copy itself when
+  // that pays: the four small kernels cost ~40 us at 1e6 rows, a scan of nq queries gains ~15 % of its time -- from
+  // ORDER_MIN_NQ (2048) queries on.  LSQ scans index row_bias / norm bytes by position and keep the arrival order.
+  if (!perm && !row_bias && order_pays(n, nq)) {
+    void *ord = nullptr;
+    RQ_TRY(workspace(WS_ORDER, order_base_bytes(n, mp), &ord, stream));
+    RQ_TRY(order_base(&codes, &perm, ord, codes, n, mp, stream));
   }
   ScanPlan pl;
   RQ_TRY(scan_plan(pl, n, nq, m, d, k, di.num_cu, tuning("SCAN_SLICES", 0)));
@@ -390,7 +426,7 @@ int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *code
     RQ_TRY(workspace(WS_NORMB, (((size_t)n + 63) & ~(size_t)63) + 32 + 16 * 256 * 4 + (size_t)n * 4, &normb, stream));
   RQ_TRY(scan_launch(pl, both ? nullptr : dists, both ? nullptr : ids, keys, (uint64_t *)part, codes, centers, queries,
                      n, nq, m, d, k, id_offset, id_base, (uint32_t *)counter, (uint64_t *)cand, stream, lut_mode,
-                     row_bias, (uint8_t *)normb));
+                     row_bias, (uint8_t *)normb, perm));
   if (sliced) {
     const size_t off = (size_t)q_tail * k;
     RQ_TRY(merge_launch(both || !dists ? nullptr : dists + off, both || !ids ? nullptr : ids + off,
@@ -522,9 +558,17 @@ static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const
   uint32_t *dip = direct ? ids : di_.as<uint32_t>();
   const uint8_t *cdev = dcodes.as<uint8_t>();
   const float *cen = dcent.as<float>();
+  // the query chunks below scan the same base: order it once for the whole call (rows of a tiled width only -- other
+  // widths are padded per chunk scan and ordered there)
+  const uint32_t *perm = nullptr;
+  DevBuf dord;
+  if (scan_padded_m(m) == m && order_pays(n, nq)) {
+    RQ_TRY(dord.alloc(order_base_bytes(n, m)));
+    RQ_TRY(order_base(&cdev, &perm, dord.p, cdev, n, m, nullptr));
+  }
   RQ_TRY(scan_and_fetch(dists, ids, direct ? nullptr : ddp, dip, nq, k, [&](int64_t q0, int64_t nqc, hipStream_t stream) {
     return dev_linscan(ddp + (size_t)q0 * k, dip + (size_t)q0 * k, nullptr, cdev, cen, qdev + (size_t)q0 * d, n, nqc, m,
-                       d, k, 0, id_base, stream);
+                       d, k, 0, id_base, stream, LUT_PQ, nullptr, perm);
   }));
   g_t_total = tt.ms();
   return RQ_OK;
@@ -1031,6 +1075,51 @@ int rq_dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *c
                    int id_base, void *stream) {
   return dev_linscan(dists, ids, keys, codes, centers, queries, n, nq, m, d, k, id_offset, id_base,
                      (hipStream_t)stream);
+}
+
+int rq_scan_row_width(int m) { return scan_padded_m(m); }
+
+int64_t rq_order_bytes(int64_t n, int m) {
+  const int mp = scan_padded_m(m);
+  return (mp < 0 || n < 1) ? 0 : (int64_t)order_base_bytes(n, mp);
+}
+
+int rq_dev_order_rows(void *ordered, const uint8_t **codes_out, const uint32_t **perm_out, const uint8_t *codes, int64_t n,
+                      int m, void *stream) {
+  if (!ordered || !codes_out || !perm_out || !codes) return fail(RQ_EINVAL, "order_rows: NULL argument");
+  if (n < 1 || n >= (1LL << 31)) return fail(RQ_EINVAL, "n=%lld must be in [1, 2^31)", (long long)n);
+  const int mp = scan_padded_m(m);
+  if (mp < 0) return fail(RQ_EUNSUPPORTED, "the ADC scan kernels cover 1 <= m <= 64 sub-quantizers; got m=%d", m);
+  if ((((uintptr_t)codes | (uintptr_t)ordered) & 15) != 0) return fail(RQ_EINVAL, "codes / ordered must be 16-byte aligned");
+  DeviceLock launch_lock;
+  hipStream_t st = (hipStream_t)stream;
+  const uint8_t *src = codes;
+  if (mp != m) {          // pad first (the ordered copy has the tiled row width)
+    void *padded = nullptr;
+    RQ_TRY(workspace(WS_PAD, (size_t)n * mp, &padded, st));
+    RQ_TRY(pad_codes_launch((uint8_t *)padded, codes, n, m, mp, st));
+    src = (const uint8_t *)padded;
+  }
+  *codes_out = nullptr; *perm_out = nullptr;
+  RQ_TRY(order_base(codes_out, perm_out, ordered, src, n, mp, st));
+  if (!*perm_out) {       // tiny base: nothing to order -- identity copy so that the pair is always usable
+    RQ_HIP(hipMemcpyAsync(ordered, src, (size_t)n * mp, hipMemcpyDeviceToDevice, st));
+    *codes_out = (const uint8_t *)ordered;
+  }
+  return RQ_OK;
+}
+
+int rq_dev_linscan_ordered(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes_ordered, const uint32_t *perm,
+                           const float *centers, const float *queries, int64_t n, int64_t nq, int m, int d, int k,
+                           uint32_t id_offset, int id_base, void *stream) {
+  if (!perm) {
+    // identity order (rq_dev_order_rows on a tiny base): rows are padded already, scan them as they are
+    const int mp = scan_padded_m(m);
+    if (mp != m) return fail(RQ_EUNSUPPORTED, "ordered scan without perm needs a tiled row width (m=%d)", m);
+    return dev_linscan(dists, ids, keys, codes_ordered, centers, queries, n, nq, m, d, k, id_offset, id_base, (hipStream_t)stream);
+  }
+  return dev_linscan(dists, ids, keys, codes_ordered, centers, queries, n, nq, m, d, k, id_offset, id_base,
+                     (hipStream_t)stream, LUT_PQ, nullptr, perm);
 }
 
 int rq_dev_merge_topk(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t *keys_in, int64_t nq, int P,

@@ -126,7 +126,8 @@ struct IxDev {          // one per DISTINCT device of the index
 struct IxShard {
   int dev = 0;          // index into devs
   int64_t row0 = 0, n = 0;
-  uint8_t *codes = nullptr;
+  uint8_t *codes = nullptr;   // the shard's rows -- in bank-aware order when perm != nullptr (rq_order.hip)
+  const uint32_t *perm = nullptr;   // position -> row of the shard (inside the `codes` allocation)
   uint64_t *keys = nullptr;   // [nq][k] sorted keys of the last search (shards off the root device)
   size_t keys_cap = 0;
   uint64_t *tmp = nullptr;    // [nq][k_local] when the shard holds fewer than k rows
@@ -309,9 +310,31 @@ static int index_set(rq_index *ix, int64_t n, uint32_t id_offset, Fill fill) {
     IxDev &dv = ix->devs[s.dev];
     RQ_HIP(hipSetDevice(dv.device));
     if (s.codes) { RQ_HIP(hipStreamSynchronize(dv.stream)); RQ_HIP(hipFree(s.codes)); s.codes = nullptr; }
+    s.perm = nullptr;
     if (s.n == 0) continue;
     RQ_HIP(hipMalloc((void **)&s.codes, (size_t)s.n * ix->m));
     RQ_TRY(fill(s, dv.stream));
+    // The base is resident for many searches: put its rows in bank-aware order ONCE (rq_order.hip; the scan's table gathers
+    // then hit distinct LDS columns, keys still carry the original row numbers through perm).  Rows of a tiled width only;
+    // other widths are padded and ordered per search.  Costs 4 bytes per row for perm; the arrival-order copy is freed.
+    if (tuning("INDEX_ORDER", 1) && scan_padded_m(ix->m) == ix->m && order_pays(s.n, 1 << 30)) {
+      DeviceLock order_lock;      // scratch lookup + launches of this device, like a scan
+      void *ord = nullptr;
+      RQ_HIP(hipMalloc(&ord, order_base_bytes(s.n, ix->m)));
+      const uint8_t *oc = nullptr;
+      const uint32_t *op = nullptr;
+      int rc = order_base(&oc, &op, ord, s.codes, s.n, ix->m, dv.stream);
+      if (rc == RQ_OK) { hipError_t e = hipStreamSynchronize(dv.stream); if (e != hipSuccess) rc = fail_hip(e, "order sync", __FILE__, __LINE__); }
+      if (rc != RQ_OK || !op) {
+        (void)hipFree(ord);
+        if (rc != RQ_OK) return rc;
+      } else {
+        RQ_HIP(hipFree(s.codes));
+        s.codes = (uint8_t *)ord;
+        s.perm = op;
+      }
+      (void)release_stream_workspace(dv.stream);    // the key scratch (4 bytes per row + the histogram) is not needed again
+    }
   }
   for (auto &dv : ix->devs) {
     RQ_HIP(hipSetDevice(dv.device));
@@ -368,7 +391,7 @@ int index_search(rq_index *ix, float *dists, uint32_t *ids, const float *queries
   if (P == 1) {
     IxShard &s = ix->shards[0];
     RQ_TRY(dev_linscan(ix->dd, ix->di, nullptr, s.codes, root.centers, R_host ? root.queries_rot : root.queries, s.n, nq, m,
-                       d, k, ix->id_offset, id_base, root.stream));
+                       d, k, ix->id_offset, id_base, root.stream, LUT_PQ, nullptr, s.perm));
   } else {
     RQ_TRY(grow((void **)&ix->gathered, &ix->gathered_cap, (size_t)P * cnt * 8));
     RQ_TRY(grow((void **)&ix->inter, &ix->inter_cap, (size_t)P * cnt * 8));
@@ -410,7 +433,7 @@ int index_search(rq_index *ix, float *dists, uint32_t *ids, const float *queries
         uint64_t *dst = k_local < k ? s.tmp + (size_t)q0 * k_local : out;
         const float *qs = (R_host ? dv.queries_rot : dv.queries) + (size_t)q0 * d;
         RQ_TRY(dev_linscan(nullptr, nullptr, dst, s.codes, dv.centers, qs, s.n, nqc, m, d, k_local,
-                           (uint32_t)(ix->id_offset + (uint64_t)s.row0), 0, dv.stream));
+                           (uint32_t)(ix->id_offset + (uint64_t)s.row0), 0, dv.stream, LUT_PQ, nullptr, s.perm));
         if (k_local < k)
           RQ_HIP(hipMemcpy2DAsync(out, (size_t)k * 8, dst, (size_t)k_local * 8, (size_t)k_local * 8, (size_t)nqc,
                                   hipMemcpyDeviceToDevice, dv.stream));

@@ -45,7 +45,7 @@ void host_pool_free(void *p);
 void host_pool_trim();
 void sharded_cache_release();
 int aux_streams(hipStream_t *compute, hipStream_t *transfer);
-enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_PAD = 4, WS_MERGE = 5, WS_NORMB = 6, WS_SLOTS = 7 };
+enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_PAD = 4, WS_MERGE = 5, WS_NORMB = 6, WS_ORDER = 7, WS_ORDER_TMP = 8, WS_SLOTS = 9 };
 
 // Per-device launch lock (recursive): held while a call looks up scratch, resets the work counter and
 // launches, so two host threads cannot interleave those sequences on one device.
@@ -84,12 +84,24 @@ int scan_plan(ScanPlan &pl, int64_t n, int64_t nq, int m, int d, int K, int num_
 int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, uint64_t *part, const uint8_t *codes,
                 const float *centers, const float *queries, int64_t n, int64_t nq, int m, int d, int K,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
-                hipStream_t stream, int lut_mode = 0, const float *row_bias = nullptr, uint8_t *norm_buf = nullptr);
+                hipStream_t stream, int lut_mode = 0, const float *row_bias = nullptr, uint8_t *norm_buf = nullptr,
+                const uint32_t *perm = nullptr);
 enum { LUT_PQ = 0, LUT_LSQ = 1, LUT_CQ = 2 };
 // argument checks + planner + launches of one resident shard (rq_dev_linscan's body)
 int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes, const float *centers,
                 const float *queries, int64_t n, int64_t nq, int m, int d, int k, uint32_t id_offset,
-                int id_base, hipStream_t stream, int lut_mode = LUT_PQ, const float *row_bias = nullptr);
+                int id_base, hipStream_t stream, int lut_mode = LUT_PQ, const float *row_bias = nullptr,
+                const uint32_t *perm = nullptr);
+bool order_pays(int64_t n, int64_t nq);                                 // SCAN_ORDER / ORDER_MIN_ROWS / ORDER_MIN_NQ
+size_t order_base_bytes(int64_t n, int mp);
+int order_base(const uint8_t **out_codes, const uint32_t **out_perm, void *dst, const uint8_t *codes, int64_t n, int mp,
+               hipStream_t stream);
+// ---- bank-aware row order (rq_order.hip) ---------------------------------------------------------
+int order_key_bits(int64_t n, int mp, int nb[8]);                       // key layout; returns the total bits (0: no ordering)
+size_t order_scratch_bytes(int64_t n, int total_bits);
+void scan_order_tiling(int mp, int *rpt, int *gran);                   // the scan kernel's rows per lane and rows per sub-step
+int order_rows_launch(uint8_t *dst, uint32_t *perm, const uint8_t *src, int64_t n, int mp, void *scratch, int rpt,
+                      int gran, hipStream_t stream);
 // [P][nq][k] -> [nq][P][k] (lists gathered shard-major, merged query-major)
 int interleave_keys_launch(uint64_t *dst, const uint64_t *src, int64_t nq, int P, int k, size_t pstride, hipStream_t stream);
 int scan_padded_m(int m);   // smallest tiled row width >= m (2,4,8,16,32,64) or -1

@@ -1,0 +1,205 @@
+// rq_order.hip -- bank-aware row order of a resident code matrix for the ADC scan (round 4).
+//
+// The scan's hot loop gathers one 8-byte table entry per code byte from a 256-entry LDS table: a ds_read_b64 of a
+// 32-lane group costs as many passes as the fullest of the 32 eight-byte slot columns holds DISTINCT addresses
+// (entry r sits in column r mod 32; equal addresses broadcast).  With the base rows in arrival order the 32 bytes of a
+// group are random: 3.15 passes per gather, 63 % of the LDS cycles are conflict replays (profiles/r3_pmc_counters.md).
+// But WHICH rows share a lane group is free -- the scan is a set operation and every key carries its row id.  If the 32
+// rows of a group have byte k inside one aligned window of 32 consecutive values (the same top 3 bits), their gathers of
+// table k hit 32 distinct columns or the same address: ONE pass.  A base of n rows has n/32 groups, i.e. log2(n/32) bits
+// of freedom: a counting sort of the rows by the top 3 bits of their leading code bytes -- 15 bits = 5 of the 8 bytes at
+// n = 1e6, 21 bits = 7 bytes on the 1.25e8-row shard of the SIFT1B configuration, all 8 bytes from 2^29 rows on -- makes
+// those tables conflict-free (LDS-pass model, tools/rowperm_sim.py: 25.2 -> 15.5 passes per row at n = 1e6).
+//
+// Output: the permuted code matrix and perm[position] = original row.  Only rows that SURVIVE the threshold read perm
+// (0.3-5 % of the rows), so keys carry original ids and the (dist, id) order of deps/src/linscan_aqd.cpp:91-97 is untouched:
+// the answer is bit-identical for ANY permutation (tests/test_gpu_order.py).
+//
+// Two details the kernel's row tiling dictates (rq_scan.hip):
+//  * lane j of half-wave h handles rows  tile*T + h*32*RPT + j*RPT + r  (T = 64*RPT, r < RPT), so the 32 consecutive rows
+//    of the sort order that should meet in one gather are DEALT to those positions;
+//  * the second threshold estimate (retune_tau) treats the first eighth of a slice as a random sample of it, and the
+//    XCD windows / row slices treat any row range alike.  A sorted base breaks that (measured: 487 of 1250 items fell
+//    back to the exact redo, 2.4 -> 9.5 ms).  So whole granules of `gran` rows (one coalesced sub-step of a workgroup) are
+//    spread by a Weyl permutation g -> g*A mod G: any range of positions is a stratified sample of the sort order.
+#include "rq_internal.h"
+
+#include <cmath>
+
+namespace rq {
+
+struct OrderParams {
+  const uint8_t *src;     // [n][mp]
+  uint8_t *dst;           // [n][mp]
+  uint32_t *perm;         // [n]   position -> original row
+  uint32_t *rank;         // [n]   scratch: rank of the row inside its bucket
+  uint32_t *hist;         // [nbins (+ tile totals behind, see order_bytes)]
+  uint32_t n;
+  int mp;                 // row width (2, 4, 8, 16, 32, 64)
+  int ncoord;             // code bytes that take part in the key (<= 8)
+  int nb[8];              // bits of byte c in the key (top bits of the byte)
+  uint32_t nbins;
+  uint32_t tile;          // T = 64 * RPT rows: one wavefront's rows of a sub-step
+  uint32_t rpt;
+  uint32_t gran;          // shuffle granule (rows, multiple of tile)
+  uint32_t ngran;         // full granules: n / gran
+  uint32_t weyl;          // A: odd, coprime with ngran
+};
+
+constexpr int ORDER_SCAN_TILE = 16384;    // bins per scan workgroup (1024 threads x 16)
+
+__device__ __forceinline__ uint32_t order_key_of(const OrderParams &p, uint32_t row) {
+  // the first min(mp, 8) bytes of the row (rows are mp-byte aligned)
+  uint64_t w;
+  const uint8_t *r = p.src + (size_t)row * p.mp;
+  if (p.mp >= 8) w = *reinterpret_cast<const uint64_t *>(r);
+  else if (p.mp == 4) w = *reinterpret_cast<const uint32_t *>(r);
+  else w = *reinterpret_cast<const uint16_t *>(r);
+  uint32_t key = 0;
+  for (int c = 0; c < p.ncoord; ++c) {
+    const uint32_t b = (uint32_t)(w >> (8 * c)) & 0xffu;
+    key = (key << p.nb[c]) | (b >> (8 - p.nb[c]));
+  }
+  return key;
+}
+
+// pass 1: bucket sizes, and every row's arrival rank inside its bucket (any order will do: the result of the scan does not
+// depend on the permutation)
+__global__ __launch_bounds__(256) void order_rank_kernel(OrderParams p) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += gridDim.x * blockDim.x)
+    p.rank[i] = atomicAdd(&p.hist[order_key_of(p, i)], 1u);
+}
+
+// pass 2a: exclusive scan inside tiles of ORDER_SCAN_TILE bins, tile totals to hist[nbins + tile]
+__global__ __launch_bounds__(1024) void order_scan_tiles_kernel(uint32_t *hist, uint32_t nbins) {
+  __shared__ uint32_t wsum[16];
+  const uint32_t t0 = blockIdx.x * ORDER_SCAN_TILE + threadIdx.x * 16;
+  uint32_t v[16], s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { v[i] = t0 + i < nbins ? hist[t0 + i] : 0u; s += v[i]; }
+  // inclusive scan of s over the 1024 threads: wave scan + scan of the 16 wave sums
+  uint32_t x = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off);
+    if ((threadIdx.x & 63) >= (uint32_t)off) x += y;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wbase += wsum[w];
+  uint32_t run = wbase + x - s;    // exclusive prefix of this thread's 16 bins inside the tile
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { if (t0 + i < nbins) hist[t0 + i] = run; run += v[i]; }
+  if (threadIdx.x == 1023) hist[nbins + blockIdx.x] = run;
+}
+
+// pass 2b: exclusive scan of the (<= 1024) tile totals, one workgroup
+__global__ __launch_bounds__(1024) void order_scan_top_kernel(uint32_t *tot, uint32_t ntiles) {
+  __shared__ uint32_t wsum[16];
+  const uint32_t s = threadIdx.x < ntiles ? tot[threadIdx.x] : 0u;
+  uint32_t x = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off);
+    if ((threadIdx.x & 63) >= (uint32_t)off) x += y;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wbase += wsum[w];
+  if (threadIdx.x < ntiles) tot[threadIdx.x] = wbase + x - s;
+}
+
+// sorted rank -> position (see the header comment)
+__device__ __forceinline__ uint32_t order_deal(const OrderParams &p, uint32_t s) {
+  uint32_t g = s / p.gran;
+  if (g < p.ngran) {
+    const uint32_t g2 = (uint32_t)(((uint64_t)g * p.weyl) % p.ngran);
+    s = g2 * p.gran + (s - g * p.gran);
+  }
+  const uint32_t t = s / p.tile;
+  if ((uint64_t)(t + 1) * p.tile > p.n) return s;     // the ragged last tile stays in sort order
+  const uint32_t u = s - t * p.tile, half = 32u * p.rpt;
+  const uint32_t h = u / half, v = u - h * half;
+  const uint32_t r = v >> 5, j = v & 31u;
+  return t * p.tile + h * half + j * p.rpt + r;
+}
+
+// pass 3: every row to its position, perm[position] = row
+__global__ __launch_bounds__(256) void order_scatter_kernel(OrderParams p) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += gridDim.x * blockDim.x) {
+    const uint32_t key = order_key_of(p, i);
+    const uint32_t s = p.hist[key] + p.hist[p.nbins + key / ORDER_SCAN_TILE] + p.rank[i];
+    const uint32_t pos = order_deal(p, s);
+    const uint8_t *a = p.src + (size_t)i * p.mp;
+    uint8_t *b = p.dst + (size_t)pos * p.mp;
+    if (p.mp == 8) *reinterpret_cast<uint64_t *>(b) = *reinterpret_cast<const uint64_t *>(a);
+    else if (p.mp >= 16) {
+      for (int o = 0; o < p.mp; o += 16) *reinterpret_cast<uint4 *>(b + o) = *reinterpret_cast<const uint4 *>(a + o);
+    } else if (p.mp == 4) *reinterpret_cast<uint32_t *>(b) = *reinterpret_cast<const uint32_t *>(a);
+    else *reinterpret_cast<uint16_t *>(b) = *reinterpret_cast<const uint16_t *>(a);
+    p.perm[pos] = i;
+  }
+}
+
+static uint32_t gcd_u32(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
+
+// Key layout for n rows of mp bytes: 3 bits per leading code byte while log2(n / 32) bits last (a 32-value window per
+// byte); what is left over goes to the next byte (1-2 bits: a 64/128-value window still halves its passes).  0 bits: no
+// ordering (tiny bases).
+int order_key_bits(int64_t n, int mp, int nb[8]) {
+  for (int c = 0; c < 8; ++c) nb[c] = 0;
+  if (n < 1024) return 0;
+  int budget = tuning("ORDER_BITS", 0);
+  if (budget <= 0) budget = n >= 64 ? (int)std::floor(std::log2((double)n / 32.0) + 0.5) : 0;   // one bit per doubling of the group count
+  budget = std::min(budget, 24);
+  const int nc = std::min(mp, 8);
+  int total = 0;
+  for (int c = 0; c < nc && total < budget; ++c) { nb[c] = std::min(3, budget - total); total += nb[c]; }
+  // narrow rows (m <= 4): more bits per byte once every byte has its window
+  for (int c = 0; c < nc && total < budget; ++c) { const int add = std::min(5, budget - total); nb[c] += add; total += add; }
+  return total;
+}
+
+size_t order_scratch_bytes(int64_t n, int total_bits) {
+  const size_t nbins = (size_t)1 << total_bits;
+  const size_t ntiles = (nbins + ORDER_SCAN_TILE - 1) / ORDER_SCAN_TILE;
+  return (size_t)n * 4 + (nbins + ntiles + 16) * 4;
+}
+
+// codes [n][mp] -> dst [n][mp] + perm [n]; scratch of order_scratch_bytes().  rpt / gran: the scan tiling (scan_order_tiling).
+int order_rows_launch(uint8_t *dst, uint32_t *perm, const uint8_t *src, int64_t n, int mp, void *scratch, int rpt,
+                      int gran, hipStream_t stream) {
+  OrderParams p;
+  const int total = order_key_bits(n, mp, p.nb);
+  if (total <= 0 || total > 24) return fail(RQ_EINVAL, "order_rows: nothing to order (n=%lld)", (long long)n);
+  p.src = src; p.dst = dst; p.perm = perm;
+  p.n = (uint32_t)n; p.mp = mp;
+  p.ncoord = 0;
+  for (int c = 0; c < 8; ++c) if (p.nb[c]) p.ncoord = c + 1;
+  p.nbins = 1u << total;
+  p.rank = reinterpret_cast<uint32_t *>(scratch);
+  p.hist = p.rank + n;
+  p.rpt = (uint32_t)rpt;
+  p.tile = 64u * (uint32_t)rpt;
+  p.gran = (uint32_t)std::max(gran, (int)p.tile) / p.tile * p.tile;
+  p.ngran = (uint32_t)(n / p.gran);
+  p.weyl = 1;
+  if (p.ngran > 2 && tuning("ORDER_SHUFFLE", 1)) {
+    uint32_t a = (uint32_t)((double)p.ngran * 0.6180339887498949) | 1u;
+    while (gcd_u32(a, p.ngran) != 1u) a += 2u;
+    p.weyl = a % p.ngran;
+  }
+  const uint32_t ntiles = (p.nbins + ORDER_SCAN_TILE - 1) / ORDER_SCAN_TILE;
+  RQ_HIP(hipMemsetAsync(p.hist, 0, (size_t)(p.nbins + ntiles) * 4, stream));
+  const uint32_t grid = (uint32_t)std::min<int64_t>((n + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(order_rank_kernel, dim3(grid), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(order_scan_tiles_kernel, dim3(ntiles), dim3(1024), 0, stream, p.hist, p.nbins);
+  hipLaunchKernelGGL(order_scan_top_kernel, dim3(1), dim3(1024), 0, stream, p.hist + p.nbins, ntiles);
+  hipLaunchKernelGGL(order_scatter_kernel, dim3(grid), dim3(256), 0, stream, p);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+}  // namespace rq

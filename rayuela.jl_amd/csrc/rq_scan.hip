@@ -510,7 +510,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
           for (int q = 0; q < QG; ++q) acc[q] = acc[q] + bias;
         }
         // ---- survivors: rows whose distance beats the query's threshold ------------------------
-        emit_survivors<QG>(acc, tau, row0 + r < r_end, row0 + r + p.id_offset, selmask, ctrl, cand_wg, p.cap, lane);
+        emit_survivors<QG>(acc, tau, row0 + r < r_end, row0 + r, p.perm, p.id_offset, selmask, ctrl, cand_wg, p.cap, lane);
         // one row at a time when a row's gathers alone fill half of the register budget (m = 16, 8 queries: 32 x 16 bytes):
         // interleaving two rows spilled 160 registers in the norm-adding (LSQ) variant
         if constexpr (M * Cfg::NQUAD >= 32) __builtin_amdgcn_sched_barrier(0);
@@ -966,8 +966,9 @@ __global__ void norm_quant_kernel(const float *__restrict__ nrm, uint32_t n, con
 int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, uint64_t *part, const uint8_t *codes,
                 const float *centers, const float *queries, int64_t n, int64_t nq, int m, int d, int K,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
-                hipStream_t stream, int lut_mode, const float *row_bias, uint8_t *norm_buf) {
+                hipStream_t stream, int lut_mode, const float *row_bias, uint8_t *norm_buf, const uint32_t *perm) {
   ScanParams p;
+  p.perm = perm;
   p.codes = codes; p.centers = centers; p.queries = queries;
   p.n = (uint32_t)n; p.nq = (uint32_t)nq; p.sub = d / m; p.d = d; p.K = K;
   p.m_real = m;
@@ -1078,6 +1079,22 @@ int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t
   hipLaunchKernelGGL(merge_topk_kernel, dim3((uint32_t)nq), dim3(MERGE_THREADS), lds, stream, p);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
+}
+
+// the row tiling rq_order.hip has to match: rows per lane and sub-step, rows per workgroup sub-step (the shuffle granule)
+void scan_order_tiling(int mp, int *rpt, int *gran) {
+  int r = 1, g = SCAN_THREADS;
+  switch (mp) {
+    case 2: r = ScanCfg<2>::RPT; g = ScanCfg<2>::SUB; break;
+    case 4: r = ScanCfg<4>::RPT; g = ScanCfg<4>::SUB; break;
+    case 8: r = ScanCfg<8>::RPT; g = ScanCfg<8>::SUB; break;
+    case 16: r = ScanCfg<16>::RPT; g = ScanCfg<16>::SUB; break;
+    case 32: r = ScanCfg<32>::RPT; g = ScanCfg<32>::SUB; break;
+    case 64: r = ScanCfg<64>::RPT; g = ScanCfg<64>::SUB; break;
+  }
+  const int tg = tuning("ORDER_GRAN", 0);
+  *rpt = r;
+  *gran = tg > 0 ? tg : g;
 }
 
 int pad_codes_launch(uint8_t *dst, const uint8_t *src, int64_t n, int m, int mp, hipStream_t stream) {

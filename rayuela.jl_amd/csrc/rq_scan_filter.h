@@ -322,7 +322,7 @@ template <int M, bool BIAS, bool FINE>
 __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, const uint8_t *codes,
                                           const float *row_bias, uint32_t id_offset, uint32_t cap, const float4 *lut4,
                                           const float4 *gtab, const uint32_t *qtab, const uint32_t *queue, uint32_t count,
-                                          const uint8_t *norm_bytes) {
+                                          const uint8_t *norm_bytes, const uint32_t *__restrict__ perm) {
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD, KL = Cfg::KL;
   static_assert(Cfg::QPG == 4, "pair refinement: float4 table entries");
@@ -330,6 +330,7 @@ __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64
   const int lane = threadIdx.x & 63;
   const bool valid = (uint32_t)lane < count;
   const uint32_t row = queue[valid ? lane : 0];
+  const uint32_t kid = (perm ? perm[row] : row) + id_offset;      // ordered bases: the row's original number
   uint32_t w1[(M + 3) / 4];
   load_row<M>(w1, codes, row);
   // byte sums of the row, exactly as the hot loop forms them
@@ -376,7 +377,7 @@ __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64
       if (acc <= ctrl->tau[q]) {
         const uint32_t pos = atomicAdd(&ctrl->cnt[q], 1u);
         uint64_t *buf = cand_wg + ((size_t)q * 2 + ((selmask >> q) & 1u)) * cap;
-        buf[pos] = make_key(acc, row + id_offset);
+        buf[pos] = make_key(acc, kid);
       }
     }
   }
@@ -387,11 +388,11 @@ template <int M, bool BIAS, bool FILT, bool FINE>
 __device__ __forceinline__ void refine_queue(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64_t *cand_wg, const uint8_t *codes,
                                              const float *row_bias, uint32_t id_offset, uint32_t cap, const float4 *lut4,
                                              const float4 *gtab, const uint32_t *qtab, const uint32_t *queue, uint32_t count,
-                                             const uint8_t *norm_bytes) {
+                                             const uint8_t *norm_bytes, const uint32_t *perm) {
   if constexpr (FILT && ScanCfg<M>::HAS_FILT)
-    refine_pairs<M, BIAS, FINE>(ctrl, cand_wg, codes, row_bias, id_offset, cap, lut4, gtab, qtab, queue, count, norm_bytes);
+    refine_pairs<M, BIAS, FINE>(ctrl, cand_wg, codes, row_bias, id_offset, cap, lut4, gtab, qtab, queue, count, norm_bytes, perm);
 }
-#define RQ_REFINE(c, cw, cd, rb, io, cp, l4, gt, qu, n) refine_queue<M, BIAS, FILT, FINE>(c, cw, cd, rb, io, cp, l4, gt, qtab, qu, n, p.norm_bytes)
+#define RQ_REFINE(c, cw, cd, rb, io, cp, l4, gt, qu, n) refine_queue<M, BIAS, FILT, FINE>(c, cw, cd, rb, io, cp, l4, gt, qtab, qu, n, p.norm_bytes, p.perm)
 
 
 }  // namespace rq

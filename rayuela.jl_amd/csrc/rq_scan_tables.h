@@ -102,6 +102,7 @@ struct ScanParams {
   const uint8_t *norm_bytes;  // LSQ pre-filter: row norms quantised to 256 lower edges, [n]
   const float *norm_info;     // ... {nmin, nstep, max |.|} of the quantised quantity: norm[row] - sum_k |c_k[b_k]|^2
   const float *cnorm;         // ... |c_k[r]|^2, [M][256]: folded into the filter's tables (see build_qtab)
+  const uint32_t *perm;     // bank-aware row order (rq_order.hip): perm[position] = original row, read for survivors only; or nullptr
   uint32_t id_offset;
   int id_base;
   uint32_t nslices, rows_per_slice, ngroups;
@@ -272,7 +273,8 @@ __device__ __forceinline__ void load_row(uint32_t *w, const uint8_t *codes, uint
 // queries: lane q reserves popc(mk[q]) slots of query q.
 // ------------------------------------------------------------------------------------------
 template <int QG>
-__device__ __forceinline__ void emit_survivors(const float (&acc)[QG], const float (&tau)[QG], bool valid, uint32_t kid,
+__device__ __forceinline__ void emit_survivors(const float (&acc)[QG], const float (&tau)[QG], bool valid, uint32_t row,
+                                               const uint32_t *__restrict__ perm, uint32_t id_offset,
                                                uint32_t selmask, ScanCtrl<QG> *ctrl, uint64_t *cand_wg, uint32_t cap,
                                                int lane) {
   uint64_t mk[QG];
@@ -283,6 +285,10 @@ __device__ __forceinline__ void emit_survivors(const float (&acc)[QG], const flo
     any |= mk[q];
   }
   if (any) {
+    // the key's id: the row's ORIGINAL number (ordered bases: one load per surviving row, never in the common path)
+    uint32_t kid = row;
+    if (perm && ((any >> lane) & 1ull)) kid = perm[row];
+    kid += id_offset;
     uint32_t want = 0;
 #pragma unroll
     for (int q = 0; q < QG; ++q)

@@ -64,12 +64,65 @@ def adc_lut(centers, queries):
     return lut
 
 
+class OrderedBase:
+    """A resident code matrix in bank-aware row order (rq_dev_order_rows): `codes` [n][row_width] uint8 and `perm` [n]
+    int32 (position -> original row; None for a base too small to order) are views into ONE device buffer."""
+
+    def __init__(self, buf, codes, perm, n, m):
+        self.buf, self.codes, self.perm, self.n, self.m = buf, codes, perm, n, m
+
+    @property
+    def shape(self):
+        return (self.n, self.m)
+
+
+def order_rows(codes):
+    """Bank-aware order of a resident base: returns an OrderedBase for linscan(...).  The answer of a scan does not
+    depend on it (ids are original row numbers); only the LDS bank conflicts of the table gathers do."""
+    import ctypes as C
+    n, m = codes.shape
+    L = _lib.lib()
+    nbytes = int(L.rq_order_bytes(n, m))
+    mp = int(L.rq_scan_row_width(m))
+    buf = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=codes.device)     # 16-byte aligned
+    c_out, p_out = C.c_void_p(), C.c_void_p()
+    _lib.check(L.rq_dev_order_rows(buf.data_ptr(), C.byref(c_out), C.byref(p_out), _chk(codes, torch.uint8, "codes"),
+                                   n, m, _stream()))
+    b8 = buf.view(torch.uint8)
+    co = (c_out.value or buf.data_ptr()) - buf.data_ptr()
+    oc = b8[co:co + n * mp].view(n, mp)
+    perm = None
+    if p_out.value:
+        po = p_out.value - buf.data_ptr()
+        perm = b8[po:po + 4 * n].view(torch.int32)
+    return OrderedBase(buf, oc, perm, n, m)
+
+
 def linscan(codes, centers, queries, k, id_offset=0, id_base=0, want_keys=False, out=None):
     """Scan one resident shard.  Returns (dists, ids) or packed sorted keys [nq][k] (int64 view of
-    the uint64 keys) when want_keys."""
-    n, m = codes.shape
+    the uint64 keys) when want_keys.  `codes`: [n][m] uint8, or an OrderedBase (order_rows)."""
     nq, d = queries.shape
     dev = queries.device
+    if isinstance(codes, OrderedBase):
+        ob = codes
+        n, m = ob.n, ob.m
+        if want_keys:
+            dists = ids = None
+            keys = torch.empty((nq, k), dtype=torch.int64, device=dev) if out is None else out
+        elif out is None:
+            keys = None
+            dists = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        else:
+            keys = None
+            dists, ids = out
+        _lib.check(_lib.lib().rq_dev_linscan_ordered(
+            None if dists is None else dists.data_ptr(), None if ids is None else ids.data_ptr(),
+            None if keys is None else keys.data_ptr(), ob.codes.data_ptr(), None if ob.perm is None else ob.perm.data_ptr(),
+            _chk(centers, torch.float32, "centers"), _chk(queries, torch.float32, "queries"), n, nq, m, d, k,
+            id_offset, id_base, _stream()))
+        return keys if want_keys else (dists, ids)
+    n, m = codes.shape
     if want_keys:
         keys = torch.empty((nq, k), dtype=torch.int64, device=dev) if out is None else out
         _lib.check(_lib.lib().rq_dev_linscan(None, None, keys.data_ptr(), _chk(codes, torch.uint8, "codes"),

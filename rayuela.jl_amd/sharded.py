@@ -46,7 +46,7 @@ def shard_bounds(n_total, world):
 
 class ShardedIndex:
     def __init__(self, codes_local, centers, id_offset, group=None, scan_fn=None, merge_fn=None, host_staging=False,
-                 always_exchange=False):
+                 always_exchange=False, order=True):
         # always_exchange: take the all_to_all / gather path even at world size 1 (exercises the RCCL collectives
         # on a one-GPU box; the product never sets it)
         self.always_exchange = always_exchange
@@ -62,6 +62,19 @@ class ShardedIndex:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # total rows of the base: k beyond it has no answer (the reference requires K <= N, linscan_aqd.cpp:91)
         self.n_total = int(codes_local.shape[0])
+        # The shard is resident for many searches: put its rows in bank-aware order once (csrc/rq_order.hip: the scan's
+        # table gathers then hit distinct LDS bank columns; ids stay original row numbers, the answer is unchanged).
+        # HIP path only -- an injected scan_fn (CPU tests) sees the codes as given.
+        self.ordered = None
+        self.order_ms = None
+        if scan_fn is None and codes_local.is_cuda and codes_local.shape[0] >= 65536 and order:
+            from . import device
+            t0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0[0].record()
+            self.ordered = device.order_rows(codes_local)
+            t0[1].record()
+            torch.cuda.synchronize()
+            self.order_ms = t0[0].elapsed_time(t0[1])
         if self.world > 1:
             t = torch.tensor([self.n_total], dtype=torch.int64, device="cpu" if host_staging else codes_local.device)
             dist.all_reduce(t, group=group)
@@ -74,7 +87,8 @@ class ShardedIndex:
         k_local = min(k, n_local)
         if k_local == 0:
             return torch.full((nq, k), KEY_MAX, dtype=torch.int64, device=queries.device)
-        keys = self.scan_fn(self.codes, self.centers, queries, k_local, self.id_offset)
+        keys = self.scan_fn(self.ordered if self.ordered is not None else self.codes, self.centers, queries, k_local,
+                            self.id_offset)
         if k_local < k:
             pad = torch.full((nq, k - k_local), KEY_MAX, dtype=torch.int64, device=keys.device)
             keys = torch.cat([keys, pad], dim=1)

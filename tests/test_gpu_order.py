@@ -1,0 +1,192 @@
+"""Bank-aware row order (csrc/rq_order.hip): the ordered base is a permutation of the arrival-order base, and every scan
+over it returns the SAME ids and distance bits as the reference semantics (deps/src/linscan_aqd.cpp:85-97: sequential f32
+sums, the k smallest (dist, id) pairs) -- ids are original row numbers, ties included."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+class _Tuning:
+    def __init__(self, rq, **kv):
+        self.rq, self.kv = rq, kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.rq.set_tuning(k, v)
+
+    def __exit__(self, *exc):
+        defaults = {"SCAN_ORDER": 1, "ORDER_MIN_ROWS": 65536, "ORDER_MIN_NQ": 2048, "ORDER_BITS": 0, "ORDER_GRAN": 0,
+                    "ORDER_SHUFFLE": 1, "SCAN_SRANK_MUL": 2, "SCAN_SLACK": 0, "SCAN_SLICES": 0, "SCAN_FILTER": 1,
+                    "SCAN_RETUNE_Z": 6, "INDEX_ORDER": 1, "SCAN_XCD_MIN_MB": 0, "SCAN_WINDOW_MB": 0}
+        for k in self.kv:
+            self.rq.set_tuning(k, defaults[k])
+
+
+def _lds_passes(codes, rpt):
+    """LDS-pass model of the byte-table gathers (tools/rowperm_sim.py): mean over lane groups and bytes of the fullest
+    slot column's number of distinct addresses."""
+    n, m = codes.shape
+    tile = 64 * rpt
+    g = codes[: n // tile * tile].reshape(-1, 2, 32, rpt, m).transpose(0, 1, 3, 2, 4).reshape(-1, 32, m)
+    tot = 0.0
+    for k in range(m):
+        pres = np.zeros((g.shape[0], 256), dtype=bool)
+        pres[np.arange(g.shape[0])[:, None], g[:, :, k]] = True
+        tot += pres.reshape(-1, 8, 32).sum(1).max(1).mean()
+    return tot / m
+
+
+@pytest.mark.parametrize("n,m", [(1_000_000, 8), (300_001, 16), (70_000, 4), (200_000, 5), (65_536, 2), (100_003, 32)])
+def test_order_rows_is_a_permutation_with_fewer_bank_conflicts(rq, n, m):
+    import torch
+    from rayuela_jl_amd import device as rqd
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import _lib
+    codes = synth.random_codes(n, m, seed=n + m)
+    ob = rqd.order_rows(torch.from_numpy(codes).cuda())
+    mp = int(_lib.lib().rq_scan_row_width(m))
+    oc, perm = ob.codes.cpu().numpy(), ob.perm.cpu().numpy().view(np.uint32).astype(np.int64)
+    assert oc.shape == (n, mp)
+    assert np.array_equal(np.sort(perm), np.arange(n))                     # a bijection
+    assert np.array_equal(oc[:, :m], codes[perm])                          # ordered row i IS original row perm[i]
+    assert not oc[:, m:].any()                                             # zero padding bytes
+    if m in (8, 16):
+        rpt = 2 if m == 8 else 1
+        before, after = _lds_passes(codes, rpt), _lds_passes(oc[:, :m], rpt)
+        # n = 1e6, m = 8: 3.15 -> 1.94 passes per gather (5 of 8 byte tables conflict-free)
+        assert after < (0.68 if m == 8 else 0.85) * before, (before, after)
+
+
+def _hostile_codes(kind, n, m, rng):
+    if kind == "uniform":
+        return rng.integers(0, 256, (n, m), dtype=np.uint8)
+    if kind == "dups":          # 60 distinct rows: massive exact ties across the permutation
+        pool = rng.integers(0, 256, (60, m), dtype=np.uint8)
+        return pool[rng.integers(0, 60, n)]
+    if kind == "lowbits":       # every byte in [0, 8): one sort bucket, ties everywhere
+        return rng.integers(0, 8, (n, m), dtype=np.uint8)
+    if kind == "skew":          # half of the rows in ONE bucket, the rest uniform
+        c = rng.integers(0, 256, (n, m), dtype=np.uint8)
+        c[: n // 2] = c[0]
+        return c[rng.permutation(n)]
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "dups", "lowbits", "skew"])
+@pytest.mark.parametrize("n,m,sub,nq,K", [(150_000, 8, 4, 24, 1000), (100_003, 8, 4, 9, 1), (90_000, 16, 2, 16, 100),
+                                          (70_001, 8, 4, 8, 3000)])
+def test_ordered_scan_is_bit_exact(rq, oracle, kind, n, m, sub, nq, K):
+    """SCAN_ORDER = 2 forces the in-call ordering at any batch size; ids and distances equal the oracle's."""
+    rng = np.random.default_rng(n + m + K)
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = _hostile_codes(kind, n, m, rng)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    with _Tuning(rq, SCAN_ORDER=2, ORDER_MIN_ROWS=1):
+        d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+    assert np.array_equal(i0, i1), (kind, n, m, K)
+    assert _eq_bits(d0, d1)
+
+
+@pytest.mark.parametrize("knobs", [dict(SCAN_SRANK_MUL=0), dict(SCAN_SLACK=64, SCAN_SRANK_MUL=0), dict(SCAN_FILTER=0),
+                                   dict(SCAN_SLICES=3), dict(SCAN_RETUNE_Z=-8), dict(ORDER_SHUFFLE=0),
+                                   dict(ORDER_BITS=9), dict(ORDER_BITS=20), dict(ORDER_GRAN=128)])
+def test_ordered_scan_on_every_threshold_path(rq, oracle, knobs):
+    """The exact fallback (tau = +inf with capacity cuts: emit_survivors reads perm), the unfiltered loop, row slices +
+    merge, a second estimate that is too tight, an unshuffled (sorted) base -- the estimate then misses and the slice is
+    redone exactly -- and other key widths / granules: the answer never changes."""
+    rng = np.random.default_rng(5)
+    n, m, sub, nq = 300_000, 8, 4, 16
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = _hostile_codes("dups", n // 2, m, rng)
+    codes = np.concatenate([codes, _hostile_codes("uniform", n - n // 2, m, rng)])[rng.permutation(n)]
+    for K in (100, 1000):
+        d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+        with _Tuning(rq, SCAN_ORDER=2, ORDER_MIN_ROWS=1, **knobs):
+            d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+        assert np.array_equal(i0, i1) and _eq_bits(d0, d1), (knobs, K)
+
+
+def test_ordered_base_object_with_shards_and_keys(rq, oracle):
+    """rq_dev_order_rows + rq_dev_linscan_ordered: shards ordered separately, global ids through id_offset, packed keys
+    merged on the device -- the multi-GPU data path over ordered shards."""
+    import torch
+    from rayuela_jl_amd import device as rqd
+    rng = np.random.default_rng(8)
+    n, m, sub, nq, K = 260_000, 8, 4, 24, 500
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = _hostile_codes("dups", n, m, rng)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    cen, qs = torch.from_numpy(centers).cuda(), torch.from_numpy(queries).cuda()
+    bounds = [0, 100_000, 100_300, n]        # one shard shorter than K (too small to order: perm is None)
+    keys = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        ob = rqd.order_rows(torch.from_numpy(codes[a:b]).cuda())
+        assert (ob.perm is None) == (b - a < 1000)
+        kk = min(K, b - a)
+        ks = rqd.linscan(ob, cen, qs, kk, id_offset=a, want_keys=True)
+        if kk < K:
+            ks = torch.cat([ks, torch.full((nq, K - kk), -1, dtype=torch.int64, device="cuda")], dim=1)
+        keys.append(ks)
+    dists, ids = rqd.merge_topk(torch.stack(keys, dim=1).contiguous(), K)
+    assert np.array_equal(ids.cpu().numpy().view(np.uint32), i0) and _eq_bits(dists.cpu().numpy(), d0)
+    # and the (dists, ids) form on one ordered base, one-based ids
+    ob = rqd.order_rows(torch.from_numpy(codes).cuda())
+    d1, i1 = rqd.linscan(ob, cen, qs, K, id_base=1)
+    assert np.array_equal(i1.cpu().numpy().view(np.uint32), i0 + 1) and _eq_bits(d1.cpu().numpy(), d0)
+
+
+@pytest.mark.parametrize("order", [1, 0])
+def test_index_handle_orders_its_shards(rq, oracle, order):
+    """rq_index_set_codes orders every shard once (INDEX_ORDER = 1); searches return original ids."""
+    rng = np.random.default_rng(3)
+    n, m, sub, nq, K = 400_000, 8, 4, 40, 300
+    d = m * sub
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
+    codes = _hostile_codes("skew", n, m, rng)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    with _Tuning(rq, INDEX_ORDER=order):
+        for devices in ([0], [0, 0, 0]):
+            ix = rq.Index([centers[i] for i in range(m)], d, devices=devices)
+            ix.set_codes(codes)
+            dd, ii = ix.search(queries, K, id_base=0)
+            assert np.array_equal(np.asarray(ii).view(np.uint32), i0) and _eq_bits(dd, d0), (order, devices)
+            del ix
+
+
+def test_auto_order_at_bench_batch_size(rq, oracle):
+    """nq >= ORDER_MIN_NQ: rq_dev_linscan / the host-pointer call order the base themselves (default tuning)."""
+    import rayuela_jl_amd.synth as synth
+    rng = np.random.default_rng(17)
+    n, m, sub, nq, K = 200_000, 8, 4, 2048, 100
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=4)
+    d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+    with _Tuning(rq, SCAN_ORDER=0):
+        d2, i2 = rq.linscan_aqd_query(codes, centers, queries, K)
+    assert np.array_equal(i1, i2) and _eq_bits(d1, d2)
+    sel = np.arange(0, nq, 37)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries[sel], K)
+    assert np.array_equal(i1[sel], i0) and _eq_bits(d1[sel], d0)
+
+
+def test_xcd_windows_over_an_ordered_base(rq, oracle):
+    """Big-base plan (row windows per XCD) forced on a small ordered base."""
+    rng = np.random.default_rng(23)
+    n, m, sub, nq, K = 600_000, 8, 4, 64, 100
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = _hostile_codes("dups", n, m, rng)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    with _Tuning(rq, SCAN_ORDER=2, ORDER_MIN_ROWS=1, SCAN_XCD_MIN_MB=1, SCAN_WINDOW_MB=1):
+        d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+    assert np.array_equal(i0, i1) and _eq_bits(d0, d1)
