@@ -34,7 +34,10 @@ namespace rq {
 // fields: floor((A + B) / 2) = (A & B) + (((A ^ B) >> 1) & 0x7f..) <= (THR - 1) / 2 for odd THR.
 // M = 16: two sets of 8 (8 * 31 <= 255), compared against THR16 = 159 through their per-byte average (<= 79).
 constexpr uint32_t FILT_CLAMP = 31;
-constexpr uint32_t filt_thr8(bool fine) { return fine ? 191u : 95u; }
+#ifndef RQ_FILT_THR8
+#define RQ_FILT_THR8 95
+#endif
+constexpr uint32_t filt_thr8(bool fine) { return fine ? 191u : (uint32_t)RQ_FILT_THR8; }
 constexpr uint32_t filt_clamp8(bool fine) { return fine ? 63u : 31u; }
 constexpr uint32_t FILT_THR16 = 159;
 
@@ -257,7 +260,9 @@ __device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC 
     for (int j = 0; j < NQ; ++j) {
       uint32_t v = a[j];
       if constexpr (FINE) v = (a[j] & a[NQ + j]) + (((a[j] ^ a[NQ + j]) >> 1) & 0x7f7f7f7fu);
-      all &= ((v | H) - TC) | v;
+      // THR = 127 (coarse tables): "sum <= THR" IS bit 7 of the byte sum -- no compare arithmetic at all
+      if constexpr (!FINE && filt_thr8(false) == 127u) all &= v;
+      else all &= ((v | H) - TC) | v;
     }
     return (all & H) != H;
   } else if constexpr (ScanCfg<M>::NQUAD == 2) {
@@ -302,7 +307,8 @@ __device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<
     for (int j = 0; j < NQ; ++j) {
       uint32_t v = a[j];
       if constexpr (FINE) v = (a[j] & a[NQ + j]) + (((a[j] ^ a[NQ + j]) >> 1) & 0x7f7f7f7fu);
-      bits |= high_bits4(~(((v | H) - TC) | v)) << (4 * j);
+      if constexpr (!FINE && filt_thr8(false) == 127u) bits |= high_bits4(~v) << (4 * j);
+      else bits |= high_bits4(~(((v | H) - TC) | v)) << (4 * j);
     }
     return bits;
   } else if constexpr (Cfg::NQUAD == 2) {
@@ -330,7 +336,6 @@ __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64
   const int lane = threadIdx.x & 63;
   const bool valid = (uint32_t)lane < count;
   const uint32_t row = queue[valid ? lane : 0];
-  const uint32_t kid = (perm ? perm[row] : row) + id_offset;      // ordered bases: the row's original number
   uint32_t w1[(M + 3) / 4];
   load_row<M>(w1, codes, row);
   // byte sums of the row, exactly as the hot loop forms them
@@ -377,6 +382,9 @@ __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64
       if (acc <= ctrl->tau[q]) {
         const uint32_t pos = atomicAdd(&ctrl->cnt[q], 1u);
         uint64_t *buf = cand_wg + ((size_t)q * 2 + ((selmask >> q) & 1u)) * cap;
+        // ordered bases: the key carries the row's ORIGINAL number -- read here, for true survivors only (a load per queued
+        // row was 1.6e8 random 4-byte reads per launch on a 1.25e8-row shard: more HBM traffic than the codes)
+        const uint32_t kid = (perm ? perm[row] : row) + id_offset;
         buf[pos] = make_key(acc, kid);
       }
     }

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
 
 template <int NT, int QGB, int R, int KG = 0>
 __global__ __launch_bounds__(NT) void filt_kernel(const uint8_t *__restrict__ codes, const uint2 *__restrict__ tabs, uint32_t n,
@@ -345,6 +346,30 @@ int main() {
   const uint32_t n = 1000000, nq = 10016;   // multiple of 32
   std::vector<uint8_t> hc((size_t)n * 8);
   for (auto &c : hc) c = (uint8_t)(rand() >> 8);
+  if (const char *ob = getenv("ORDER")) {
+    // round 4: bank-aware row order (csrc/rq_order.hip): counting sort by the top 3 bits of the leading code bytes, the 32
+    // consecutive sorted rows of a lane group dealt to lanes (2 rows per lane), 1024-row granules left in sort order
+    // (the micro-kernel has no threshold estimate that would need the shuffle)
+    const int bits = atoi(ob);
+    std::vector<uint64_t> key(n);
+    std::vector<uint32_t> idx(n);
+    for (uint32_t i = 0; i < n; ++i) {
+      uint64_t k = 0; int left = bits;
+      for (int c = 0; c < 8 && left > 0; ++c) { const int nb = left < 3 ? left : 3; k = (k << nb) | (hc[(size_t)i * 8 + c] >> (8 - nb)); left -= nb; }
+      key[i] = (k << 32) | i; idx[i] = i;
+    }
+    std::sort(key.begin(), key.end());
+    std::vector<uint8_t> h2(hc.size());
+    for (uint32_t s = 0; s < n; ++s) {
+      const uint32_t src = (uint32_t)key[s];
+      uint32_t pos = s;
+      const uint32_t t = s / 128;
+      if ((t + 1) * 128 <= n) { const uint32_t u = s % 128, h = u / 64, v = u % 64, r = v / 32, j = v % 32; pos = t * 128 + h * 64 + j * 2 + r; }
+      for (int c = 0; c < 8; ++c) h2[(size_t)pos * 8 + c] = hc[(size_t)src * 8 + c];
+    }
+    hc.swap(h2);
+    printf("rows ordered by a %d-bit key\n", bits);
+  }
   std::vector<uint8_t> ht((size_t)(nq / 8) * 8 * 256 * 8);
   for (auto &t : ht) t = (uint8_t)((rand() >> 8) % 28);        // entries 0..27: sums ~108 +- 23
   uint8_t *codes; uint2 *tabs;
@@ -357,6 +382,14 @@ int main() {
   const uint32_t thr = 62;   // ~ a few % of (row, set) pairs alive
   run<512, 8>(codes, tabs, n, nq, thr, 2);
   run<512, 8>(codes, tabs, n, nq, thr, 4);
+  if (getenv("MICRO_QUICK")) {
+    run<256, 8>(codes, tabs, n, nq, thr, 8);
+    run<512, 16>(codes, tabs, n, nq, thr, 4);
+    run_nib<512>(codes, tabs, n, nq, 40, 2);
+    run_nib<512>(codes, tabs, n, nq, 40, 4);
+    for (uint32_t tA : {9u, 13u}) { run_casc<512>(codes, tabs, ntabs, n, nq, tA, 62, 2); run_casc<512>(codes, tabs, ntabs, n, nq, tA, 62, 4); }
+    return 0;
+  }
   run<1024, 8>(codes, tabs, n, nq, thr, 2);
   run<512, 16>(codes, tabs, n, nq, thr, 2);
   run<512, 16>(codes, tabs, n, nq, thr, 4);

@@ -20,7 +20,7 @@ from rayuela_jl_amd import device as rqd  # noqa: E402
 from rayuela_jl_amd import _lib  # noqa: E402
 
 
-def bench(fn, iters=5, warm=2):
+def bench(fn, iters=5, warm=8):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -75,7 +75,11 @@ for mode in a.modes.split(","):
         extra = ""
         if stats:
             s = _lib.scan_stats()
-            extra = "  fallbacks=%d cuts=%d items=%d" % (s["n_fallbacks"], s["n_cuts"], s["n_items"])
+            tot = sum(s[k] for k in ("lut", "sample", "stream", "final_cut", "sort_write")) or 1
+            extra = "  fallbacks=%d cuts=%d items=%d | %s first_block_alive=%.2f%%" % (
+                s["n_fallbacks"], s["n_cuts"], s["n_items"],
+                " ".join("%s=%.1f" % (k, 100.0 * s[k] / tot) for k in ("lut", "sample", "stream", "cuts", "final_cut", "sort_write", "sample_rows", "sort_load", "sort_stages", "sort_out")),
+                100.0 * s["first_block_pushed"] / max(1, s["first_block_rows"]))
         if K not in ref:
             ref[K] = (out[0].clone(), out[1].clone())
         else:
