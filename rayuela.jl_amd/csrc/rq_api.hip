@@ -359,14 +359,14 @@ size_t order_base_bytes(int64_t n, int mp) { return (((size_t)n * mp + 255) & ~(
 int order_base(const uint8_t **out_codes, const uint32_t **out_perm, void *dst, const uint8_t *codes, int64_t n, int mp,
                hipStream_t stream) {
   int nb[8];
-  const int bits = order_key_bits(n, mp, nb);
+  OrderTiling ot;
+  scan_order_tiling(mp, &ot);
+  const int bits = order_key_bits(n, mp, ot, nb);
   if (bits <= 0) return RQ_OK;          // tiny base: stays as it is (*out_perm untouched = nullptr)
   void *tmp = nullptr;
   RQ_TRY(workspace(WS_ORDER_TMP, order_scratch_bytes(n, bits), &tmp, stream));
-  int rpt = 1, gran = 512;
-  scan_order_tiling(mp, &rpt, &gran);
   uint32_t *pm = reinterpret_cast<uint32_t *>((uint8_t *)dst + (order_base_bytes(n, mp) - (size_t)n * 4));
-  RQ_TRY(order_rows_launch((uint8_t *)dst, pm, codes, n, mp, tmp, rpt, gran, stream));
+  RQ_TRY(order_rows_launch((uint8_t *)dst, pm, codes, n, mp, tmp, ot, stream));
   *out_codes = (const uint8_t *)dst;
   *out_perm = pm;
   return RQ_OK;

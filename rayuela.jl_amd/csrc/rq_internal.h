@@ -97,11 +97,12 @@ size_t order_base_bytes(int64_t n, int mp);
 int order_base(const uint8_t **out_codes, const uint32_t **out_perm, void *dst, const uint8_t *codes, int64_t n, int mp,
                hipStream_t stream);
 // ---- bank-aware row order (rq_order.hip) ---------------------------------------------------------
-int order_key_bits(int64_t n, int mp, int nb[8]);                       // key layout; returns the total bits (0: no ordering)
+struct OrderTiling { int rpt, gran, group, cbits; };                    // see scan_order_tiling (rq_scan.hip)
+void scan_order_tiling(int mp, OrderTiling *t);
+int order_key_bits(int64_t n, int mp, const OrderTiling &t, int nb[8]);  // key layout; returns the total bits (0: no ordering)
 size_t order_scratch_bytes(int64_t n, int total_bits);
-void scan_order_tiling(int mp, int *rpt, int *gran);                   // the scan kernel's rows per lane and rows per sub-step
-int order_rows_launch(uint8_t *dst, uint32_t *perm, const uint8_t *src, int64_t n, int mp, void *scratch, int rpt,
-                      int gran, hipStream_t stream);
+int order_rows_launch(uint8_t *dst, uint32_t *perm, const uint8_t *src, int64_t n, int mp, void *scratch,
+                      const OrderTiling &t, hipStream_t stream);
 // [P][nq][k] -> [nq][P][k] (lists gathered shard-major, merged query-major)
 int interleave_keys_launch(uint64_t *dst, const uint64_t *src, int64_t nq, int P, int k, size_t pstride, hipStream_t stream);
 int scan_padded_m(int m);   // smallest tiled row width >= m (2,4,8,16,32,64) or -1

@@ -41,6 +41,7 @@ struct OrderParams {
   uint32_t nbins;
   uint32_t tile;          // T = 64 * RPT rows: one wavefront's rows of a sub-step
   uint32_t rpt;
+  uint32_t group;         // rows that meet in one LDS gather: 32 (8-byte entries) or 64 (dword entries)
   uint32_t gran;          // shuffle granule (rows, multiple of tile)
   uint32_t ngran;         // full granules: n / gran
   uint32_t weyl;          // A: odd, coprime with ngran
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(1024) void order_scan_top_kernel(uint32_t *tot, uin
   if (threadIdx.x < ntiles) tot[threadIdx.x] = wbase + x - s;
 }
 
-// sorted rank -> position (see the header comment)
+// sorted rank -> position (see the header comment): `group` consecutive ranks become one lane group of the kernel --
+// lane l of a wavefront handles rows tile * T + l * RPT + r (r < RPT), the group (b, r) is lanes [b * group, (b + 1) * group)
 __device__ __forceinline__ uint32_t order_deal(const OrderParams &p, uint32_t s) {
   uint32_t g = s / p.gran;
   if (g < p.ngran) {
@@ -120,10 +122,10 @@ __device__ __forceinline__ uint32_t order_deal(const OrderParams &p, uint32_t s)
   }
   const uint32_t t = s / p.tile;
   if ((uint64_t)(t + 1) * p.tile > p.n) return s;     // the ragged last tile stays in sort order
-  const uint32_t u = s - t * p.tile, half = 32u * p.rpt;
-  const uint32_t h = u / half, v = u - h * half;
-  const uint32_t r = v >> 5, j = v & 31u;
-  return t * p.tile + h * half + j * p.rpt + r;
+  const uint32_t u = s - t * p.tile;
+  const uint32_t gi = u / p.group, j = u - gi * p.group;   // group inside the tile, row inside the group
+  const uint32_t b = gi / p.rpt, r = gi - b * p.rpt;
+  return t * p.tile + (b * p.group + j) * p.rpt + r;
 }
 
 // pass 3: every row to its position, perm[position] = row
@@ -145,20 +147,22 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(OrderParams p) {
 
 static uint32_t gcd_u32(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
 
-// Key layout for n rows of mp bytes: 3 bits per leading code byte while log2(n / 32) bits last (a 32-value window per
-// byte); what is left over goes to the next byte (1-2 bits: a 64/128-value window still halves its passes).  0 bits: no
-// ordering (tiny bases).
-int order_key_bits(int64_t n, int mp, int nb[8]) {
+// Key layout for n rows of mp bytes: `cbits` bits per leading code byte (the window 256 >> cbits = the bank columns one
+// gather of `group` lanes can hit without a conflict) while log2(n / group) bits last; what is left over goes to the next
+// byte (a wider window still lowers its passes).  0 bits: no ordering (tiny bases).
+int order_key_bits(int64_t n, int mp, const OrderTiling &t, int nb[8]) {
   for (int c = 0; c < 8; ++c) nb[c] = 0;
   if (n < 1024) return 0;
   int budget = tuning("ORDER_BITS", 0);
-  if (budget <= 0) budget = n >= 64 ? (int)std::floor(std::log2((double)n / 32.0) + 0.5) : 0;   // one bit per doubling of the group count
+  if (budget <= 0) budget = (int)std::floor(std::log2((double)n / (double)t.group) + 0.5);   // one bit per doubling of the group count
   budget = std::min(budget, 24);
   const int nc = std::min(mp, 8);
+  int cb = tuning("ORDER_CBITS", 0);
+  if (cb <= 0) cb = t.cbits;
   int total = 0;
-  for (int c = 0; c < nc && total < budget; ++c) { nb[c] = std::min(3, budget - total); total += nb[c]; }
+  for (int c = 0; c < nc && total < budget; ++c) { nb[c] = std::min(cb, budget - total); total += nb[c]; }
   // narrow rows (m <= 4): more bits per byte once every byte has its window
-  for (int c = 0; c < nc && total < budget; ++c) { const int add = std::min(5, budget - total); nb[c] += add; total += add; }
+  for (int c = 0; c < nc && total < budget; ++c) { const int add = std::min(8 - nb[c], budget - total); nb[c] += add; total += add; }
   return total;
 }
 
@@ -168,11 +172,12 @@ size_t order_scratch_bytes(int64_t n, int total_bits) {
   return (size_t)n * 4 + (nbins + ntiles + 16) * 4;
 }
 
-// codes [n][mp] -> dst [n][mp] + perm [n]; scratch of order_scratch_bytes().  rpt / gran: the scan tiling (scan_order_tiling).
-int order_rows_launch(uint8_t *dst, uint32_t *perm, const uint8_t *src, int64_t n, int mp, void *scratch, int rpt,
-                      int gran, hipStream_t stream) {
+// codes [n][mp] -> dst [n][mp] + perm [n]; scratch of order_scratch_bytes().  t: the scan tiling (scan_order_tiling).
+int order_rows_launch(uint8_t *dst, uint32_t *perm, const uint8_t *src, int64_t n, int mp, void *scratch,
+                      const OrderTiling &t, hipStream_t stream) {
   OrderParams p;
-  const int total = order_key_bits(n, mp, p.nb);
+  const int rpt = t.rpt, gran = t.gran;
+  const int total = order_key_bits(n, mp, t, p.nb);
   if (total <= 0 || total > 24) return fail(RQ_EINVAL, "order_rows: nothing to order (n=%lld)", (long long)n);
   p.src = src; p.dst = dst; p.perm = perm;
   p.n = (uint32_t)n; p.mp = mp;
@@ -182,6 +187,7 @@ int order_rows_launch(uint8_t *dst, uint32_t *perm, const uint8_t *src, int64_t 
   p.rank = reinterpret_cast<uint32_t *>(scratch);
   p.hist = p.rank + n;
   p.rpt = (uint32_t)rpt;
+  p.group = (uint32_t)t.group;
   p.tile = 64u * (uint32_t)rpt;
   p.gran = (uint32_t)std::max(gran, (int)p.tile) / p.tile * p.tile;
   p.ngran = (uint32_t)(n / p.gran);

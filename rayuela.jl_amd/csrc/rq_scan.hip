@@ -1081,20 +1081,23 @@ int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t
   return RQ_OK;
 }
 
-// the row tiling rq_order.hip has to match: rows per lane and sub-step, rows per workgroup sub-step (the shuffle granule)
-void scan_order_tiling(int mp, int *rpt, int *gran) {
+// the row tiling rq_order.hip has to match: rows per lane and sub-step, rows per workgroup sub-step (the shuffle granule),
+// rows that meet in one LDS gather and the key bits per code byte that make such a gather conflict-free.
+// Every LDS read width is served 32 lanes per pass on gfx950 (ds_read_b64: 256 B/clk; a dword gather moves half as much in
+// the same passes -- measured again in round 4 with byte tables split into [k][quad][256] dwords read by ds_read2st64_b32
+// and a 64-lane / 2-bit row order: 1.55 -> 2.65 ms), so the group is 32 rows and the window 32 values for all of them.
+void scan_order_tiling(int mp, OrderTiling *t) {
   int r = 1, g = SCAN_THREADS;
   switch (mp) {
-    case 2: r = ScanCfg<2>::RPT; g = ScanCfg<2>::SUB; break;
-    case 4: r = ScanCfg<4>::RPT; g = ScanCfg<4>::SUB; break;
-    case 8: r = ScanCfg<8>::RPT; g = ScanCfg<8>::SUB; break;
-    case 16: r = ScanCfg<16>::RPT; g = ScanCfg<16>::SUB; break;
-    case 32: r = ScanCfg<32>::RPT; g = ScanCfg<32>::SUB; break;
-    case 64: r = ScanCfg<64>::RPT; g = ScanCfg<64>::SUB; break;
+#define RQ_OT(MM) case MM: r = ScanCfg<MM>::RPT; g = ScanCfg<MM>::SUB; break;
+    RQ_OT(2) RQ_OT(4) RQ_OT(8) RQ_OT(16) RQ_OT(32) RQ_OT(64)
+#undef RQ_OT
   }
   const int tg = tuning("ORDER_GRAN", 0);
-  *rpt = r;
-  *gran = tg > 0 ? tg : g;
+  t->rpt = r;
+  t->gran = tg > 0 ? tg : g;
+  t->group = 32;
+  t->cbits = 3;
 }
 
 int pad_codes_launch(uint8_t *dst, const uint8_t *src, int64_t n, int m, int mp, hipStream_t stream) {
