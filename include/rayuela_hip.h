@@ -145,6 +145,11 @@ int rq_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n);
 int rq_dev_encode_pq(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m,
                      int h, void *stream);
 int rq_dev_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n, void *stream);
+/* Test aid (no reference counterpart): rq_dev_encode_pq through the split kernel (even sub-space widths <= 16), which also
+ * stores the values its bf16 matrix-core FILTER decides on: W [n][m][h], W_k = |c_k|^2 - 2 <c_k, x> as the MFMAs produced it.
+ * tests/test_gpu_encode_margin.py measures |(W_k + |x|^2) - v_k| against the bound the kernel's exactness rests on. */
+int rq_dev_encode_pq_filter_w(uint8_t *codes, float *W, const float *X, const float *C, int64_t n, int d, int m,
+                              int h, void *stream);
 /* Fused rotate+encode is an implementation detail; tmp may be NULL (library workspace). */
 int rq_dev_encode_opq(uint8_t *codes, const float *X, const float *R, const float *C, int64_t n,
                       int d, int m, int h, void *stream);

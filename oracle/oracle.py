@@ -55,6 +55,8 @@ def lib():
         _LIB.oracle_encode_pq.restype = None
         _LIB.oracle_encode_pq.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int64, C.c_int, C.c_int, C.c_int]
+        _LIB.oracle_pq_distmat.restype = None
+        _LIB.oracle_pq_distmat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]
         _LIB.oracle_encode_opq.restype = None
         _LIB.oracle_encode_opq.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int64, C.c_int, C.c_int, C.c_int]
@@ -233,6 +235,17 @@ def encode_pq(X, C_cat, m, h, with_costs=False):
     lib().oracle_encode_pq(_ptr(codes), _ptr(costs) if with_costs else None, _ptr(X), _ptr(Cc),
                            n, d, m, h)
     return (codes, costs) if with_costs else codes
+
+
+def pq_distmat(X, C_cat, m, h):
+    """U [n][m][h]: the unclamped canonical distances fl(fl(sa + sb) - 2 g) of quantize_pq's dmat (even splits)."""
+    X = _c(X, np.float32)
+    Cc = _c(np.asarray(C_cat).reshape(-1), np.float32)
+    n, d = X.shape
+    assert d % m == 0 and Cc.size == h * d
+    U = np.empty((n, m, h), dtype=np.float32)
+    lib().oracle_pq_distmat(_ptr(U), _ptr(X), _ptr(Cc), n, d, m, h)
+    return U
 
 
 def encode_opq(X, R, C_cat, m, h):

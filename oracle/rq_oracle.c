@@ -327,6 +327,28 @@ void oracle_encode_pq(uint8_t *codes, float *costs, const float *X, const float 
   free(off);
 }
 
+/* Every distance of quantize_pq's dmat (src/PQ.jl:40), not only the winners: U [n][m][h] receives the UNCLAMPED canonical
+ * value  u_k = fl( fl(sa_k + sb) - 2 g_k )  (v_k = max(u_k, 0)), same chains as oracle_encode_pq.  Even splits only
+ * (d % m == 0).  Test aid for the bf16 filter's margin (tests/test_gpu_encode_margin.py). */
+void oracle_pq_distmat(float *U, const float *X, const float *C, int64_t n, int d, int m, int h) {
+  const int sub = d / m;
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < n; j++) {
+    for (int i = 0; i < m; i++) {
+      const float *xs = X + (size_t)j * d + (size_t)i * sub;
+      float sb = 0.0f;
+      for (int s = 0; s < sub; s++) sb = fmaf(xs[s], xs[s], sb);
+      for (int k = 0; k < h; k++) {
+        const float *c = C + ((size_t)i * h + k) * sub;
+        float sa = 0.0f, g = 0.0f;
+        for (int s = 0; s < sub; s++) { sa = fmaf(c[s], c[s], sa); g = fmaf(c[s], xs[s], g); }
+        const float t = sa + sb;
+        U[((size_t)j * m + i) * h + k] = t - 2.0f * g;
+      }
+    }
+  }
+}
+
 /* src/OPQ.jl:19-27  quantize_opq(X,R,C) = quantize_pq(R'X, C) */
 void oracle_encode_opq(uint8_t *codes, const float *X, const float *R, const float *C,
                        int64_t n, int d, int m, int h) {

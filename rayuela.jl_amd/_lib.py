@@ -49,6 +49,7 @@ SIGNATURES = {
     "rq_dataset_free": (None, [_vp]),
     "rq_rotate_T": (_i32, [_vp, _vp, _vp, _i32, _i64]),
     "rq_dev_encode_pq": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "rq_dev_encode_pq_filter_w": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rq_dev_rotate_T": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp]),
     "rq_dev_encode_opq": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rq_dev_adc_lut": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),

@@ -980,6 +980,14 @@ int rq_dev_encode_pq(uint8_t *codes, const float *X, const float *C, int64_t n, 
   return encode_launch(codes, X, C, n, d, m, h, di.num_cu, (hipStream_t)stream);
 }
 
+int rq_dev_encode_pq_filter_w(uint8_t *codes, float *W, const float *X, const float *C, int64_t n, int d, int m, int h,
+                              void *stream) {
+  if (!W) return fail(RQ_EINVAL, "W is NULL");
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  return encode_launch(codes, X, C, n, d, m, h, di.num_cu, (hipStream_t)stream, W);
+}
+
 int rq_dev_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n, void *stream) {
   DeviceInfo di;
   RQ_TRY(device_info(&di));

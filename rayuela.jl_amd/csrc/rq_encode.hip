@@ -37,6 +37,8 @@ struct EncParams {
   int d, m, h, NT;
   int i0, i1;       // sub-quantizers handled by this launch (codebooks of [i0,i1) sit in LDS)
   int off[33];      // splitarray offsets (src/utils.jl:179-203)
+  float delta_rel;  // split kernel: candidate margin relative to max|c|^2 + |x|^2 (SplitCfg::DELTA_REL unless tuned, tests)
+  float *dbg_w;     // split kernel, tests only: [n][m][h] receives the filter's W values (nullptr in every product call)
 };
 
 constexpr int XS_STRIDE = 33;
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams 
       else if (tile + total_waves < ntiles) gload(tile + total_waves, 0);
       const float smax = saMax[il];
       const float ssum = smax + sb;
-      const float delta = SplitCfg::DELTA_REL * ssum;
+      const float delta = p.delta_rel * ssum;
       // the bound needs finite, non-vanishing magnitudes; otherwise this lane evaluates all its centroids exactly
       const bool slow = !(delta < __uint_as_float(0x7f800000u)) || !(ssum >= SplitCfg::TINY);
 
@@ -675,6 +677,15 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams 
         return __builtin_fminf(mm, a[15]);
       };
       auto tile_filter = [&](const f32x16 &a, int t) {
+        if (p.dbg_w) {          // tests/test_gpu_encode_margin.py: the very values the filter decides on (wave-uniform branch)
+          if (row0 + j < p.n) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int k = t * 32 + 4 * hi + 8 * (r >> 2) + (r & 3);
+              if (k < h) p.dbg_w[((size_t)(row0 + j) * m + i) * h + k] = a[r];
+            }
+          }
+        }
 #if defined(RQ_SPLIT_ABL) && RQ_SPLIT_ABL == 4
         b1 = __builtin_fminf(b1, a[t & 15]); return;
 #endif
@@ -1304,7 +1315,7 @@ static int launch_encode_split(EncParams p, int num_cu, hipStream_t stream) {
 }
 
 int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m, int h,
-                  int num_cu, hipStream_t stream) {
+                  int num_cu, hipStream_t stream, float *dbg_w) {
   if (n <= 0) return RQ_OK;
   if (m < 1 || m > 32) return fail(RQ_EUNSUPPORTED, "encode covers 1 <= m <= 32; got m=%d", m);
   if (h < 1 || h > 256) return fail(RQ_EUNSUPPORTED, "encode emits uint8 codes: 1 <= h <= 256; got h=%d", h);
@@ -1312,6 +1323,10 @@ int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int
   EncParams p;
   p.X = X; p.C = C; p.codes = codes; p.n = n; p.d = d; p.m = m; p.h = h;
   p.NT = (h + 31) / 32;
+  // ENC_SPLIT_DELTA_MILLI: the margin's numerator in thousandths (3000 = the shipped 3 * 2^-14); tests walk it down to
+  // find where codes first change -- the measured safety factor of the filter (tests/test_gpu_encode_margin.py)
+  p.delta_rel = (float)tuning("ENC_SPLIT_DELTA_MILLI", 3000) * 1e-3f * 6.103515625e-05f;
+  p.dbg_w = dbg_w;
   const int per = d / m, extra = d % m;
   int pos = 0, maxsub = 0;
   for (int i = 0; i < m; ++i) {
@@ -1345,6 +1360,7 @@ int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int
 #undef RQ_SPLIT_CASE
 #undef RQ_SPLIT_NT
   }
+  if (dbg_w) return fail(RQ_EUNSUPPORTED, "the filter's W values exist for the split kernel only (even sub-space widths <= 16)");
 #define RQ_ENC_NT(KSV, NW, DIR)                                             \
   do {                                                                     \
     if (nt <= 1) return launch_encode<KSV, 1, NW, DIR>(p, num_cu, stream);  \

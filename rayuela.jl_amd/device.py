@@ -25,6 +25,16 @@ def encode_pq(X, Ccat, m, h, out=None):
     return out
 
 
+def encode_pq_filter_w(X, Ccat, m, h):
+    """Test aid: (codes, W [n][m][h]) of the split encode kernel -- W = the bf16 matrix-core filter's values."""
+    n, d = X.shape
+    out = torch.empty((n, m), dtype=torch.uint8, device=X.device)
+    W = torch.full((n, m, h), float("nan"), dtype=torch.float32, device=X.device)
+    _lib.check(_lib.lib().rq_dev_encode_pq_filter_w(out.data_ptr(), W.data_ptr(), _chk(X, torch.float32, "X"),
+                                                    _chk(Ccat, torch.float32, "C"), n, d, m, h, _stream()))
+    return out, W
+
+
 def rotate_T(R, X, out=None):
     n, d = X.shape
     out = torch.empty_like(X) if out is None else out

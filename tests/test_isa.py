@@ -78,3 +78,91 @@ def test_prefilter_hot_loop_has_no_scratch_traffic(scan_asm, m, fine):
         if "scratch_" in ln and since_call > 12:
             hot.append(ln)
     assert not hot, "scratch access on the streaming path of the pre-filter loop:\n" + "\n".join(hot[:8])
+
+
+# ---- encode_pq_split_kernel: inline asm never reads MFMA results the compiler has not waited for ------------------------
+# The hazard recogniser does not look inside inline asm: an asm compare issued straight after an MFMA read stale accumulator
+# registers now and then in round 3 (2-12 wrong codes per 1e7, csrc/rq_encode.hip near the tile re-run).  The asm that is
+# left (the exec-masked v_mov_b64 copy of the winning tile, mask_leq16's v_cmp / v_addc) is only safe behind a
+# COMPILER-VISIBLE VALU read of the same MFMA's destination registers (tile_min's v_min3 tree): that read carries the
+# s_nop / dependency stall the hardware needs, and MFMAs retire in order.  This test walks the generated code of every
+# instantiation and fails if an asm statement touches a register of an MFMA that no ordinary VALU instruction has read yet.
+@pytest.fixture(scope="module")
+def encode_asm(tmp_path_factory):
+    if not os.path.isfile(HIPCC):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa_enc") / "rq_encode.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
+                           "--cuda-device-only", os.path.join(ROOT, "rayuela.jl_amd", "csrc", "rq_encode.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _vregs(operand_text):
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", operand_text):
+        regs.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bv(\d+)\b", operand_text):
+        regs.add(int(a))
+    return regs
+
+
+def _mfma_asm_hazards(lines):
+    """(line number, text) of asm-block instructions that touch registers of a not-yet-consumed MFMA"""
+    pending = []          # [(dest register set)] of MFMAs no compiler-visible VALU instruction has read yet, oldest first
+    in_asm = False
+    bad = []
+    for no, ln in enumerate(lines):
+        s = ln.strip()
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not s or s.startswith((";", ".")) or s.endswith(":"):
+            continue
+        op, _, rest = s.partition(" ")
+        rest = rest.split(";")[0]
+        if in_asm:
+            touched = _vregs(rest)
+            if any(touched & d for d in pending):
+                bad.append((no, s))
+            continue
+        if op.startswith("v_mfma"):
+            dest = _vregs(rest.split(",")[0])
+            pending = [d for d in pending if not (d & dest)] + [dest]      # a chained MFMA on the same accumulator replaces it
+            continue
+        if op.startswith("v_"):
+            srcs = _vregs(",".join(rest.split(",")[1:]))
+            for i in range(len(pending) - 1, -1, -1):
+                if pending[i] & srcs:
+                    pending = pending[i + 1:]          # this MFMA and (in-order retirement) every older one are complete
+                    break
+    return bad
+
+
+def test_split_encode_asm_never_reads_unconsumed_mfma_results(encode_asm):
+    names = sorted(set(re.findall(r"\n(_ZN2rq22encode_pq_split_kernelILi\d+ELi\d+ELi\d+EEEvNS_9EncParamsE):", encode_asm)))
+    assert len(names) >= 24, names        # 8 widths x 4 tile counts x 3 wave counts are instantiated
+    checked = 0
+    for name in names:
+        start = encode_asm.index("\n" + name + ":")
+        lines = encode_asm[start:encode_asm.index("s_endpgm", start)].splitlines()
+        if not any("v_mfma" in ln for ln in lines):
+            continue
+        bad = _mfma_asm_hazards(lines)
+        assert not bad, "%s: inline asm reads MFMA results before any compiler-visible VALU read:\n%s" % (
+            name, "\n".join("%d: %s" % b for b in bad[:6]))
+        checked += 1
+    assert checked >= 24
+
+
+def test_mfma_hazard_walker_detects_a_planted_hazard():
+    """the walker itself: an asm read straight behind the MFMA is flagged, one behind a v_min3 of the same tile is not"""
+    unsafe = ["v_mfma_f32_32x32x16_bf16 v[0:15], v[86:89], v[58:61], v[0:15]", ";;#ASMSTART", "v_mov_b64 v[90:91], v[2:3]", ";;#ASMEND"]
+    safe = ["v_mfma_f32_32x32x16_bf16 v[0:15], v[86:89], v[58:61], v[0:15]", "v_min3_f32 v40, v0, v1, v2", ";;#ASMSTART",
+            "v_mov_b64 v[90:91], v[2:3]", ";;#ASMEND"]
+    younger = ["v_mfma_f32_32x32x16_bf16 v[0:15], v[86:89], v[58:61], v[0:15]", "v_mfma_f32_32x32x16_bf16 v[16:31], v[86:89], v[58:61], v[16:31]",
+               "v_min3_f32 v40, v0, v1, v2", ";;#ASMSTART", "v_mov_b64 v[90:91], v[18:19]", ";;#ASMEND"]
+    assert _mfma_asm_hazards(unsafe) and not _mfma_asm_hazards(safe) and _mfma_asm_hazards(younger)
