@@ -77,6 +77,17 @@ int rq_linscan_lsq(float *dists, uint32_t *ids, const uint8_t *codes, const floa
                    int m, int h, int d, int k, int id_base);
 int rq_linscan_cq(float *dists, uint32_t *ids, const uint8_t *codes, const float *queries,
                   const float *codebooks, int64_t n, int64_t nq, int m, int h, int d, int k, int id_base);
+/* linscan_lsq over a PREPARED base (round 4): the pre-filter of the LSQ scan needs an O(n) pass over the base
+ * (|c|^2 tables, per-row cross-term norms in float64, their range, one byte per row) that rq_linscan_lsq redoes on every
+ * call because the ABI of deps/src/linscan_aqd_pairwise_byte.cpp:181-196 has no place to keep it (a cache keyed by the
+ * pointers would be unsound: callers rewrite buffers in place).  The handle keeps codes, dbnorms, codebooks and that pass
+ * on the device; searches upload queries only.  Same answers as rq_linscan_lsq (R may be NULL), bit for bit. */
+typedef struct rq_lsq_index rq_lsq_index;
+rq_lsq_index *rq_lsq_prepare(const uint8_t *codes, const float *codebooks, const float *dbnorms, int64_t n, int m,
+                             int h, int d);
+int rq_lsq_search(rq_lsq_index *ix, float *dists, uint32_t *ids, const float *queries, const float *R, int64_t nq,
+                  int k, int id_base);
+void rq_lsq_release(rq_lsq_index *ix);
 /* device-pointer form; lut_mode 1 = LSQ (dbnorms required), 2 = CQ */
 int rq_dev_linscan_aq(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes,
                       const float *codebooks, const float *queries, const float *dbnorms, int64_t n,

@@ -97,6 +97,50 @@ def linscan_lsq(B, X, C, dbnorms, R, k=10000):
     return dists, idx
 
 
+class LsqIndex:
+    """linscan_lsq over a PREPARED base (rq_lsq_prepare): codes, dbnorms and codebooks stay on the device together with the
+    pre-filter's O(n) preprocessing, which linscan_lsq otherwise repeats on every call.  search(X, R, k) returns exactly what
+    linscan_lsq(B, X, C, dbnorms, R, k) returns."""
+
+    def __init__(self, B, C, dbnorms):
+        Bu = _codes_u8(B)
+        n, m = Bu.shape
+        d = np.asarray(C[0]).shape[1]
+        cb = _hcat(C, m, d)
+        nrm = np.ascontiguousarray(dbnorms, dtype=np.float32)
+        if nrm.shape != (n,):
+            raise ValueError("dbnorms must have one entry per database row")
+        self.n, self.m, self.d = n, m, d
+        self._h = _lib.lib().rq_lsq_prepare(Bu.ctypes.data, cb.ctypes.data, nrm.ctypes.data, n, m, 256, d)
+        if not self._h:
+            raise _lib.RayuelaHipError("rq_lsq_prepare: " + _lib.lib().rq_last_error().decode("utf-8", "replace"))
+
+    def search(self, X, R=None, k=10000):
+        X = _as_f32(X, "X")
+        nq, d = X.shape
+        if d != self.d:
+            raise ValueError("queries must have d=%d columns" % self.d)
+        Rp = None if R is None else _as_f32(R, "R")
+        dists = _lib.result_empty((nq, k), np.float32)
+        idx = _lib.result_empty((nq, k), np.uint32)
+        _lib.check(_lib.lib().rq_lsq_search(self._h, dists.ctypes.data, idx.ctypes.data, X.ctypes.data,
+                                            None if Rp is None else Rp.ctypes.data, nq, k, 1))
+        return dists, idx
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().rq_lsq_release(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def linscan_cq(B, X, C, k=10000):
     """linscan_cq(B, X, C, k=10000) -> dists, idx      (src/Linscan.jl:160-193): T = |x - c|^2 per entry."""
     Bu = _codes_u8(B)

@@ -16,7 +16,7 @@ from .RVQ import quantize_rvq, quantize_rvq_u8  # noqa: F401
 from .PQ import train_pq, kmpp_seeds  # noqa: F401,E402
 from .OPQ import train_opq  # noqa: F401,E402
 from .RVQ import train_rvq  # noqa: F401,E402
-from .Linscan import (linscan_pq, linscan_opq, linscan_lsq, linscan_cq, linscan_aqd_query,  # noqa: F401
+from .Linscan import (linscan_pq, linscan_opq, linscan_lsq, linscan_cq, linscan_aqd_query, LsqIndex,  # noqa: F401
                       linscan_aqd_query_extra_byte, eval_recall)
 
 from .index import Index, Dataset  # noqa: F401,E402

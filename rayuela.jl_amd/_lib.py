@@ -33,6 +33,9 @@ SIGNATURES = {
     "linscan_aqd_cq_query_extra_byte": (None, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32]),
     "rq_linscan_lsq": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32]),
     "rq_linscan_cq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32]),
+    "rq_lsq_prepare": (_vp, [_vp, _vp, _vp, _i64, _i32, _i32, _i32]),
+    "rq_lsq_search": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
+    "rq_lsq_release": (None, [_vp]),
     "rq_dev_linscan_aq": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _u32, _i32, _vp]),
     "rq_linscan_pq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32]),
     "rq_linscan_opq": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32]),

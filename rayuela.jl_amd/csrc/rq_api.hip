@@ -375,7 +375,10 @@ int order_base(const uint8_t **out_codes, const uint32_t **out_perm, void *dst, 
 // ---- shared implementation of the scan on device pointers --------------------------------------------
 int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes, const float *centers,
                 const float *queries, int64_t n, int64_t nq, int m, int d, int k, uint32_t id_offset,
-                int id_base, hipStream_t stream, int lut_mode, const float *row_bias, const uint32_t *perm) {
+                int id_base, hipStream_t stream, int lut_mode, const float *row_bias, const ScanBase *base) {
+  const uint32_t *perm = base ? base->perm : nullptr;
+  uint8_t *norm_prepared = base ? base->norm_prepared : nullptr;
+  const bool padded = base && (base->padded || base->perm);
   if (nq <= 0) return RQ_OK;
   if (n < 1 || n >= (1LL << 31)) return fail(RQ_EINVAL, "n=%lld must be in [1, 2^31)", (long long)n);
   if (lut_mode < LUT_PQ || lut_mode > LUT_CQ) return fail(RQ_EINVAL, "lut_mode=%d", lut_mode);
@@ -392,7 +395,7 @@ int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *code
   DeviceLock launch_lock;   // workspace lookup + counter reset + launches of this device: one thread at a time
   const int mp = scan_padded_m(m);
   if (mp < 0) return fail(RQ_EUNSUPPORTED, "the ADC scan kernels cover 1 <= m <= 64 sub-quantizers; got m=%d", m);
-  if (mp != m && !perm) {
+  if (mp != m && !padded) {
     // row width not one of the tiled ones: zero-pad the rows (padding tables are all zero, so the
     // sequential sum is unchanged bit for bit)
     void *padded = nullptr;
@@ -421,12 +424,12 @@ int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *code
   const bool both = keys && (dists || ids);      // keys requested together with dists/ids: unpack at the end
   void *part = nullptr;
   if (sliced) RQ_TRY(workspace(WS_KEYS, (size_t)(nq - q_tail) * pl.nslices * k * sizeof(uint64_t), &part, stream));
-  void *normb = nullptr;     // LSQ pre-filter: one byte per row, 32 bytes of min / step, |c|^2 tables, f32 residual norms
-  if (lut_mode == LUT_LSQ && row_bias)
-    RQ_TRY(workspace(WS_NORMB, (((size_t)n + 63) & ~(size_t)63) + 32 + 16 * 256 * 4 + (size_t)n * 4, &normb, stream));
+  void *normb = norm_prepared;     // LSQ pre-filter: one byte per row, 32 bytes of min / step, |c|^2 tables, f32 residual norms
+  if (lut_mode == LUT_LSQ && row_bias && !normb)
+    RQ_TRY(workspace(WS_NORMB, lsq_norm_bytes(n), &normb, stream));
   RQ_TRY(scan_launch(pl, both ? nullptr : dists, both ? nullptr : ids, keys, (uint64_t *)part, codes, centers, queries,
                      n, nq, m, d, k, id_offset, id_base, (uint32_t *)counter, (uint64_t *)cand, stream, lut_mode,
-                     row_bias, (uint8_t *)normb, perm));
+                     row_bias, (uint8_t *)normb, perm, norm_prepared != nullptr));
   if (sliced) {
     const size_t off = (size_t)q_tail * k;
     RQ_TRY(merge_launch(both || !dists ? nullptr : dists + off, both || !ids ? nullptr : ids + off,
@@ -503,6 +506,17 @@ static int scan_and_fetch(float *dists, uint32_t *ids, float *dd, uint32_t *di, 
   return RQ_OK;
 }
 
+// Results in the library's page-locked arrays (rq_host_alloc): the kernel can store them over PCIe itself (one launch, no
+// copy back: 3.6 vs 3.8 ms at k = 1000).  Kernel stores cross PCIe at ~36 GB/s, the copy engine at ~45: from
+// HOST_DIRECT_MAX_MB (256) of results on -- k = 10000: 800 MB -- chunked scans with copy-engine transfers behind them win
+// (22.2 -> 20.0 ms; the floor is 800 MB / ~52 GB/s = 15.4 ms of PCIe plus the first chunk's scan).
+static bool use_direct_results(const float *dists, const uint32_t *ids, int64_t nq, int k) {
+  const size_t res_bytes = (size_t)nq * k * 8;
+  const size_t direct_max = (size_t)(tuning("HOST_DIRECT_MAX_MB", 0) > 0 ? tuning("HOST_DIRECT_MAX_MB", 0) : 256) << 20;
+  return tuning("HOST_DIRECT", 1) && res_bytes <= direct_max && host_pool_owns(dists, (size_t)nq * k * 4) &&
+         host_pool_owns(ids, (size_t)nq * k * 4);
+}
+
 static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers,
                         const float *queries, const float *R, int64_t n, int64_t nq, int m, int d, int k,
                         int id_base) {
@@ -531,14 +545,7 @@ static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const
   DevBuf dcodes, dcent, dq, dr, drq, dd, di_;
   const size_t cb = (size_t)n * m, ce = (size_t)m * 256 * (d / m) * 4, qb = (size_t)nq * d * 4;
   RQ_TRY(dcodes.alloc(cb)); RQ_TRY(dcent.alloc(ce)); RQ_TRY(dq.alloc(qb));
-  // Results in the library's page-locked arrays: the kernel can store them over PCIe itself (one launch, no copy back:
-  // 3.6 vs 3.8 ms at k = 1000).  Kernel stores cross PCIe at ~36 GB/s, the copy engine at ~45: from HOST_DIRECT_MAX_MB
-  // (256) of results on -- k = 10000: 800 MB -- chunked scans with copy-engine transfers behind them win (22.2 -> 20.0 ms;
-  // the floor is 800 MB / ~52 GB/s = 15.4 ms of PCIe plus the first chunk's scan).
-  const size_t res_bytes = (size_t)nq * k * 8;
-  const size_t direct_max = (size_t)(tuning("HOST_DIRECT_MAX_MB", 0) > 0 ? tuning("HOST_DIRECT_MAX_MB", 0) : 256) << 20;
-  const bool direct = tuning("HOST_DIRECT", 1) && res_bytes <= direct_max && host_pool_owns(dists, (size_t)nq * k * 4) &&
-                      host_pool_owns(ids, (size_t)nq * k * 4);
+  const bool direct = use_direct_results(dists, ids, nq, k);
   if (!direct) { RQ_TRY(dd.alloc((size_t)nq * k * 4)); RQ_TRY(di_.alloc((size_t)nq * k * 4)); }
   Timer t1;
   RQ_HIP(hipMemcpy(dcodes.p, codes, cb, hipMemcpyHostToDevice));
@@ -566,9 +573,11 @@ static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const
     RQ_TRY(dord.alloc(order_base_bytes(n, m)));
     RQ_TRY(order_base(&cdev, &perm, dord.p, cdev, n, m, nullptr));
   }
+  ScanBase sbase;
+  sbase.perm = perm;
   RQ_TRY(scan_and_fetch(dists, ids, direct ? nullptr : ddp, dip, nq, k, [&](int64_t q0, int64_t nqc, hipStream_t stream) {
     return dev_linscan(ddp + (size_t)q0 * k, dip + (size_t)q0 * k, nullptr, cdev, cen, qdev + (size_t)q0 * d, n, nqc, m,
-                       d, k, 0, id_base, stream, LUT_PQ, nullptr, perm);
+                       d, k, 0, id_base, stream, LUT_PQ, nullptr, &sbase);
   }));
   g_t_total = tt.ms();
   return RQ_OK;
@@ -585,20 +594,20 @@ static int host_linscan_aq(float *dists, uint32_t *ids, const uint8_t *codes, co
   if (n < 1 || m < 1 || d < 1) return fail(RQ_EINVAL, "bad shape n=%lld m=%d d=%d", (long long)n, m, d);
   if (k < 1 || k > n) return fail(RQ_EINVAL, "k=%d must be in [1, n=%lld]", k, (long long)n);
   if (lut_mode == LUT_LSQ && !dbnorms) return fail(RQ_EINVAL, "dbnorms is NULL");
+  SavedDevice saved;      // RAYUELA_HIP_DEVICES may move this call to another device: the caller's device comes back
+  {
+    // the additive-quantizer scans run on ONE device: the first entry of RAYUELA_HIP_DEVICES (row sharding over several
+    // devices covers linscan_pq / linscan_opq, rq_index.hip)
+    int devs[64];
+    if (env_devices(devs, 64) >= 1) RQ_HIP(hipSetDevice(devs[0]));
+  }
   DeviceInfo di;
   RQ_TRY(device_info(&di));
   DeviceLock call_lock;   // host-pointer calls on one device run one at a time (shared scratch + streams)
   DevBuf dcodes, dcb, dq, dn, dr, drq, dd, di_;
   const size_t cb = (size_t)n * m, ce = (size_t)m * 256 * d * 4, qb = (size_t)nq * d * 4;
   RQ_TRY(dcodes.alloc(cb)); RQ_TRY(dcb.alloc(ce)); RQ_TRY(dq.alloc(qb));
-  // Results in the library's page-locked arrays: the kernel can store them over PCIe itself (one launch, no copy back:
-  // 3.6 vs 3.8 ms at k = 1000).  Kernel stores cross PCIe at ~36 GB/s, the copy engine at ~45: from HOST_DIRECT_MAX_MB
-  // (256) of results on -- k = 10000: 800 MB -- chunked scans with copy-engine transfers behind them win (22.2 -> 20.0 ms;
-  // the floor is 800 MB / ~52 GB/s = 15.4 ms of PCIe plus the first chunk's scan).
-  const size_t res_bytes = (size_t)nq * k * 8;
-  const size_t direct_max = (size_t)(tuning("HOST_DIRECT_MAX_MB", 0) > 0 ? tuning("HOST_DIRECT_MAX_MB", 0) : 256) << 20;
-  const bool direct = tuning("HOST_DIRECT", 1) && res_bytes <= direct_max && host_pool_owns(dists, (size_t)nq * k * 4) &&
-                      host_pool_owns(ids, (size_t)nq * k * 4);
+  const bool direct = use_direct_results(dists, ids, nq, k);
   if (!direct) { RQ_TRY(dd.alloc((size_t)nq * k * 4)); RQ_TRY(di_.alloc((size_t)nq * k * 4)); }
   Timer t1;
   RQ_HIP(hipMemcpy(dcodes.p, codes, cb, hipMemcpyHostToDevice));
@@ -840,6 +849,117 @@ int rq_linscan_lsq(float *dists, uint32_t *ids, const uint8_t *codes, const floa
                    const float *dbnorms, const float *R, int64_t n, int64_t nq, int m, int h, int d, int k,
                    int id_base) {
   return host_linscan_aq(dists, ids, codes, queries, codebooks, dbnorms, R, n, nq, m, h, d, k, id_base, LUT_LSQ);
+}
+
+// ---- linscan_lsq over a PREPARED base: codes, norms, codebooks resident, the filter's O(n) preprocessing done once ---------
+struct rq_lsq_index_impl {
+  int device = 0;
+  int64_t n = 0;
+  int m = 0, mp = 0, d = 0;
+  uint8_t *codes = nullptr;      // [n][mp] (zero-padded to a tiled row width)
+  float *cb = nullptr, *norms = nullptr;
+  uint8_t *normb = nullptr;      // prepared norm buffer (lsq_norm_bytes) or nullptr when the filter does not apply
+};
+
+static void lsq_free(rq_lsq_index_impl *ix) {
+  if (!ix) return;
+  int cur = 0;
+  const bool have = hipGetDevice(&cur) == hipSuccess;
+  if (hipSetDevice(ix->device) == hipSuccess) {
+    (void)hipDeviceSynchronize();
+    if (ix->codes) (void)hipFree(ix->codes);
+    if (ix->cb) (void)hipFree(ix->cb);
+    if (ix->norms) (void)hipFree(ix->norms);
+    if (ix->normb) (void)hipFree(ix->normb);
+  }
+  if (have) (void)hipSetDevice(cur);
+  (void)hipGetLastError();
+  delete ix;
+}
+
+rq_lsq_index *rq_lsq_prepare(const uint8_t *codes, const float *codebooks, const float *dbnorms, int64_t n, int m, int h,
+                             int d) {
+  if (!codes || !codebooks || !dbnorms) { fail(RQ_EINVAL, "rq_lsq_prepare: NULL argument"); return nullptr; }
+  if (h != 256) { fail(RQ_EUNSUPPORTED, "the scan kernels cover h = 256 (uint8 codes); got h=%d", h); return nullptr; }
+  if (n < 1 || n >= (1LL << 31) || m < 1 || d < 1) { fail(RQ_EINVAL, "rq_lsq_prepare: bad shape n=%lld m=%d d=%d", (long long)n, m, d); return nullptr; }
+  const int mp = scan_padded_m(m);
+  if (mp < 0) { fail(RQ_EUNSUPPORTED, "the ADC scan kernels cover 1 <= m <= 64 sub-quantizers; got m=%d", m); return nullptr; }
+  DeviceInfo di;
+  if (device_info(&di) != RQ_OK) return nullptr;
+  DeviceLock lock;
+  rq_lsq_index_impl *ix = new rq_lsq_index_impl;
+  ix->device = di.device; ix->n = n; ix->m = m; ix->mp = mp; ix->d = d;
+  auto body = [&]() -> int {
+    RQ_HIP(hipMalloc((void **)&ix->codes, (size_t)n * mp));
+    RQ_HIP(hipMalloc((void **)&ix->cb, (size_t)m * 256 * d * 4));
+    RQ_HIP(hipMalloc((void **)&ix->norms, (size_t)n * 4));
+    RQ_HIP(hipMemcpy(ix->cb, codebooks, (size_t)m * 256 * d * 4, hipMemcpyHostToDevice));
+    RQ_HIP(hipMemcpy(ix->norms, dbnorms, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (mp == m) {
+      RQ_HIP(hipMemcpy(ix->codes, codes, (size_t)n * m, hipMemcpyHostToDevice));
+    } else {
+      DevBuf raw;
+      RQ_TRY(raw.alloc((size_t)n * m));
+      RQ_HIP(hipMemcpy(raw.p, codes, (size_t)n * m, hipMemcpyHostToDevice));
+      RQ_TRY(pad_codes_launch(ix->codes, raw.as<uint8_t>(), n, m, mp, nullptr));
+      RQ_HIP(hipDeviceSynchronize());
+    }
+    if ((mp == 8 || mp == 16) && tuning("SCAN_FILTER", 1) && tuning("SCAN_FILTER_LSQ", 1)) {
+      RQ_HIP(hipMalloc((void **)&ix->normb, lsq_norm_bytes(n)));
+      RQ_TRY(lsq_norm_prepare(ix->normb, ix->codes, ix->cb, ix->norms, n, mp, m, d, nullptr));
+      RQ_HIP(hipDeviceSynchronize());
+    }
+    return RQ_OK;
+  };
+  if (body() != RQ_OK) { lsq_free(ix); return nullptr; }
+  return reinterpret_cast<rq_lsq_index *>(ix);
+}
+
+void rq_lsq_release(rq_lsq_index *handle) { lsq_free(reinterpret_cast<rq_lsq_index_impl *>(handle)); }
+
+int rq_lsq_search(rq_lsq_index *handle, float *dists, uint32_t *ids, const float *queries, const float *R, int64_t nq, int k,
+                  int id_base) {
+  rq_lsq_index_impl *ix = reinterpret_cast<rq_lsq_index_impl *>(handle);
+  if (!ix) return fail(RQ_EINVAL, "rq_lsq_search: NULL handle");
+  if (nq <= 0) return RQ_OK;
+  if (!dists || !ids || !queries) return fail(RQ_EINVAL, "rq_lsq_search: NULL argument");
+  if (k < 1 || k > ix->n) return fail(RQ_EINVAL, "k=%d must be in [1, n=%lld]", k, (long long)ix->n);
+  Timer tt;
+  g_t_h2d = g_t_kernel = g_t_d2h = 0;
+  SavedDevice saved;
+  RQ_HIP(hipSetDevice(ix->device));
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  DeviceLock call_lock;
+  const int d = ix->d;
+  DevBuf dq, dr, drq, dd, di_;
+  const size_t qb = (size_t)nq * d * 4;
+  RQ_TRY(dq.alloc(qb));
+  const bool direct = use_direct_results(dists, ids, nq, k);
+  if (!direct) { RQ_TRY(dd.alloc((size_t)nq * k * 4)); RQ_TRY(di_.alloc((size_t)nq * k * 4)); }
+  Timer t1;
+  RQ_HIP(hipMemcpy(dq.p, queries, qb, hipMemcpyHostToDevice));
+  const float *qdev = dq.as<float>();
+  if (R) {
+    RQ_TRY(dr.alloc((size_t)d * d * 4)); RQ_TRY(drq.alloc(qb));
+    RQ_HIP(hipMemcpy(dr.p, R, (size_t)d * d * 4, hipMemcpyHostToDevice));
+  }
+  g_t_h2d = t1.ms();
+  if (R) {
+    RQ_TRY(rotate_launch(drq.as<float>(), dr.as<float>(), dq.as<float>(), d, nq, di.num_cu, nullptr));
+    qdev = drq.as<float>();
+  }
+  float *ddp = direct ? dists : dd.as<float>();
+  uint32_t *dip = direct ? ids : di_.as<uint32_t>();
+  RQ_TRY(scan_and_fetch(dists, ids, direct ? nullptr : ddp, dip, nq, k, [&](int64_t q0, int64_t nqc, hipStream_t stream) {
+    ScanBase sb;
+    sb.padded = true;
+    sb.norm_prepared = ix->normb;
+    return dev_linscan(ddp + (size_t)q0 * k, dip + (size_t)q0 * k, nullptr, ix->codes, ix->cb, qdev + (size_t)q0 * d, ix->n, nqc,
+                       ix->m, d, k, 0, id_base, stream, LUT_LSQ, ix->norms, &sb);
+  }));
+  g_t_total = tt.ms();
+  return RQ_OK;
 }
 
 int rq_linscan_cq(float *dists, uint32_t *ids, const uint8_t *codes, const float *queries, const float *codebooks,
@@ -1126,8 +1246,10 @@ int rq_dev_linscan_ordered(float *dists, uint32_t *ids, uint64_t *keys, const ui
     if (mp != m) return fail(RQ_EUNSUPPORTED, "ordered scan without perm needs a tiled row width (m=%d)", m);
     return dev_linscan(dists, ids, keys, codes_ordered, centers, queries, n, nq, m, d, k, id_offset, id_base, (hipStream_t)stream);
   }
+  ScanBase sb;
+  sb.perm = perm;
   return dev_linscan(dists, ids, keys, codes_ordered, centers, queries, n, nq, m, d, k, id_offset, id_base,
-                     (hipStream_t)stream, LUT_PQ, nullptr, perm);
+                     (hipStream_t)stream, LUT_PQ, nullptr, &sb);
 }
 
 int rq_dev_merge_topk(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t *keys_in, int64_t nq, int P,

@@ -390,8 +390,10 @@ int index_search(rq_index *ix, float *dists, uint32_t *ids, const float *queries
   RQ_TRY(grow((void **)&ix->di, &ix->di_cap, ob));
   if (P == 1) {
     IxShard &s = ix->shards[0];
+    ScanBase sb0;
+    sb0.perm = s.perm;
     RQ_TRY(dev_linscan(ix->dd, ix->di, nullptr, s.codes, root.centers, R_host ? root.queries_rot : root.queries, s.n, nq, m,
-                       d, k, ix->id_offset, id_base, root.stream, LUT_PQ, nullptr, s.perm));
+                       d, k, ix->id_offset, id_base, root.stream, LUT_PQ, nullptr, &sb0));
   } else {
     RQ_TRY(grow((void **)&ix->gathered, &ix->gathered_cap, (size_t)P * cnt * 8));
     RQ_TRY(grow((void **)&ix->inter, &ix->inter_cap, (size_t)P * cnt * 8));
@@ -432,8 +434,10 @@ int index_search(rq_index *ix, float *dists, uint32_t *ids, const float *queries
         uint64_t *out = (remote(si) ? s.keys : ix->gathered + (size_t)si * cnt) + (size_t)q0 * k;   // root shards: in place
         uint64_t *dst = k_local < k ? s.tmp + (size_t)q0 * k_local : out;
         const float *qs = (R_host ? dv.queries_rot : dv.queries) + (size_t)q0 * d;
+        ScanBase sbs;
+        sbs.perm = s.perm;
         RQ_TRY(dev_linscan(nullptr, nullptr, dst, s.codes, dv.centers, qs, s.n, nqc, m, d, k_local,
-                           (uint32_t)(ix->id_offset + (uint64_t)s.row0), 0, dv.stream, LUT_PQ, nullptr, s.perm));
+                           (uint32_t)(ix->id_offset + (uint64_t)s.row0), 0, dv.stream, LUT_PQ, nullptr, &sbs));
         if (k_local < k)
           RQ_HIP(hipMemcpy2DAsync(out, (size_t)k * 8, dst, (size_t)k_local * 8, (size_t)k_local * 8, (size_t)nqc,
                                   hipMemcpyDeviceToDevice, dv.stream));

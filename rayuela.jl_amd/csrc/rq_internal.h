@@ -85,13 +85,22 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
                 const float *centers, const float *queries, int64_t n, int64_t nq, int m, int d, int K,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
                 hipStream_t stream, int lut_mode = 0, const float *row_bias = nullptr, uint8_t *norm_buf = nullptr,
-                const uint32_t *perm = nullptr);
+                const uint32_t *perm = nullptr, bool norm_ready = false);
+size_t lsq_norm_bytes(int64_t n);      // LSQ pre-filter: bytes of a base's prepared norm buffer
+int lsq_norm_prepare(uint8_t *norm_buf, const uint8_t *codes, const float *centers, const float *row_bias, int64_t n,
+                     int mp, int m_real, int d, hipStream_t stream);
 enum { LUT_PQ = 0, LUT_LSQ = 1, LUT_CQ = 2 };
+// what a caller may know about a resident base beyond its code bytes
+struct ScanBase {
+  const uint32_t *perm = nullptr;     // rows are in bank-aware order (rq_order.hip): perm[position] = row; implies `padded`
+  uint8_t *norm_prepared = nullptr;   // LSQ: the pre-filter's prepared norm buffer (lsq_norm_prepare), else per call
+  bool padded = false;                // rows are scan_padded_m(m) bytes wide already
+};
 // argument checks + planner + launches of one resident shard (rq_dev_linscan's body)
 int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *codes, const float *centers,
                 const float *queries, int64_t n, int64_t nq, int m, int d, int k, uint32_t id_offset,
                 int id_base, hipStream_t stream, int lut_mode = LUT_PQ, const float *row_bias = nullptr,
-                const uint32_t *perm = nullptr);
+                const ScanBase *base = nullptr);
 bool order_pays(int64_t n, int64_t nq);                                 // SCAN_ORDER / ORDER_MIN_ROWS / ORDER_MIN_NQ
 size_t order_base_bytes(int64_t n, int mp);
 int order_base(const uint8_t **out_codes, const uint32_t **out_perm, void *dst, const uint8_t *codes, int64_t n, int mp,

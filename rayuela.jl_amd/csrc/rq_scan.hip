@@ -963,10 +963,35 @@ __global__ void norm_quant_kernel(const float *__restrict__ nrm, uint32_t n, con
   }
 }
 
+// LSQ pre-filter preprocessing of a base (O(n), independent of the queries): |c|^2 of the codebooks, the rows' cross-term
+// norms rho = norm - sum_k |c_k[b_k]|^2 (float64, rounded down), their range and one byte per row.
+// norm_buf: [n rounded up to 64] row bytes | 8 words of info | |c|^2 [16][256] f32 | rho [n] f32   (lsq_norm_bytes)
+size_t lsq_norm_bytes(int64_t n) { return (((size_t)n + 63) & ~(size_t)63) + 32 + 16 * 256 * 4 + (size_t)n * 4; }
+
+int lsq_norm_prepare(uint8_t *norm_buf, const uint8_t *codes, const float *centers, const float *row_bias, int64_t n,
+                     int mp, int m_real, int d, hipStream_t stream) {
+  const size_t nb_bytes = ((size_t)n + 63) & ~(size_t)63;
+  uint32_t *info = reinterpret_cast<uint32_t *>(norm_buf + nb_bytes);
+  float *cn = reinterpret_cast<float *>(info + 8);
+  float *rho = cn + 16 * 256;
+  RQ_HIP(hipMemsetAsync(info, 0xff, 4, stream));
+  RQ_HIP(hipMemsetAsync(info + 1, 0, 4, stream));
+  RQ_HIP(hipMemsetAsync(cn, 0, 16 * 256 * 4, stream));       // padding tables (m_real < m): |c|^2 = 0
+  const uint32_t grid = (uint32_t)std::min<int64_t>(2048, (n + 255) / 256);
+  hipLaunchKernelGGL(cnorm_kernel, dim3((m_real * 256 + 255) / 256), dim3(256), 0, stream, centers, m_real * 256, d, cn);
+  hipLaunchKernelGGL(norm_residual_kernel, dim3(grid), dim3(256), 0, stream, row_bias, codes, (uint32_t)n, mp, m_real, cn, rho);
+  hipLaunchKernelGGL(norm_minmax_kernel, dim3(grid), dim3(256), 0, stream, (const float *)rho, (uint32_t)n, info);
+  hipLaunchKernelGGL(norm_info_kernel, dim3(1), dim3(1), 0, stream, info);
+  hipLaunchKernelGGL(norm_quant_kernel, dim3(grid), dim3(256), 0, stream, (const float *)rho, (uint32_t)n, info, norm_buf);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
 int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys, uint64_t *part, const uint8_t *codes,
                 const float *centers, const float *queries, int64_t n, int64_t nq, int m, int d, int K,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
-                hipStream_t stream, int lut_mode, const float *row_bias, uint8_t *norm_buf, const uint32_t *perm) {
+                hipStream_t stream, int lut_mode, const float *row_bias, uint8_t *norm_buf, const uint32_t *perm,
+                bool norm_ready) {
   ScanParams p;
   p.perm = perm;
   p.codes = codes; p.centers = centers; p.queries = queries;
@@ -1010,21 +1035,11 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.norm_bytes = nullptr; p.norm_info = nullptr; p.cnorm = nullptr;
   if (lut_mode == LUT_LSQ && row_bias && norm_buf && (m == 8 || m == 16) && tuning("SCAN_FILTER", 1) &&
       tuning("SCAN_FILTER_LSQ", 1)) {
-    // norm_buf: [n rounded up to 64] row bytes | 8 words of info | |c|^2 [16][256] f32 | rho [n] f32
+    // the O(n) preprocessing of the base -- unless the caller holds a prepared base (rq_lsq_prepare: paid once, not per call)
+    if (!norm_ready) RQ_TRY(lsq_norm_prepare(norm_buf, codes, centers, row_bias, n, m, p.m_real, d, stream));
     const size_t nb_bytes = ((size_t)n + 63) & ~(size_t)63;
     uint32_t *info = reinterpret_cast<uint32_t *>(norm_buf + nb_bytes);
     float *cn = reinterpret_cast<float *>(info + 8);
-    float *rho = cn + 16 * 256;
-    RQ_HIP(hipMemsetAsync(info, 0xff, 4, stream));
-    RQ_HIP(hipMemsetAsync(info + 1, 0, 4, stream));
-    RQ_HIP(hipMemsetAsync(cn, 0, 16 * 256 * 4, stream));       // padding tables (m_real < m): |c|^2 = 0
-    const uint32_t grid = (uint32_t)std::min<int64_t>(2048, (n + 255) / 256);
-    hipLaunchKernelGGL(cnorm_kernel, dim3((p.m_real * 256 + 255) / 256), dim3(256), 0, stream, centers, p.m_real * 256, d, cn);
-    hipLaunchKernelGGL(norm_residual_kernel, dim3(grid), dim3(256), 0, stream, row_bias, codes, (uint32_t)n, m, p.m_real, cn, rho);
-    hipLaunchKernelGGL(norm_minmax_kernel, dim3(grid), dim3(256), 0, stream, (const float *)rho, (uint32_t)n, info);
-    hipLaunchKernelGGL(norm_info_kernel, dim3(1), dim3(1), 0, stream, info);
-    hipLaunchKernelGGL(norm_quant_kernel, dim3(grid), dim3(256), 0, stream, (const float *)rho, (uint32_t)n, info, norm_buf);
-    RQ_HIP(hipGetLastError());
     p.norm_bytes = norm_buf;
     p.norm_info = reinterpret_cast<const float *>(info) + 4;
     p.cnorm = cn;

@@ -56,3 +56,29 @@ def test_aq_vs_oracle_random(rq, oracle, n, m, d, nq, K):
     d0, i0 = oracle.linscan_cq(codes, cb, q, K)
     d1, i1 = rq.linscan_aqd_query_extra_byte(codes, q, cb, None, K)
     assert np.array_equal(i0, i1) and _eq_bits(d0, d1)
+
+
+@pytest.mark.parametrize("n,m,d,nq,K", [(300_000, 8, 64, 24, 1000), (100_003, 16, 48, 9, 100), (50_000, 5, 40, 7, 50), (5_000, 4, 32, 3, 5000)])
+def test_prepared_lsq_index_equals_linscan_lsq(rq, oracle, n, m, d, nq, K):
+    """rq_lsq_prepare / rq_lsq_search / rq_lsq_release (ADVICE r2): the pre-filter's O(n) preprocessing is paid once per base;
+    every search returns what linscan_lsq returns (= the compiled reference's deps/src/linscan_aqd_pairwise_byte.cpp:14-94
+    semantics, one-based ids), with and without a rotation, on clustered codes where the filter is active (m = 8, 16), on a
+    padded width (m = 5) and on a width without the filter (m = 4)."""
+    import rayuela_jl_amd.synth as synth
+    rng = np.random.default_rng(n + m)
+    C = [rng.standard_normal((256, d)).astype(np.float32) for _ in range(m)]
+    cb = np.concatenate(C)
+    codes = synth.random_codes(n, m, seed=n)
+    codes[: n // 2] = codes[rng.integers(0, 300, n // 2)]            # half of the rows are copies: ties and a live filter
+    nrm = ((cb.reshape(m, 256, d)[np.arange(m)[None, :], codes]).sum(1) ** 2).sum(1).astype(np.float32)   # true |x_hat|^2
+    R = synth.rotation(d, seed=5)
+    with rq.LsqIndex(codes, C, nrm) as ix:
+        for rot in (None, R):
+            for rep in range(2):                                      # searches re-use the prepared base
+                q = rng.standard_normal((nq, d)).astype(np.float32)
+                qr = q if rot is None else oracle.rotate_T(rot, q)
+                d0, i0 = oracle.linscan_lsq(codes, cb, qr, nrm, K)
+                d1, i1 = ix.search(q, rot, K)
+                assert np.array_equal(i1.view(np.int32), i0) and _eq_bits(d1, d0), (m, rot is not None, rep)
+                d2, i2 = rq.linscan_lsq(codes, q, C, nrm, np.eye(d, dtype=np.float32) if rot is None else rot, K)
+                assert np.array_equal(i2, i1) and _eq_bits(d2, d1)
