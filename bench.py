@@ -9,6 +9,8 @@ Workloads (BASELINE.json `configs`):
   deep    Deep1M-shape OPQ d=96 m=16 h=256                                   (config 4)
   sift1b  SIFT1B-shape base, 1e9 x 8 uint8 codes generated on the devices, nq=1024, k=100, rows sharded over
           the N GPUs, per-shard top-k gathered over xGMI (RCCL) and merged    (config 5; default at N > 1)
+  train_opq / train_pq   SURVEY 8f rank 1 (src/OPQ.jl:49-139, src/PQ.jl:68-99) on the SIFT1M-shape base through the C ABI
+          (rq_train_opq / rq_train_pq): a step = ONE training iteration; --steps = niter (the demos use 25); N = 1 only
 
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM: the ADC scan +
 exact top-k of nq queries over the WHOLE base (`value` = true queries/s against the whole base), and -- timed in
@@ -54,7 +56,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="auto", choices=["auto", "pq", "opq", "deep", "sift1b"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "pq", "opq", "deep", "sift1b", "train_opq", "train_pq"])
     ap.add_argument("--rows", dest="n", type=int, default=0, help="rows of the WHOLE base (default 1e6; sift1b: 1e9)")
     ap.add_argument("--nq", type=int, default=0, help="queries per step (default 10000; sift1b: 1024)")
     ap.add_argument("--k", type=int, default=0, help="neighbours (default 1000; sift1b: 100)")
@@ -150,8 +152,120 @@ def scan_roofline(m, n_local, nq, K, kernel_ms):
             "hbm": hbm}
 
 
+def train_bench(a):
+    """`--workload train_opq|train_pq`: one step = one iteration of the training loop on the resident SIFT1M-shape base.
+    ms_per_step = the library's own wall clock over the iteration loop / iterations (X upload, initialisation and the
+    download of the results are outside it and reported next to it); the phase split comes from a second, profiled call
+    (TRAIN_PROFILE = 1: every phase between device synchronisations)."""
+    import numpy as np
+    import torch
+    import rayuela_jl_amd as rq
+    import rayuela_jl_amd.synth as synth
+    import rayuela_jl_amd.synth_torch as st
+    from rayuela_jl_amd import _lib
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    opq = a.workload == "train_opq"
+    d, m, h = 128, 8, 256
+    n = a.n or 1_000_000
+    niter = max(1, a.steps)
+    X = torch.cat([st.sift_like(min(250_000, n - o), d, seed=synth.SEED_BASE, ncentres=65536, row0=o, device=device)
+                   for o in range(0, n, 250_000)], 0).cpu().numpy()
+
+    def run(it):
+        if opq:
+            return rq.train_opq(X, m, h, it, "natural", seed=7)
+        return rq.train_pq(X, m, h, it, seed=7)
+
+    if a.warmup > 0:
+        run(max(1, min(a.warmup, 3)))
+    t0 = time.perf_counter()
+    out = run(niter)
+    wall = time.perf_counter() - t0
+    prof = _lib.train_profile()
+    iters = max(1.0, prof["iterations"])
+    ms_step = prof["loop_ms"] / iters
+    rq.set_tuning("TRAIN_PROFILE", 1)
+    try:
+        run(niter)
+        fine = _lib.train_profile()
+    finally:
+        rq.set_tuning("TRAIN_PROFILE", 0)
+    fi = max(1.0, fine["iterations"])
+    per_iter = {k: round(fine[k] / fi, 4) for k in ("qerror_ms", "gram_ms", "svd_ms", "rotate_ms", "update_centers_ms", "encode_ms",
+                                                    "reconstruct_ms", "converge_ms") if fine[k] > 0}
+    # every device phase against its own roof (algorithmic bytes / flops per iteration, SURVEY 8d's style)
+    GB = 1e9
+    shapes = {"rotate_ms": ("mfma", 2.0 * d * d * n), "gram_ms": ("mfma", 2.0 * d * d * n), "encode_ms": ("mfma", 2.0 * d * h * n),
+              "update_centers_ms": ("hbm", (4.0 * d + m) * n), "reconstruct_ms": ("hbm", (4.0 * d + m) * n), "qerror_ms": ("hbm", 8.0 * d * n)}
+    roofs = {}
+    for k, (bound, work) in shapes.items():
+        if k not in per_iter:
+            continue
+        t = per_iter[k] * 1e-3
+        if bound == "mfma":
+            ach = work / t / 1e12
+            roofs[k[:-3]] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4)}
+        else:
+            ach = work / t / GB
+            roofs[k[:-3]] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+    dev_phases = {k: v for k, v in per_iter.items() if k not in ("svd_ms", "converge_ms")}
+    dom = max(dev_phases, key=dev_phases.get)[:-3] if dev_phases else None
+    roof = dict(roofs.get(dom, {}), kernel=dom, traffic=None, per_phase=roofs,
+                note="the dominant DEVICE phase of an iteration; svd_ms (host, d x d polar factor) is not a kernel") if dom else None
+    # CPU baseline: the numpy/oracle restatement of the same loop (oracle/train_oracle.py) on a bounded sample
+    cpu = None
+    if not a.no_cpu:
+        from oracle import oracle, train_oracle as to
+        ns = min(n, 100_000)
+        Xs = X[:ns]
+        off = to.offsets(d, m)
+        rngc = np.random.default_rng(0)
+        C0 = [Xs[rngc.choice(ns, h, replace=False)][:, off[i]:off[i + 1]].copy() for i in range(m)]
+        t0 = time.perf_counter()
+        if opq:
+            to.train_opq(Xs, m, h, 1, np.eye(d, dtype=np.float32), C0, fast=True)      # niter = 1 -> 2 loop iterations
+            its = 2
+        else:
+            codes = oracle.encode_pq(Xs, np.concatenate([c.reshape(-1) for c in C0]), m, h)
+            C1 = to.update_centers_fast(C0, Xs, codes, off, h)
+            oracle.encode_pq(Xs, np.concatenate([c.reshape(-1) for c in C1]), m, h)
+            its = 2
+        dt = time.perf_counter() - t0
+        ms_it = dt / its * 1e3 * (n / ns)
+        cpu = {"value": round(n / (ms_it * 1e-3), 1), "unit": "vectors x iterations / s", "cores": os.cpu_count() or 1, "kind": "port",
+               "ms_per_iteration_scaled": round(ms_it, 1),
+               "sample": "%d iterations of oracle/train_oracle.py (numpy + the C oracle's encode, all host cores) on the first %d of the %d "
+                         "vectors (%.1f s), time scaled by %g" % (its, ns, n, dt, n / ns)}
+    obj = None
+    if opq:
+        o = np.asarray(out[3], dtype=np.float64)
+        obj = {"first": float(o[0]), "last": float(o[-1]), "monotone_non_increasing": bool((np.diff(o) <= 1e-3 * o[:-1]).all())}
+    line = {
+        "metric": "%s training throughput (vectors x iterations / s)" % a.workload, "value": round(n / (ms_step * 1e-3), 1),
+        "unit": "vectors x iterations / s", "n_gpus": 1, "steps": int(iters), "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "SIFT1M-shape %s m=8 h=256, niter=%d (%s)" % (a.workload, niter, "src/OPQ.jl:49-139" if opq else "src/PQ.jl:68-99"),
+                   "n": n, "d": d, "m": m, "h": h, "generator": "splitmix64 (rayuela.jl_amd/synth.py)", "parallelism": "single GPU"},
+        "per_iteration_ms": per_iter,
+        "outside_the_loop_ms": {"x_upload": round(prof["h2d_ms"] or fine["h2d_ms"], 2), "init": round(fine["init_ms"], 2),
+                                "results_download": round(fine["d2h_ms"], 2), "whole_call_wall": round(wall * 1e3, 1)},
+        "profiled_loop_ms_per_step": round(fine["loop_ms"] / fi, 4),
+        "jacobi_sweeps_per_iteration": round(prof["jacobi_sweeps"] / iters, 2) if opq else None,
+        "objective": obj,
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+    sys.stdout.flush()
+
+
 def main():
     a = parse()
+    if a.workload in ("train_opq", "train_pq"):
+        if a.gpus != 1:
+            sys.stderr.write("bench.py: the training workloads run on one GPU\n")
+            sys.exit(2)
+        return train_bench(a)
     dev_list = [int(x) for x in a.devices.split(",") if x.strip() != ""] if a.devices else None
     if dev_list:
         if not a.inproc:

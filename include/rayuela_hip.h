@@ -237,6 +237,12 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
 int rq_kmpp_seeds(int64_t *seeds, float *C, const float *X, int64_t n, int d, int m, int h, uint64_t seed);
 int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, int64_t n, int d, int m,
                  int h, int niter, int init, uint64_t seed, const float *R0, const float *C0);
+/* Phase clock of the calling thread's last rq_train_pq / rq_train_opq call, milliseconds (measurement aid, bench.py
+ * --workload train_opq|train_pq): out[0] X upload, [1] initialisation, [2] qerror, [3] gram X'CB, [4] d x d polar factor
+ * incl. its two small copies, [5] rotation, [6] update_centers, [7] encode, [8] reconstruct, [9] convergence check,
+ * [10] results D2H, [11] wall time of the iteration loop, [12] iterations run.  [2]-[9] need tuning TRAIN_PROFILE = 1
+ * (every phase is then bracketed by device synchronisations). */
+int rq_train_profile(double *out, int cap);
 
 /* ---- device-resident index handle: codes uploaded once, searched many times -- on one device, or
  * row-sharded over the GPUs of a node from ONE host process (what a Julia session is).

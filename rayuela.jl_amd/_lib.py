@@ -70,6 +70,7 @@ SIGNATURES = {
     "rq_kmpp_seeds": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _u64]),
     "rq_train_pq": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _u64]),
     "rq_train_opq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _u64, _vp, _vp]),
+    "rq_train_profile": (_i32, [_vp, _i32]),
     "rq_index_create": (_vp, [_i32, _i32, _vp]),
     "rq_index_create_sharded": (_vp, [_i32, _i32, _vp, _vp, _i32]),
     "rq_index_set_codes": (_i32, [_vp, _vp, _i64, _u32]),
@@ -171,6 +172,17 @@ def result_empty(shape, dtype):
         if ptr:
             return np.asarray(_PinnedBlock(ptr, shape, dtype))
     return np.empty(shape, dtype=dtype)
+
+
+TRAIN_PHASES = ["h2d_ms", "init_ms", "qerror_ms", "gram_ms", "svd_ms", "rotate_ms", "update_centers_ms", "encode_ms",
+                "reconstruct_ms", "converge_ms", "d2h_ms", "loop_ms", "iterations", "jacobi_sweeps"]
+
+
+def train_profile():
+    """Phase clock of this thread's last train_pq / train_opq call (rq_train_profile)."""
+    out = (C.c_double * 16)()
+    check(lib().rq_train_profile(C.cast(out, C.c_void_p), 16))
+    return dict(zip(TRAIN_PHASES, [float(x) for x in out]))
 
 
 def last_timing():

@@ -150,6 +150,8 @@ int qerror_launch(double *acc_dev, const float *X, const float *CB, int64_t n, i
 // mincost [m][n] floats and partial [m][1024] doubles are scratch, u [m][h] uniforms in [0,1) (device pointers)
 int kmpp_init_launch(float *C, long long *seeds, float *mincost, double *partial, const double *u, const float *X,
                      int64_t n, int d, int m, int h, hipStream_t stream);
+int polar_factor_launch(float *Rimg, const float *G, double *Vw, int warm, int d, int *status, double *scratch, hipStream_t stream);
+int codes_changed_launch(unsigned long long *out, const uint8_t *a, const uint8_t *b, size_t nbytes, hipStream_t stream);
 int gram_launch(float *G, const float *X, const float *CB, int64_t n, int d, int num_cu, hipStream_t stream);
 
 }  // namespace rq

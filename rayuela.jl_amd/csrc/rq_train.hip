@@ -485,4 +485,225 @@ int gram_launch(float *G, const float *X, const float *CB, int64_t n, int d, int
   return RQ_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Polar factor  R = U V'  of the d x d matrix G = X CB'  (src/OPQ.jl:112-113: U, S, VV = svd(X * CB'); R = U * VV') on the
+// device: one-sided Jacobi SVD in double, ONE workgroup, the whole matrix in LDS (d <= 128, even: 128 KiB at d = 128).
+// Round 3 ran the same algorithm on ONE host core: 6.6 ms of a 10.1 ms OPQ iteration at SIFT1M shape (bench.py --workload
+// train_opq); here the d/2 column pairs of a round rotate in parallel -- the round-robin ("circle") ordering gives d - 1
+// rounds of d/2 disjoint pairs per sweep -- 16 lanes per pair.
+//   A <- G V0 (V0 = the previous call's right singular vectors: successive G of an OPQ run differ little, 2-3 sweeps instead of
+//        ~10; identity on the first call);  sweeps until max |a_p . a_q| / (|a_p| |a_q|) < 1e-14;
+//   s_p = |a_p|, U = A / s;  V' = S^-1 U' G  (A = G V  =>  U' G = S V');  R = U V'.
+// Only A lives in LDS; V is never rotated along (it is recovered from U' G at the end and kept for the next warm start).
+// status: 0 ok, 1 = a vanishing singular value (the polar factor is not unique there: the caller falls back to the host
+// path, which completes the basis).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double group16_sum(double v) {
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+  return v;
+}
+
+// (1) A0 = G V0, column-major doubles: A0[p * d + i] = sum_k G[i][k] V0[k][p]   (Vw[p * d + k] = V0[k][p]); warm == 0: A0 = G
+__global__ void polar_prep_kernel(double *__restrict__ A0, const float *__restrict__ G, const double *__restrict__ Vw, int warm, int d) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d * d) return;
+  const int p = e / d, i = e - p * d;
+  double acc;
+  if (warm) {
+    acc = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < d; ++k) acc = __builtin_fma((double)G[(size_t)i * d + k], Vw[(size_t)p * d + k], acc);
+  } else {
+    acc = (double)G[(size_t)i * d + p];
+  }
+  A0[e] = acc;
+}
+
+// fast double reciprocal / reciprocal square root: the hardware estimates (v_rcp_f64 / v_rsq_f64, ~2^-27) + two Newton steps.
+// The IEEE division and sqrt sequences (~50 instructions each, executed by every lane of every wavefront) were most of a
+// Jacobi round: 2.5 ms per polar factor.  A rotation only has to be orthogonal to ~1e-15, which c = rsqrt(1 + t^2),
+// s = c t is by construction.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  return y;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+  y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+__device__ __forceinline__ double group8_sum(double v) {
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) v += __shfl_xor(v, off, 8);
+  return v;
+}
+
+// (2) the sweeps, one workgroup of 512 threads (8 lanes per column pair, 16 elements per lane at d = 128): A (LDS) <- A0;
+//     on exit U = A / s (column-major, back into A0's storage) and s
+constexpr int POLAR_THREADS = 512, POLAR_LANES = 8, POLAR_EPL = 16;
+__global__ __launch_bounds__(POLAR_THREADS) void polar_jacobi_kernel(double *__restrict__ AU, double *__restrict__ sv, int d, int *status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // column p at A + p * ld, ld = d + 8: a lane group reads 8 consecutive doubles of its column, the four pairs of a 32-lane
+  // LDS pass hold CONSECUTIVE columns (circle ordering below), so their bank groups 8 p mod 32 are distinct.  (With ld = d
+  // every column starts on bank 0: 8-way conflicts, 3.3 us per round instead of ~0.5.)
+  double *A = reinterpret_cast<double *>(smem_raw);
+  const int ld = d + 8;
+  __shared__ unsigned long long s_off;
+  __shared__ int s_bad;
+  __shared__ double s_sv[128];
+  const int tid = threadIdx.x, slot = tid / POLAR_LANES, sub = tid % POLAR_LANES;
+  const int npairs = d / 2;
+  for (int e = tid; e < d * d; e += POLAR_THREADS) A[(e / d) * ld + (e % d)] = AU[e];
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  int nsweeps = 0;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    ++nsweeps;
+    if (tid == 0) s_off = 0ull;
+    __syncthreads();
+    for (int round = 0; round < d - 1; ++round) {
+      if (slot < npairs) {
+        // circle method: position d-1 is fixed, the others rotate (round + slot and round - slot + d - 1 are below 2 (d - 1))
+        int p, q;
+        if (slot == 0) { p = d - 1; q = round; }
+        else {
+          p = round + slot; if (p >= d - 1) p -= d - 1;
+          q = round - slot + (d - 1); if (q >= d - 1) q -= d - 1;
+        }
+        double *ap = A + (size_t)p * ld, *aq = A + (size_t)q * ld;
+        double x[POLAR_EPL], y[POLAR_EPL];
+        double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+        for (int i = 0; i < POLAR_EPL; ++i) {
+          const int e = sub + POLAR_LANES * i;
+          x[i] = e < d ? ap[e] : 0.0;
+          y[i] = e < d ? aq[e] : 0.0;
+          al = __builtin_fma(x[i], x[i], al);
+          be = __builtin_fma(y[i], y[i], be);
+          ga = __builtin_fma(x[i], y[i], ga);
+        }
+        al = group8_sum(al); be = group8_sum(be); ga = group8_sum(ga);
+        const double ab = al * be, g2 = ga * ga;
+        if (ab > 0.0) {
+          // lim^2 = (a_p . a_q)^2 / (|a_p|^2 |a_q|^2); rotate while lim >= 1e-15
+          if (sub == 0) atomicMax(&s_off, (unsigned long long)__double_as_longlong(g2 * fast_rcp(ab)));   // >= 0: bit order = value order
+          if (g2 >= 1e-30 * ab) {
+            const double zeta = (be - al) * 0.5 * fast_rcp(ga);
+            const double az = fabs(zeta);
+            // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2));  sqrt(w) = w rsqrt(w)
+            const double w = __builtin_fma(zeta, zeta, 1.0);
+            double t = fast_rcp(az + w * fast_rsqrt(w));
+            if (!(az < 1e150)) t = 0.5 * fast_rcp(az);          // zeta^2 overflows: t -> 1 / (2 zeta)
+            t = zeta >= 0.0 ? t : -t;
+            const double c = fast_rsqrt(__builtin_fma(t, t, 1.0)), sn = c * t;
+#pragma unroll
+            for (int i = 0; i < POLAR_EPL; ++i) {
+              const int e = sub + POLAR_LANES * i;
+              if (e < d) {
+                ap[e] = c * x[i] - sn * y[i];
+                aq[e] = sn * x[i] + c * y[i];
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const double off2 = __longlong_as_double((long long)s_off);
+    __syncthreads();
+    // max |cos angle| between two columns below 1e-9: G itself is an f32 accumulation (relative error ~1e-6) and R is stored
+    // as f32 (2^-24 = 6e-8), so the 1e-14 of the host version bought nothing -- and every sweep is d - 1 latency-bound rounds
+    if (off2 < 1e-18) break;
+  }
+  for (int p = slot; p < d; p += POLAR_THREADS / POLAR_LANES) {
+    double nn = 0.0;
+    for (int i = 0; i < POLAR_EPL; ++i) { const int e = sub + POLAR_LANES * i; if (e < d) nn = __builtin_fma(A[(size_t)p * ld + e], A[(size_t)p * ld + e], nn); }
+    nn = sqrt(group8_sum(nn));
+    if (sub == 0) s_sv[p] = nn;
+  }
+  __syncthreads();
+  {
+    double mx = 0.0;
+    for (int p = 0; p < d; ++p) mx = fmax(mx, s_sv[p]);
+    for (int p = tid; p < d; p += POLAR_THREADS) if (!(s_sv[p] > mx * 1e-12) || !(mx > 0.0) || !(mx < 1e300)) s_bad = 1;
+  }
+  __syncthreads();
+  if (tid == 0) { status[0] = s_bad; status[1] = nsweeps; }
+  if (s_bad) return;
+  for (int e = tid; e < d * d; e += POLAR_THREADS) AU[e] = A[(e / d) * ld + (e % d)] / s_sv[e / d];
+  for (int p = tid; p < d; p += POLAR_THREADS) sv[p] = s_sv[p];
+}
+
+// (3) V'[p][b] = (U' G)[p][b] / s_p   (A = G V = U S  =>  U' G = S V');  kept for the next warm start: Vw[p * d + b] = V[b][p]
+__global__ void polar_vt_kernel(double *__restrict__ Vw, const double *__restrict__ U, const float *__restrict__ G,
+                                const double *__restrict__ sv, int d, const int *status) {
+  if (*status != 0) return;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d * d) return;
+  const int p = e / d, b = e - p * d;
+  double acc = 0.0;
+#pragma unroll 8
+  for (int a = 0; a < d; ++a) acc = __builtin_fma(U[(size_t)p * d + a], (double)G[(size_t)a * d + b], acc);
+  Vw[e] = acc / sv[p];
+}
+
+// (4) R = U V' ; memory image of Julia's R: Rimg[i * d + k] = R[k][i] = sum_p U[k][p] V[i][p]
+__global__ void polar_r_kernel(float *__restrict__ Rimg, const double *__restrict__ U, const double *__restrict__ Vw, int d,
+                               const int *status) {
+  if (*status != 0) return;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d * d) return;
+  const int i = e / d, k = e - i * d;
+  double acc = 0.0;
+#pragma unroll 8
+  for (int p = 0; p < d; ++p) acc = __builtin_fma(U[(size_t)p * d + k], Vw[(size_t)p * d + i], acc);
+  Rimg[e] = (float)acc;
+}
+
+// G [d][d] f32 (row-major, G[a][b] = (X CB')[a, b]) -> Rimg [d][d] f32; Vw [d][d] doubles persists between calls (warm != 0:
+// it holds the previous V); scratch (d*d + d) doubles; status one int (read it after the stream has drained: 0 = R written).
+// d even, 2 <= d <= 128.
+int polar_factor_launch(float *Rimg, const float *G, double *Vw, int warm, int d, int *status, double *scratch, hipStream_t stream) {
+  if (d < 2 || d > 128 || (d & 1)) return fail(RQ_EUNSUPPORTED, "device polar factor: even d <= 128; got %d", d);
+  const size_t lds = (size_t)d * (d + 8) * sizeof(double);
+  double *AU = scratch, *sv = scratch + (size_t)d * d;
+  const int nb = (d * d + 255) / 256;
+  hipLaunchKernelGGL(polar_prep_kernel, dim3(nb), dim3(256), 0, stream, AU, G, (const double *)Vw, warm, d);
+  RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(polar_jacobi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(polar_jacobi_kernel, dim3(1), dim3(POLAR_THREADS), lds, stream, AU, sv, d, status);
+  hipLaunchKernelGGL(polar_vt_kernel, dim3(nb), dim3(256), 0, stream, Vw, (const double *)AU, G, (const double *)sv, d, (const int *)status);
+  hipLaunchKernelGGL(polar_r_kernel, dim3(nb), dim3(256), 0, stream, Rimg, (const double *)AU, (const double *)Vw, d, (const int *)status);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+// number of positions where two code arrays differ (train_pq's convergence test: "no assignment changed")
+__global__ void codes_changed_kernel(unsigned long long *out, const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, size_t nbytes) {
+  unsigned long long c = 0;
+  const size_t nw = nbytes / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t x = reinterpret_cast<const uint64_t *>(a)[i] ^ reinterpret_cast<const uint64_t *>(b)[i];
+    // bytes of x that are non-zero
+    const uint64_t nz = ((x | ((x | 0x8080808080808080ull) - 0x0101010101010101ull)) & 0x8080808080808080ull);
+    c += (unsigned long long)__popcll(nz);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t i = nw * 8; i < nbytes; ++i) c += a[i] != b[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+int codes_changed_launch(unsigned long long *out, const uint8_t *a, const uint8_t *b, size_t nbytes, hipStream_t stream) {
+  RQ_HIP(hipMemsetAsync(out, 0, 8, stream));
+  const uint32_t grid = (uint32_t)std::min<size_t>(1024, (nbytes / 8 + 255) / 256 + 1);
+  hipLaunchKernelGGL(codes_changed_kernel, dim3(grid), dim3(256), 0, stream, out, a, b, nbytes);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
 }  // namespace rq

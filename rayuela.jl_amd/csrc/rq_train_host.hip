@@ -11,6 +11,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <chrono>
 #include <vector>
 
 #include "rq_internal.h"
@@ -149,6 +150,26 @@ static void polar_factor(const double *G, double *out, int d, std::vector<double
   }
 }
 
+// Phase clock of the training loops (rq_train_profile).  The loop's wall time (slot LOOP) and the iteration count are always
+// recorded -- two device synchronisations per call; with tuning TRAIN_PROFILE = 1 every phase is bracketed by
+// synchronisations too, so the per-phase figures are exact and the loop total a little longer than an unprofiled run's.
+enum { TP_H2D = 0, TP_INIT, TP_QERROR, TP_GRAM, TP_SVD, TP_ROTATE, TP_CENTERS, TP_ENCODE, TP_RECONSTRUCT, TP_CONVERGE,
+       TP_D2H, TP_LOOP, TP_ITERS, TP_SWEEPS, TP_SLOTS = 16 };
+static thread_local double g_train_prof[TP_SLOTS];
+struct TrainProf {
+  bool fine;
+  std::chrono::steady_clock::time_point t0, tl;
+  TrainProf() : fine(tuning("TRAIN_PROFILE", 0) != 0) { for (double &x : g_train_prof) x = 0.0; }
+  static double since(std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+  }
+  void start() { if (fine) { (void)hipDeviceSynchronize(); t0 = std::chrono::steady_clock::now(); } }
+  void stop(int slot) { if (fine) { (void)hipDeviceSynchronize(); g_train_prof[slot] += since(t0); } }
+  void loop_begin() { (void)hipDeviceSynchronize(); tl = std::chrono::steady_clock::now(); }
+  void loop_end(int iters) { (void)hipDeviceSynchronize(); g_train_prof[TP_LOOP] = since(tl); g_train_prof[TP_ITERS] = iters; }
+};
+#define RQ_PH(slot, stmt) do { prof.start(); stmt; prof.stop(slot); } while (0)
+
 struct DevMem {
   void *p = nullptr;
   ~DevMem() { if (p) (void)hipFree(p); }
@@ -239,17 +260,30 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
   RQ_TRY(dX.alloc((size_t)n * d * 4)); RQ_TRY(dC.alloc((size_t)h * d * 4)); RQ_TRY(dcodes.alloc((size_t)n * m));
   RQ_TRY(dprev.alloc((size_t)n * m)); RQ_TRY(dcnt.alloc((size_t)m * h * 4)); RQ_TRY(dCB.alloc((size_t)n * d * 4));
   RQ_TRY(dacc.alloc(8)); RQ_TRY(d16.alloc((size_t)n * m * 2));
-  RQ_HIP(hipMemcpy(dX.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice));
-  RQ_TRY(seed_centers(dC.as<float>(), dX.as<float>(), n, d, m, h, off, rng));
+  TrainProf prof;
+  RQ_PH(TP_H2D, RQ_HIP(hipMemcpy(dX.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice)));
+  RQ_PH(TP_INIT, RQ_TRY(seed_centers(dC.as<float>(), dX.as<float>(), n, d, m, h, off, rng)));
   std::vector<unsigned int> counts((size_t)m * h);
-  std::vector<uint8_t> cur((size_t)n * m), prev;
+  // convergence = "no assignment changed" (Clustering.kmeans' tol on these magnitudes): the codes of two consecutive
+  // iterations are compared ON THE DEVICE (a D2H of n*m bytes + a host compare per iteration cost more than the encode)
+  DevMem dchg;
+  RQ_TRY(dchg.alloc(8));
+  int iters_done = 0;
+  prof.loop_begin();
   for (int it = 0; it < niter; ++it) {
-    RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
-    RQ_HIP(hipMemcpy(cur.data(), dcodes.p, (size_t)n * m, hipMemcpyDeviceToHost));
-    if (!prev.empty() && prev == cur) break;   // assignments stable: Lloyd has converged
-    prev = cur;
-    RQ_TRY(update_centers_launch(dC.as<float>(), dcnt.as<unsigned int>(), dX.as<float>(), dcodes.as<uint8_t>(), n, d,
-                                 m, h, di.num_cu, nullptr));
+    RQ_PH(TP_ENCODE, RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr)));
+    unsigned long long changed = 1;
+    prof.start();
+    if (it > 0) {
+      RQ_TRY(codes_changed_launch(dchg.as<unsigned long long>(), dcodes.as<uint8_t>(), dprev.as<uint8_t>(), (size_t)n * m, nullptr));
+      RQ_HIP(hipMemcpy(&changed, dchg.p, 8, hipMemcpyDeviceToHost));
+    }
+    if (changed) RQ_HIP(hipMemcpyAsync(dprev.p, dcodes.p, (size_t)n * m, hipMemcpyDeviceToDevice, nullptr));
+    prof.stop(TP_CONVERGE);
+    if (!changed) break;   // assignments stable: Lloyd has converged
+    ++iters_done;
+    RQ_PH(TP_CENTERS, RQ_TRY(update_centers_launch(dC.as<float>(), dcnt.as<unsigned int>(), dX.as<float>(), dcodes.as<uint8_t>(), n, d,
+                                 m, h, di.num_cu, nullptr)));
     RQ_HIP(hipMemcpy(counts.data(), dcnt.p, (size_t)m * h * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < m; ++i)               // re-seed empty clusters from sampled rows
       for (int k = 0; k < h; ++k)
@@ -260,15 +294,18 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
                            sizeof(float) * sub, hipMemcpyDeviceToDevice));
         }
   }
-  RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
-  RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr));
-  RQ_TRY(qerror_launch(dacc.as<double>(), dX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr));
+  prof.loop_end(iters_done);
+  RQ_PH(TP_ENCODE, RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr)));
+  RQ_PH(TP_RECONSTRUCT, RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr)));
+  RQ_PH(TP_QERROR, RQ_TRY(qerror_launch(dacc.as<double>(), dX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr)));
   RQ_TRY(widen_codes_launch(d16.as<int16_t>(), dcodes.as<uint8_t>(), n * m, nullptr));
   double acc = 0;
   RQ_HIP(hipMemcpy(&acc, dacc.p, 8, hipMemcpyDeviceToHost));
   if (error) *error = acc / (double)n;
+  prof.start();
   RQ_HIP(hipMemcpy(C, dC.p, (size_t)h * d * 4, hipMemcpyDeviceToHost));
   RQ_HIP(hipMemcpy(B1, d16.p, (size_t)n * m * 2, hipMemcpyDeviceToHost));
+  prof.stop(TP_D2H);
   return RQ_OK;
 }
 
@@ -352,40 +389,79 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
   RQ_TRY(dC.alloc((size_t)h * d * 4)); RQ_TRY(dcodes.alloc((size_t)n * m)); RQ_TRY(dcnt.alloc((size_t)m * h * 4));
   RQ_TRY(dCB.alloc((size_t)n * d * 4)); RQ_TRY(dacc.alloc(8)); RQ_TRY(dG.alloc((size_t)d * d * 4));
   RQ_TRY(d16.alloc((size_t)n * m * 2));
-  RQ_HIP(hipMemcpy(dX.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice));
+  TrainProf prof;
+  RQ_PH(TP_H2D, RQ_HIP(hipMemcpy(dX.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice)));
+  prof.start();
   RQ_HIP(hipMemcpy(dR.p, Rh.data(), (size_t)d * d * 4, hipMemcpyHostToDevice));
   RQ_TRY(rotate_launch(dRX.as<float>(), dR.as<float>(), dX.as<float>(), d, n, di.num_cu, nullptr));
   if (C0) RQ_HIP(hipMemcpy(dC.p, C0, (size_t)h * d * 4, hipMemcpyHostToDevice));
   else RQ_TRY(init_centers(dC.as<float>(), dRX.as<float>(), n, d, m, h, off, rng));
   RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dRX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
   RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr));
+  prof.stop(TP_INIT);
   std::vector<float> Gf((size_t)d * d);
   std::vector<double> Vwarm;   // empty on the first iteration: cold start
+  // the d x d polar factor on the device (rq_train.hip: polar_factor_kernel) for even d <= 128; the host Jacobi otherwise,
+  // and whenever the device kernel reports a vanishing singular value (the host code completes the basis there)
+  const bool dev_polar = tuning("TRAIN_GPU_POLAR", 1) && d >= 2 && d <= 128 && (d & 1) == 0;
+  DevMem dVw, dscr, dstat;
+  if (dev_polar) { RQ_TRY(dVw.alloc((size_t)d * d * 8)); RQ_TRY(dscr.alloc(((size_t)d * d + d) * 8)); RQ_TRY(dstat.alloc(8)); }
+  bool dev_warm = false;
+  prof.loop_begin();
   for (int it = 0; it <= niter; ++it) {
     // objective |R CB - X|^2 / n == |CB - R'X|^2 / n (src/OPQ.jl:108)
+    prof.start();
     RQ_TRY(qerror_launch(dacc.as<double>(), dRX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr));
     double acc = 0;
     RQ_HIP(hipMemcpy(&acc, dacc.p, 8, hipMemcpyDeviceToHost));
+    prof.stop(TP_QERROR);
     if (obj) obj[it] = (float)(acc / (double)n);
     // update R (src/OPQ.jl:112-113): G = X CB' on the device, polar factor on the host
-    RQ_TRY(gram_launch(dG.as<float>(), dX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr));
-    RQ_HIP(hipMemcpy(Gf.data(), dG.p, (size_t)d * d * 4, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < Gf.size(); ++i) G[i] = Gf[i];
-    polar_factor(G.data(), P.data(), d, &Vwarm);       // P = U V' = Julia's R
-    for (int i = 0; i < d; ++i)
-      for (int k = 0; k < d; ++k) Rh[(size_t)i * d + k] = (float)P[(size_t)k * d + i];
-    RQ_HIP(hipMemcpy(dR.p, Rh.data(), (size_t)d * d * 4, hipMemcpyHostToDevice));
-    RQ_TRY(rotate_launch(dRX.as<float>(), dR.as<float>(), dX.as<float>(), d, n, di.num_cu, nullptr));
-    RQ_TRY(update_centers_launch(dC.as<float>(), dcnt.as<unsigned int>(), dRX.as<float>(), dcodes.as<uint8_t>(), n, d,
-                                 m, h, di.num_cu, nullptr));
-    RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dRX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
-    RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr));
+    RQ_PH(TP_GRAM, RQ_TRY(gram_launch(dG.as<float>(), dX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr)));
+    prof.start();
+    int pstat = 1;
+    if (dev_polar) {
+      RQ_TRY(polar_factor_launch(dR.as<float>(), dG.as<float>(), dVw.as<double>(), dev_warm ? 1 : 0, d, dstat.as<int>(),
+                                 dscr.as<double>(), nullptr));
+      int st2[2] = {1, 0};
+      RQ_HIP(hipMemcpy(st2, dstat.p, 8, hipMemcpyDeviceToHost));
+      pstat = st2[0];
+      g_train_prof[TP_SWEEPS] += st2[1];
+      dev_warm = pstat == 0;
+    }
+    if (pstat != 0) {
+      RQ_HIP(hipMemcpy(Gf.data(), dG.p, (size_t)d * d * 4, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < Gf.size(); ++i) G[i] = Gf[i];
+      polar_factor(G.data(), P.data(), d, &Vwarm);       // P = U V' = Julia's R
+      for (int i = 0; i < d; ++i)
+        for (int k = 0; k < d; ++k) Rh[(size_t)i * d + k] = (float)P[(size_t)k * d + i];
+      RQ_HIP(hipMemcpy(dR.p, Rh.data(), (size_t)d * d * 4, hipMemcpyHostToDevice));
+    }
+    prof.stop(TP_SVD);
+    RQ_PH(TP_ROTATE, RQ_TRY(rotate_launch(dRX.as<float>(), dR.as<float>(), dX.as<float>(), d, n, di.num_cu, nullptr)));
+    RQ_PH(TP_CENTERS, RQ_TRY(update_centers_launch(dC.as<float>(), dcnt.as<unsigned int>(), dRX.as<float>(), dcodes.as<uint8_t>(), n, d,
+                                 m, h, di.num_cu, nullptr)));
+    RQ_PH(TP_ENCODE, RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dRX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr)));
+    RQ_PH(TP_RECONSTRUCT, RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr)));
   }
+  prof.loop_end(niter + 1);
   RQ_TRY(widen_codes_launch(d16.as<int16_t>(), dcodes.as<uint8_t>(), n * m, nullptr));
   RQ_HIP(hipDeviceSynchronize());
+  prof.start();
   RQ_HIP(hipMemcpy(C, dC.p, (size_t)h * d * 4, hipMemcpyDeviceToHost));
   RQ_HIP(hipMemcpy(B1, d16.p, (size_t)n * m * 2, hipMemcpyDeviceToHost));
-  memcpy(R, Rh.data(), sizeof(float) * d * d);
+  RQ_HIP(hipMemcpy(R, dR.p, sizeof(float) * d * d, hipMemcpyDeviceToHost));     // (the device copy is the current R on both paths)
+  prof.stop(TP_D2H);
+  return RQ_OK;
+}
+
+// Phase clock of the calling thread's last rq_train_pq / rq_train_opq call, milliseconds:
+//   [0] X upload  [1] initialisation (seeding / first rotation + encode)  [2] qerror  [3] gram X'CB  [4] host SVD incl. its
+//   two small copies  [5] rotation  [6] update_centers  [7] encode  [8] reconstruct  [9] convergence check  [10] results D2H
+//   [11] wall time of the iteration loop  [12] iterations run.  [2]-[9] are filled with tuning TRAIN_PROFILE = 1 only.
+int rq_train_profile(double *out, int cap) {
+  if (!out || cap < 1) return fail(RQ_EINVAL, "rq_train_profile: bad arguments");
+  for (int i = 0; i < cap && i < TP_SLOTS; ++i) out[i] = g_train_prof[i];
   return RQ_OK;
 }
 
