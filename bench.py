@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-ref1", action="store_true", help="skip the single-GPU timing of the N > 1 workload (N > 1: same_workload_1gpu; default N = 1 run: scale_anchor_1gpu)")
     ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (PCIe-inclusive) timing")
+    ap.add_argument("--no-ab", action="store_true", help="skip the prepared-base / arrival-order comparison runs (profiling: every "
+                    "scan launch of the run is then the headline's kernel on ordered rows)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -377,6 +379,12 @@ def main():
 
         def scan():
             res["r"] = ix_lib.search(Qh, K, R=Rh, id_base=0)
+    elif world == 1 and big:
+        # BASELINE config 5 on one GPU: the same resident, once-ordered shard object the N > 1 ranks hold (world size 1)
+        ix = ShardedIndex(codes, centers, id_offset=0)
+
+        def scan():
+            res["r"] = ix.search(Qs, K)
     elif world == 1:
         out = (torch.empty((nq, K), dtype=torch.float32, device=device),
                torch.empty((nq, K), dtype=torch.int32, device=device))
@@ -407,10 +415,15 @@ def main():
         kl = min(K, n_local)
         kout = torch.empty((nq, kl), dtype=torch.int64, device=device)
         ks = max(2, min(a.steps, 10))
-        ordered = rqd.order_rows(codes) if os.environ.get("RQ_SCAN_ORDER", "1") != "0" else codes
+        if world == 1 and big and ix.ordered is not None:
+            ordered = ix.ordered
+        elif world > 1 and ix.ordered is not None:
+            ordered = ix.ordered
+        else:
+            ordered = rqd.order_rows(codes) if os.environ.get("RQ_SCAN_ORDER", "1") != "0" else codes
         kern_total, _ = timed(lambda: rqd.linscan(ordered, centers, Qs, kl, id_offset=r0, want_keys=True, out=kout), ks, 1, barrier)
         kern_ms = kern_total / ks
-        if world == 1 and ordered is not codes:
+        if world == 1 and not big and ordered is not codes and not a.no_ab:
             # the three ways to run the same scan, same answer bit for bit (checked below):
             #   in_call   = the headline (`value`): arrival-order codes in, ordering inside every call
             #   prepared  = the base ordered once (index handle / rq_dev_order_rows), searches pay nothing for it
@@ -713,7 +726,8 @@ def main():
         "recall": recall,
         "checks": checks,
         "host_path": host,
-        "row_order": order_info if world == 1 else ({"index_prepare_ms": round(ix.order_ms, 3)} if (world > 1 and ix.order_ms is not None) else None),
+        "row_order": order_info if (world == 1 and not big) else
+                     ({"index_prepare_ms_once": round(ix.order_ms, 3)} if (not a.inproc and ix.order_ms is not None) else None),
         "same_workload_1gpu": ref1,
         "scale_anchor_1gpu": anchor,
         "wall_ms_per_step": round(scan_wall / a.steps, 4),

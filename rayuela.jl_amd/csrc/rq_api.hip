@@ -346,10 +346,16 @@ struct Timer {
 };
 
 // ---- bank-aware row order of a resident base (rq_order.hip) ---------------------------------------------
-bool order_pays(int64_t n, int64_t nq) {
+// Does ordering a scratch copy of the base INSIDE a call pay?  From ORDER_MIN_NQ queries on (the four small kernels cost
+// ~0.1 ms per 1e6 rows, the scan gains ~0.15 us per query group and 1e6 rows) and below ORDER_MAX_K neighbours: at
+// k = 10000 a fifth of the rows reach the exact evaluation and 44 % of the time is the per-query sample sort -- the table
+// gathers no longer bound the kernel (measured: 5.73 ms in arrival order, 5.74 prepared, 5.84 with the ordering inside).
+// k <= 0: a base prepared once (index handles, rq_dev_order_rows) -- ordered whenever it is large enough.
+bool order_pays(int64_t n, int64_t nq, int k) {
   const int mode = tuning("SCAN_ORDER", 1);
   if (mode <= 0 || n < tuning("ORDER_MIN_ROWS", 65536)) return false;
-  return mode > 1 || nq >= tuning("ORDER_MIN_NQ", 2048);
+  if (mode > 1 || k <= 0) return true;
+  return nq >= tuning("ORDER_MIN_NQ", 2048) && k < tuning("ORDER_MAX_K", 8192);
 }
 
 size_t order_base_bytes(int64_t n, int mp) { return (((size_t)n * mp + 255) & ~(size_t)255) + (size_t)n * 4; }
@@ -407,7 +413,7 @@ int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *code
   // (order_base: index handles, rq_dev_order_rows, the host-pointer calls).  Otherwise the call orders a copy itself when
   // that pays: the four small kernels cost ~40 us at 1e6 rows, a scan of nq queries gains ~15 % of its time -- from
   // ORDER_MIN_NQ (2048) queries on.  LSQ scans index row_bias / norm bytes by position and keep the arrival order.
-  if (!perm && !row_bias && order_pays(n, nq)) {
+  if (!perm && !row_bias && order_pays(n, nq, k)) {
     void *ord = nullptr;
     RQ_TRY(workspace(WS_ORDER, order_base_bytes(n, mp), &ord, stream));
     RQ_TRY(order_base(&codes, &perm, ord, codes, n, mp, stream));
@@ -569,7 +575,7 @@ static int host_linscan(float *dists, uint32_t *ids, const uint8_t *codes, const
   // widths are padded per chunk scan and ordered there)
   const uint32_t *perm = nullptr;
   DevBuf dord;
-  if (scan_padded_m(m) == m && order_pays(n, nq)) {
+  if (scan_padded_m(m) == m && order_pays(n, nq, k)) {
     RQ_TRY(dord.alloc(order_base_bytes(n, m)));
     RQ_TRY(order_base(&cdev, &perm, dord.p, cdev, n, m, nullptr));
   }

@@ -317,7 +317,7 @@ static int index_set(rq_index *ix, int64_t n, uint32_t id_offset, Fill fill) {
     // The base is resident for many searches: put its rows in bank-aware order ONCE (rq_order.hip; the scan's table gathers
     // then hit distinct LDS columns, keys still carry the original row numbers through perm).  Rows of a tiled width only;
     // other widths are padded and ordered per search.  Costs 4 bytes per row for perm; the arrival-order copy is freed.
-    if (tuning("INDEX_ORDER", 1) && scan_padded_m(ix->m) == ix->m && order_pays(s.n, 1 << 30)) {
+    if (tuning("INDEX_ORDER", 1) && scan_padded_m(ix->m) == ix->m && order_pays(s.n, 0, 0)) {
       DeviceLock order_lock;      // scratch lookup + launches of this device, like a scan
       void *ord = nullptr;
       RQ_HIP(hipMalloc(&ord, order_base_bytes(s.n, ix->m)));

@@ -101,7 +101,7 @@ int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *code
                 const float *queries, int64_t n, int64_t nq, int m, int d, int k, uint32_t id_offset,
                 int id_base, hipStream_t stream, int lut_mode = LUT_PQ, const float *row_bias = nullptr,
                 const ScanBase *base = nullptr);
-bool order_pays(int64_t n, int64_t nq);                                 // SCAN_ORDER / ORDER_MIN_ROWS / ORDER_MIN_NQ
+bool order_pays(int64_t n, int64_t nq, int k);                          // SCAN_ORDER / ORDER_MIN_ROWS / ORDER_MIN_NQ / ORDER_MAX_K
 size_t order_base_bytes(int64_t n, int mp);
 int order_base(const uint8_t **out_codes, const uint32_t **out_perm, void *dst, const uint8_t *codes, int64_t n, int mp,
                hipStream_t stream);

@@ -11,12 +11,12 @@ import re
 import shutil
 import sys
 
-RND = sys.argv[1] if len(sys.argv) > 1 else "r3"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r4"
 O = "gpurun_out/" + RND
-for f in ("bench_pq", "bench_opq", "bench_deep", "bench_pq_k10000", "bench_sift1b_1gpu", "bench_sift1b_shard", "bench_sift1b_inproc"):
+for f in ("bench_pq", "bench_opq", "bench_deep", "bench_pq_k10000", "bench_sift1b_1gpu", "bench_sift1b_shard", "bench_sift1b_inproc", "bench_train_opq", "bench_train_pq"):
     if os.path.exists("%s/%s.json" % (O, f)):
         open("profiles/%s_%s.json" % (RND, f), "w").write(open("%s/%s.json" % (O, f)).read().strip().splitlines()[-1] + "\n")
-for w in ("pq", "opq", "deep", "k10000", "sift1b", "sift1b_shard"):
+for w in ("pq", "opq", "deep", "k10000", "sift1b", "sift1b_shard", "train_opq"):
     g = glob.glob("%s/stats_%s/**/s_kernel_stats.csv" % (O, w), recursive=True)
     if not g:
         continue
