@@ -331,6 +331,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
 #pragma unroll
       for (int q = 0; q < QG; ++q) tau[q] = ctrl->tau[q];
       const uint32_t selmask = __builtin_amdgcn_readfirstlane(ctrl->selmask);
+      const bool full_blk = __builtin_amdgcn_readfirstlane((uint32_t)(base + (uint32_t)BLK <= r_end)) != 0u;
 
       // (norm-adding kernels with 32 gathers per row: one sub-step at a time -- with all U code words live next to a row's
       // 64 + 32 registers of table entries the allocator spilled the code words themselves, 160 registers in all)
@@ -398,16 +399,16 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
       if (filt_on) {
         filtered = true;
         uint32_t npush = 0;      // wave-uniform: rows this wavefront queued in this block
+        uint32_t amask = 0;      // per lane: bit (u * RPT + r) = row r of sub-step u may still beat a threshold
+        static_assert(UCH * RPT <= 31, "one alive bit per row of a chunk");
         asm volatile("; RQ_FILTER_LOOP_BEGIN" ::: "memory");     // markers for tests/test_isa.py (no instructions)
         // ---- pre-filter: byte lower bounds for the 8 queries, 8 bytes per gather; rows that may still beat a
         // threshold are queued for the exact evaluation, which runs 64 queued rows at a time
 #pragma unroll
         for (int u = 0; u < UCH; ++u) {
           const uint32_t *w = wu[u];
-          const uint32_t row0 = base + (uint32_t)(uc + u) * Cfg::SUB + (uint32_t)tid * RPT;
           // all RPT * M gathers of the sub-step are issued before the first sum (16 x ds_read_b64 / 32 x ds_read_b32)
           using FV = typename FiltVec<M>::type;
-          const FV *qt = reinterpret_cast<const FV *>(qtab);
           static_assert(sizeof(FV) == 8, "byte tables: 8 queries per ds_read_b64");
           const uint32_t shreg = 3u;
           // gathers in flight together: 16 (M = 8: both rows of the sub-step; M = 16: one row -- 32 of them with
@@ -463,30 +464,44 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
 #pragma unroll
               for (int j = 0; j < Cfg::NQUAD; ++j) a[(Cfg::NACC - 1) * Cfg::NQUAD + j] += fv_word(en[r], j);
             }
-            const bool cand = filt_alive<M, FINE>(a) && (row0 + r < r_end);
-            const uint64_t mq = __ballot(cand);
-            if (mq) {
-              if (cand) myq[qtail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u))] = row0 + r;
-              qtail += (uint32_t)__popcll(mq);
-              npush += (uint32_t)__popcll(mq);
-            }
-            if constexpr (FILT_QCAP < 64u * (RPT + 1)) {     // small queue: make room after every row
-              while (qtail >= 64u) {
-                RQ_REFINE(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - 64u), 64u);
-                qtail -= 64u;
-              }
-            }
+            // one bit per row of the chunk in a per-lane mask: the rows are queued once per chunk below (a ballot + prefix
+            // count + LDS store per ROW cost ~11 VALU instructions, a fifth of the loop's VALU time -- and with 5 % of the
+            // rows alive almost every ballot of 64 rows finds somebody)
+            amask |= filt_alive<M, FINE>(a) ? (1u << (u * RPT + r)) : 0u;
           }
           __builtin_amdgcn_sched_barrier(0);
           }  // gather batches
-          if (qtail >= 64u) {      // at most RPT * 64 rows were pushed since the last check: qtail < 64 * (RPT + 1) <= FILT_QCAP
-            // (two 64-row batches per call would overlap the call's dependent latencies -- ~2 us for queue -> code
-            // bytes -> table gathers -- but the larger callee makes every call save more registers: 3.64 -> 4.16 ms)
-            // (timing this call with clock64 costs two live VGPRs here, which spilled the code words of the block)
-            do {
+        }
+        asm volatile("; RQ_FILTER_LOOP_END" ::: "memory");
+        if (!full_blk) {          // rows behind the slice's end (only a slice's last block is ragged)
+#pragma unroll
+          for (int u = 0; u < UCH; ++u) {
+            const uint32_t row0 = base + (uint32_t)(uc + u) * Cfg::SUB + (uint32_t)tid * RPT;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+              if (!(row0 + r < r_end)) amask &= ~(1u << (u * RPT + r));
+          }
+        }
+        // queue the alive rows: every lane hands over one row per round (at most 64 per round, so the queue -- which is
+        // drained whenever 64 rows wait -- never holds more than 127 <= FILT_QCAP); 1-4 rounds per chunk of 16 rows
+        {
+          const uint32_t rowt = base + (uint32_t)uc * Cfg::SUB + (uint32_t)tid * RPT;
+          for (;;) {
+            const bool has = amask != 0u;
+            const uint64_t mq = __builtin_amdgcn_ballot_w64(has);
+            if (!mq) break;
+            const uint32_t b = (uint32_t)__builtin_ctz(amask | 0x80000000u);
+            amask &= amask - 1u;
+            if (has) myq[qtail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u))] =
+                rowt + (b / (uint32_t)RPT) * (uint32_t)Cfg::SUB + (b % (uint32_t)RPT);
+            qtail += (uint32_t)__popcll(mq);
+            npush += (uint32_t)__popcll(mq);
+            if (qtail >= 64u) {
+              // (two 64-row batches per call would overlap the call's dependent latencies -- ~2 us for queue -> code
+              // bytes -> table gathers -- but the larger callee makes every call save more registers: 3.64 -> 4.16 ms)
               RQ_REFINE(ctrl, cand_wg, p.codes, p.row_bias, p.id_offset, p.cap, lut4, gtab, myq + (qtail - 64u), 64u);
               qtail -= 64u;
-            } while (qtail >= 64u);
+            }
           }
         }
         asm volatile("; RQ_FILTER_LOOP_END" ::: "memory");
