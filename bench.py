@@ -469,8 +469,10 @@ def main():
         enc_flops = 2.0 * d * h * n_local           # per GPU
         tf = enc_flops / (enc_ms_step * 1e-3) / 1e12
         sub_w = d // m
-        split = (d % m == 0) and sub_w % 2 == 0 and sub_w <= 16 and os.environ.get("RQ_ENC_SPLIT", "1") != "0"
-        enc_roof = {"bound": "mfma", "kernel": "encode_pq_split_kernel" if split else "encode_pq_direct_kernel",
+        from rayuela_jl_amd import _lib as _l
+        enc_kernel = (_l.lib().rq_last_encode_kernel() or b"").decode() or "?"      # what the library actually launched
+        split = enc_kernel == "encode_pq_split_kernel"
+        enc_roof = {"bound": "mfma", "kernel": enc_kernel,
                     "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
                     "hbm_GBps": round((4.0 * d + m) * n_local / (enc_ms_step * 1e-3) / 1e9, 1),

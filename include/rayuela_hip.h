@@ -156,6 +156,9 @@ int rq_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n);
 int rq_dev_encode_pq(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m,
                      int h, void *stream);
 int rq_dev_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n, void *stream);
+/* Name of the kernel the calling thread's last encode call ran ("encode_pq_split_kernel", "encode_pq_direct_kernel", ...):
+ * bench.py labels its encode roofline with it instead of guessing from the tuning. */
+const char *rq_last_encode_kernel(void);
 /* Test aid (no reference counterpart): rq_dev_encode_pq through the split kernel (even sub-space widths <= 16), which also
  * stores the values its bf16 matrix-core FILTER decides on: W [n][m][h], W_k = |c_k|^2 - 2 <c_k, x> as the MFMAs produced it.
  * tests/test_gpu_encode_margin.py measures |(W_k + |x|^2) - v_k| against the bound the kernel's exactness rests on. */

@@ -1114,6 +1114,8 @@ int rq_dev_encode_pq_filter_w(uint8_t *codes, float *W, const float *X, const fl
   return encode_launch(codes, X, C, n, d, m, h, di.num_cu, (hipStream_t)stream, W);
 }
 
+const char *rq_last_encode_kernel(void) { return last_encode_kernel_name(); }
+
 int rq_dev_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n, void *stream) {
   DeviceInfo di;
   RQ_TRY(device_info(&di));

@@ -410,10 +410,14 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_direct_kernel(EncParams
 //        dropped terms  2 (xl cl + xh ec + xl ec + ex c)   <= 6.2 * 2^-16 S        <= 2^-14.4 (sa_k + sb)
 //        f32 accumulation of <= 49 terms inside the MFMA    <= 49 * 2^-23 (sa + 2S) <= 2^-16.3 (sa_k + sb)
 //        canonical u_k (fmaf chains, two roundings) vs the real value               <= 2^-18.7 (sa_k + sb)
-//     so |(W_k + sb) - u_k| <= e_k := 2^-14 (sa_k + sb), clamp included (a clamped u_k has real value <= its own error).
+//     so |(W_k + sb) - u_k| <= e_k := 1.02 * 2^-14 (sa_k + sb), clamp included (a clamped u_k has real value <= its own
+//     error).  (The three terms add up to 1.015 * 2^-14; the accumulation term assumes <= 1 ulp per add inside the MFMA.
+//     MEASURED on the kernel's own W values, tests/test_gpu_encode_margin.py: <= 0.46 * 2^-14 on hostile inputs, 0.05 / 0.36
+//     on the 2e9 / 4e9 values of the SIFT / Deep bench shapes.)
 //  2. If k* is the canonical argmin then W_k* <= W_k + e_k* + e_k for every k, so k* -- and every k that ties with it --
-//     satisfies  W_k <= min_k W + DELTA,  DELTA = 3 * 2^-14 (max_k sa_k + sb)   (1.5x the bound, for the f32 roundings of
-//     the threshold itself).  Per lane the kernel keeps the running minimum b1, a copy of the 16 W values of the tile
+//     satisfies  W_k <= min_k W + DELTA,  DELTA = 3 * 2^-14 (max_k sa_k + sb)   (needed: 2 e_k = 2.04 * 2^-14; the rest covers
+//     the f32 roundings of the threshold itself.  Walking DELTA down -- tuning ENC_SPLIT_DELTA_MILLI -- codes first change
+//     at 0.023 / 0.047 * 2^-14 on the bench shapes: 130x / 64x below the shipped value).  Per lane the kernel keeps the running minimum b1, a copy of the 16 W values of the tile
 //     that holds it, and a bit mask of the tiles that came within DELTA of the running minimum at the time (a superset of
 //     the tiles within DELTA of the final one).
 //  3. REFINE: the candidates {W_k <= b1 + DELTA} -- 1.02 per vector on SIFT-like, 1.005 on Deep-like data -- get the
@@ -1314,6 +1318,17 @@ static int launch_encode_split(EncParams p, int num_cu, hipStream_t stream) {
   return RQ_OK;
 }
 
+static thread_local int g_last_encode_kernel = 0;      // 1 split, 2 f32-MFMA direct (X in registers), 3 f32-MFMA LDS-staged, 4 wide
+const char *last_encode_kernel_name() {
+  switch (g_last_encode_kernel) {
+    case 1: return "encode_pq_split_kernel";
+    case 2: return "encode_pq_direct_kernel";
+    case 3: return "encode_pq_kernel";
+    case 4: return "encode_wide_kernel";
+    default: return "";
+  }
+}
+
 int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m, int h,
                   int num_cu, hipStream_t stream, float *dbg_w) {
   if (n <= 0) return RQ_OK;
@@ -1344,6 +1359,7 @@ int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int
     const int sw = tuning("ENC_SPLIT_WAVES", 0);
 #define RQ_SPLIT_NT(SUBV, NW)                                                        \
   do {                                                                               \
+    g_last_encode_kernel = 1;                                                        \
     if (nt <= 1) return launch_encode_split<SUBV, 1, NW>(p, num_cu, stream);           \
     if (nt <= 2) return launch_encode_split<SUBV, 2, NW>(p, num_cu, stream);           \
     if (nt <= 4) return launch_encode_split<SUBV, 4, NW>(p, num_cu, stream);           \
@@ -1363,6 +1379,7 @@ int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int
   if (dbg_w) return fail(RQ_EUNSUPPORTED, "the filter's W values exist for the split kernel only (even sub-space widths <= 16)");
 #define RQ_ENC_NT(KSV, NW, DIR)                                             \
   do {                                                                     \
+    g_last_encode_kernel = DIR ? 2 : 3;                                    \
     if (nt <= 1) return launch_encode<KSV, 1, NW, DIR>(p, num_cu, stream);  \
     if (nt <= 2) return launch_encode<KSV, 2, NW, DIR>(p, num_cu, stream);  \
     if (nt <= 4) return launch_encode<KSV, 4, NW, DIR>(p, num_cu, stream);  \
@@ -1398,6 +1415,7 @@ int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int
 #undef RQ_ENC_NT
 #undef RQ_ENC_CASE
   // any other width: chunked kernel, codebook streamed through LDS
+  g_last_encode_kernel = 4;
   if (nt <= 1) return launch_encode_wide<1>(p, num_cu, stream);
   if (nt <= 2) return launch_encode_wide<2>(p, num_cu, stream);
   if (nt <= 4) return launch_encode_wide<4>(p, num_cu, stream);

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
             ctrl->pad[0] = x;
             const uint32_t before = (j / p.xcd_round) * p.xcd_round;                   // items of the earlier rounds
             const uint32_t need = before > p.xcd_slack ? before - p.xcd_slack : 0u;
-            for (uint32_t spin = 0; spin < (1u << 18); ++spin) {
+            for (uint32_t spin = 0; spin < (1u << 10); ++spin) {      // bounded: ~2 ms at most, then the item starts anyway
               if (__hip_atomic_load(p.work_counter + 8u + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
               __builtin_amdgcn_s_sleep(64);
             }
@@ -862,12 +862,16 @@ static void plan_for(ScanPlan &pl, int64_t n, int64_t nq, int d, int K, int num_
   // large enough that the per-item work (tables, threshold sample, final select + sort) stays around one percent.  Bounds: the per-slice
   // key lists (nq * ns * K * 8 bytes) stay below 1 GiB and a query's merge below 2^20 keys.
   pl.xcd = false;
-  if (force_slices <= 0 && tail_ns <= 0 && tuning("SCAN_XCD", 1) &&
+  // the window hand-out and its pacing are written for the 8 XCDs x 32 CUs of an MI355X in SPX mode (xcd & 7, grid / 8); a
+  // partitioned device (CPX / DPX: fewer XCDs behind one agent) takes the plain planner -- results are the same either way
+  const bool eight_xcds = num_cu == 256 || tuning("SCAN_XCD", 1) > 1;
+  if (force_slices <= 0 && tail_ns <= 0 && tuning("SCAN_XCD", 1) && eight_xcds &&
       (int64_t)n * M >= ((int64_t)(tuning("SCAN_XCD_MIN_MB", 0) > 0 ? tuning("SCAN_XCD_MIN_MB", 0) : 128) << 20)) {
     int64_t wrows = ((int64_t)(tuning("SCAN_WINDOW_MB", 0) > 0 ? tuning("SCAN_WINDOW_MB", 0) : 32) << 20) / M;
     wrows = std::max<int64_t>(wrows, min_rows);
     int64_t nw = (n + wrows - 1) / wrows;
-    const int64_t cap_part = ((int64_t)1 << 30) / std::max<int64_t>(1, nq * (int64_t)K * 8);
+    // per-window key lists: at most 256 MB of scratch per (device, stream) (1 GiB x 8 streams was ~10 GiB hidden)
+    const int64_t cap_part = ((int64_t)256 << 20) / std::max<int64_t>(1, nq * (int64_t)K * 8);
     const int64_t cap_merge = ((int64_t)1 << 20) / std::max(1, K);
     nw = std::min(nw, std::min(cap_part, cap_merge));
     if (nw >= 16) { ns = nw; whole = 0; pl.xcd = true; }
