@@ -207,6 +207,42 @@ function linscan_lsq(B::Matrix{T}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat}},
 end
 
 """
+    HipLsqIndex(B, C, dbnorms)  /  search(ix, X, R, k=10000) -> dists, idx
+linscan_lsq over a PREPARED base (rq_lsq_prepare / rq_lsq_search / rq_lsq_release): codes, dbnorms and codebooks stay on the
+device together with the pre-filter's O(n) pass over the base, which `linscan_lsq` repeats on every call.  `search` returns
+exactly what `linscan_lsq(B, X, C, dbnorms, R, k)` returns (one-based `idx`).
+"""
+mutable struct HipLsqIndex
+  handle::Ptr{Cvoid}
+  n::Int
+  m::Int
+  d::Int
+  function HipLsqIndex(B::Matrix{UInt8}, C::Vector{Matrix{Cfloat}}, dbnorms::Vector{Cfloat})
+    m, n = size(B)
+    d, h = size(C[1])
+    hd = ccall((:rq_lsq_prepare, librayuela_hip), Ptr{Cvoid},
+               (Ptr{Cuchar}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cint, Cint, Cint),
+               B, hcat(C...), dbnorms, Int64(n), Cint(m), Cint(h), Cint(d))
+    hd == C_NULL && error("rq_lsq_prepare: " * unsafe_string(ccall((:rq_last_error, librayuela_hip), Cstring, ())))
+    ix = new(hd, n, m, d)
+    finalizer(x -> (x.handle != C_NULL && ccall((:rq_lsq_release, librayuela_hip), Cvoid, (Ptr{Cvoid},), x.handle); x.handle = C_NULL), ix)
+    return ix
+  end
+end
+HipLsqIndex(B::Matrix{T}, C::Vector{Matrix{Cfloat}}, dbnorms::Vector{Cfloat}) where T <: Integer =
+  HipLsqIndex(convert(Matrix{UInt8}, B .- 1), C, dbnorms)
+
+function search(ix::HipLsqIndex, X::Matrix{Cfloat}, R::Matrix{Cfloat}, k::Int=10000)
+  d, nq = size(X)
+  dists = _result(Cfloat, k, nq)
+  res   = _result(Cuint,  k, nq)
+  _check(ccall((:rq_lsq_search, librayuela_hip), Cint,
+    (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cuint}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cint, Cint),
+    ix.handle, dists, res, X, R, Int64(nq), Cint(k), Cint(1)))
+  return dists, res
+end
+
+"""
     linscan_cq(B, X, C, k=10000) -> dists, idx     (src/Linscan.jl:160-193)
 """
 function linscan_cq(B::Matrix{UInt8}, X::Matrix{Cfloat}, C::Vector{Matrix{Cfloat}}, k::Int=10000)
