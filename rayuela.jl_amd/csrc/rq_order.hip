@@ -145,6 +145,122 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(OrderParams p) {
   }
 }
 
+// ---- small bases (the ordering INSIDE a call): two levels, LDS histograms, 2 x 256 global atomics per workgroup ----------
+// The one-level path above pays one returning device-scope atomic per row (1e6 rows: 48 us of its 100) and four launches.
+// For keys of <= 18 bits the same order comes from a coarse level of 256 buckets (the key's top 8 bits) and a fine level
+// inside each bucket:
+//   order_coarse_count   per workgroup chunk: LDS histogram of the coarse byte -> ctot[256] (non-returning atomics)
+//   order_coarse_scatter the chunk's rows reserve ranges of their coarse buckets (one returning atomic per workgroup and
+//                        non-empty bucket) and write their ROW NUMBERS there
+//   order_fine           one workgroup per coarse bucket: LDS counting sort of its rows by the remaining <= 10 key bits,
+//                        rows dealt to their final positions (order_deal), perm written
+constexpr int ORDER_COARSE = 256, ORDER_FINE_MAX = 1024, ORDER_SMALL_THREADS = 1024;
+
+struct OrderSmall {
+  uint32_t *ctot;        // [256] rows per coarse bucket, then [256] cursors
+  uint32_t *idx;         // [n] row numbers grouped by coarse bucket
+  uint32_t rows_per_wg;
+  int fine_bits;
+};
+
+__device__ __forceinline__ void coarse_starts(uint32_t *starts /*LDS [257]*/, const uint32_t *ctot) {
+  // exclusive scan of the 256 bucket sizes by the first 256 threads (4 wavefronts + their sums)
+  __shared__ uint32_t wsum[4];
+  const uint32_t tid = threadIdx.x;
+  uint32_t v = 0, x = 0;
+  if (tid < ORDER_COARSE) {
+    v = ctot[tid];
+    x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off);
+      if ((tid & 63u) >= (uint32_t)off) x += y;
+    }
+    if ((tid & 63u) == 63u) wsum[tid >> 6] = x;
+  }
+  __syncthreads();
+  if (tid < ORDER_COARSE) {
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    starts[tid] = base + x - v;
+    if (tid == ORDER_COARSE - 1) starts[ORDER_COARSE] = base + x;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(ORDER_SMALL_THREADS) void order_coarse_count_kernel(OrderParams p, OrderSmall q) {
+  __shared__ uint32_t h[ORDER_COARSE];
+  const uint32_t tid = threadIdx.x;
+  if (tid < ORDER_COARSE) h[tid] = 0;
+  __syncthreads();
+  const uint32_t r0 = blockIdx.x * q.rows_per_wg, r1 = min(p.n, r0 + q.rows_per_wg);
+  for (uint32_t i = r0 + tid; i < r1; i += ORDER_SMALL_THREADS) atomicAdd(&h[order_key_of(p, i) >> q.fine_bits], 1u);
+  __syncthreads();
+  if (tid < ORDER_COARSE && h[tid]) atomicAdd(&q.ctot[tid], h[tid]);
+}
+
+__global__ __launch_bounds__(ORDER_SMALL_THREADS) void order_coarse_scatter_kernel(OrderParams p, OrderSmall q) {
+  __shared__ uint32_t h[ORDER_COARSE], base[ORDER_COARSE], starts[ORDER_COARSE + 1];
+  const uint32_t tid = threadIdx.x;
+  if (tid < ORDER_COARSE) h[tid] = 0;
+  coarse_starts(starts, q.ctot);
+  const uint32_t r0 = blockIdx.x * q.rows_per_wg, r1 = min(p.n, r0 + q.rows_per_wg);
+  // local rank inside (chunk, bucket), then one global reservation per non-empty bucket
+  constexpr int PER = 4;                       // rows_per_wg == PER * threads
+  uint32_t c[PER], lr[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const uint32_t i = r0 + u * ORDER_SMALL_THREADS + tid;
+    if (i < r1) { c[u] = order_key_of(p, i) >> q.fine_bits; lr[u] = atomicAdd(&h[c[u]], 1u); }
+  }
+  __syncthreads();
+  if (tid < ORDER_COARSE && h[tid]) base[tid] = starts[tid] + atomicAdd(&q.ctot[ORDER_COARSE + tid], h[tid]);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const uint32_t i = r0 + u * ORDER_SMALL_THREADS + tid;
+    if (i < r1) q.idx[base[c[u]] + lr[u]] = i;
+  }
+}
+
+__global__ __launch_bounds__(ORDER_SMALL_THREADS) void order_fine_kernel(OrderParams p, OrderSmall q) {
+  __shared__ uint32_t f[ORDER_FINE_MAX], starts[ORDER_COARSE + 1], wsum[16];
+  const uint32_t tid = threadIdx.x, nfine = 1u << q.fine_bits, fmask = nfine - 1u;
+  for (uint32_t i = tid; i < nfine; i += ORDER_SMALL_THREADS) f[i] = 0;
+  coarse_starts(starts, q.ctot);
+  const uint32_t b0 = starts[blockIdx.x], b1 = starts[blockIdx.x + 1];
+  for (uint32_t i = b0 + tid; i < b1; i += ORDER_SMALL_THREADS) atomicAdd(&f[order_key_of(p, q.idx[i]) & fmask], 1u);
+  __syncthreads();
+  {   // exclusive scan of the <= 1024 fine counts: one per thread
+    const uint32_t v = tid < nfine ? f[tid] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off);
+      if ((tid & 63u) >= (uint32_t)off) x += y;
+    }
+    if ((tid & 63u) == 63u) wsum[tid >> 6] = x;
+    __syncthreads();
+    uint32_t wb = 0;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) wb += wsum[w];
+    if (tid < nfine) f[tid] = b0 + wb + x - v;        // the fine bucket's first sorted rank; walks to its end below
+    __syncthreads();
+  }
+  for (uint32_t i = b0 + tid; i < b1; i += ORDER_SMALL_THREADS) {
+    const uint32_t row = q.idx[i];
+    const uint32_t s = atomicAdd(&f[order_key_of(p, row) & fmask], 1u);
+    const uint32_t pos = order_deal(p, s);
+    const uint8_t *a = p.src + (size_t)row * p.mp;
+    uint8_t *b = p.dst + (size_t)pos * p.mp;
+    if (p.mp == 8) *reinterpret_cast<uint64_t *>(b) = *reinterpret_cast<const uint64_t *>(a);
+    else if (p.mp >= 16) {
+      for (int o = 0; o < p.mp; o += 16) *reinterpret_cast<uint4 *>(b + o) = *reinterpret_cast<const uint4 *>(a + o);
+    } else if (p.mp == 4) *reinterpret_cast<uint32_t *>(b) = *reinterpret_cast<const uint32_t *>(a);
+    else *reinterpret_cast<uint16_t *>(b) = *reinterpret_cast<const uint16_t *>(a);
+    p.perm[pos] = row;
+  }
+}
+
 static uint32_t gcd_u32(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
 
 // Key layout for n rows of mp bytes: `cbits` bits per leading code byte (the window 256 >> cbits = the bank columns one
@@ -196,6 +312,21 @@ int order_rows_launch(uint8_t *dst, uint32_t *perm, const uint8_t *src, int64_t 
     uint32_t a = (uint32_t)((double)p.ngran * 0.6180339887498949) | 1u;
     while (gcd_u32(a, p.ngran) != 1u) a += 2u;
     p.weyl = a % p.ngran;
+  }
+  if (total >= 9 && total <= 18 && tuning("ORDER_TWO_LEVEL", 1)) {
+    // two levels: 256 coarse buckets, <= 1024 fine ones inside each (scratch: [n] row numbers | 512 counters)
+    OrderSmall q;
+    q.idx = reinterpret_cast<uint32_t *>(scratch);
+    q.ctot = q.idx + n;
+    q.fine_bits = total - 8;
+    q.rows_per_wg = 4 * ORDER_SMALL_THREADS;       // (order_coarse_scatter_kernel: PER)
+    const uint32_t nwg = (uint32_t)((n + q.rows_per_wg - 1) / q.rows_per_wg);
+    RQ_HIP(hipMemsetAsync(q.ctot, 0, 2 * ORDER_COARSE * 4, stream));
+    hipLaunchKernelGGL(order_coarse_count_kernel, dim3(nwg), dim3(ORDER_SMALL_THREADS), 0, stream, p, q);
+    hipLaunchKernelGGL(order_coarse_scatter_kernel, dim3(nwg), dim3(ORDER_SMALL_THREADS), 0, stream, p, q);
+    hipLaunchKernelGGL(order_fine_kernel, dim3(ORDER_COARSE), dim3(ORDER_SMALL_THREADS), 0, stream, p, q);
+    RQ_HIP(hipGetLastError());
+    return RQ_OK;
   }
   const uint32_t ntiles = (p.nbins + ORDER_SCAN_TILE - 1) / ORDER_SCAN_TILE;
   RQ_HIP(hipMemsetAsync(p.hist, 0, (size_t)(p.nbins + ntiles) * 4, stream));

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(NT) void filt_kernel(const uint8_t *__restrict__ co
     constexpr int U = 2;
     for (uint32_t base = r_begin; base < r_end; base += NT * 2 * U) {
       uint4 wu[U];
+      uint32_t amask = 0; (void)amask;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t row0 = base + u * NT * 2 + tid * 2;
@@ -72,14 +73,30 @@ __global__ __launch_bounds__(NT) void filt_kernel(const uint8_t *__restrict__ co
             const uint32_t TC = (thr + 1u) * 0x01010101u;
             const uint32_t g0 = ((a0 | H) - TC) | a0, g1 = ((a1 | H) - TC) | a1;
             const bool cand = ((g0 & g1 & H) != H) && (row0 + r < r_end);
+#ifdef DEFER_PUSH
+            // round 4: one bit per (set, sub-step, row); the rows are queued once per block below
+            amask |= cand ? (1u << ((s * U + u) * 2 + r)) : 0u;
+#else
             const uint64_t mq = __ballot(cand);
             if (mq) {
               if (cand) myq[(qtail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u))) & 255u] = (row0 + r) | (s << 29);
               qtail += (uint32_t)__popcll(mq);
             }
+#endif
           }
         }
       }
+#ifdef DEFER_PUSH
+      for (;;) {
+        const bool has = amask != 0u;
+        const uint64_t mq = __builtin_amdgcn_ballot_w64(has);
+        if (!mq) break;
+        const uint32_t b = (uint32_t)__builtin_ctz(amask | 0x80000000u);
+        amask &= amask - 1u;
+        if (has) myq[(qtail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u))) & 255u] = base + b;
+        qtail += (uint32_t)__popcll(mq);
+      }
+#endif
     }
     alive_total += qtail;
   }
@@ -379,12 +396,15 @@ int main() {
   std::vector<uint8_t> hn((size_t)(nq / 16) * 8 * 256 * 8);
   for (auto &t : hn) t = (uint8_t)(((rand() >> 8) % 8) | (((rand() >> 8) % 8) << 4));   // nibble entries 0..7
   uint2 *ntabs; hipMalloc(&ntabs, hn.size()); hipMemcpy(ntabs, hn.data(), hn.size(), hipMemcpyHostToDevice);
-  const uint32_t thr = 62;   // ~ a few % of (row, set) pairs alive
+  const uint32_t thr = getenv("THR") ? atoi(getenv("THR")) : 62;   // ~ a few % of (row, set) pairs alive
   run<512, 8>(codes, tabs, n, nq, thr, 2);
   run<512, 8>(codes, tabs, n, nq, thr, 4);
   if (getenv("MICRO_QUICK")) {
     run<256, 8>(codes, tabs, n, nq, thr, 8);
     run<512, 16>(codes, tabs, n, nq, thr, 4);
+    run<512, 16>(codes, tabs, n, nq, thr, 2);
+    run<512, 32>(codes, tabs, n, nq, thr, 2);
+    if (getenv("MICRO_FILT_ONLY")) return 0;
     run_nib<512>(codes, tabs, n, nq, 40, 2);
     run_nib<512>(codes, tabs, n, nq, 40, 4);
     for (uint32_t tA : {9u, 13u}) { run_casc<512>(codes, tabs, ntabs, n, nq, tA, 62, 2); run_casc<512>(codes, tabs, ntabs, n, nq, tA, 62, 4); }
