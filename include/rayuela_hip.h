@@ -193,6 +193,9 @@ int rq_dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *c
  *                            for a base too small to order)
  *   rq_dev_linscan_ordered   rq_dev_linscan over such a pair: ids / keys carry ORIGINAL row numbers (+ id_offset)   */
 int rq_scan_row_width(int m);
+/* host-only (tests): the key of that order for n rows x m bytes -- out[0..7] bits per leading code byte, [8] total,
+ * [9] rows per lane group, [10] rows per shuffle granule, [11] padded row width; cap >= 12 */
+int rq_order_plan(int64_t n, int m, int *out, int cap);
 int64_t rq_order_bytes(int64_t n, int m);
 int rq_dev_order_rows(void *ordered, const uint8_t **codes_out, const uint32_t **perm_out, const uint8_t *codes,
                       int64_t n, int m, void *stream);

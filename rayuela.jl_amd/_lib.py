@@ -60,6 +60,7 @@ SIGNATURES = {
     "rq_dev_linscan": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _u32, _i32, _vp]),
     "rq_scan_row_width": (_i32, [_i32]),
     "rq_order_bytes": (_i64, [_i64, _i32]),
+    "rq_order_plan": (_i32, [_i64, _i32, _vp, _i32]),
     "rq_dev_order_rows": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "rq_dev_linscan_ordered": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _u32, _i32, _vp]),
     "rq_dev_merge_topk": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),

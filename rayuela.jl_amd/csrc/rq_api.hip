@@ -1215,6 +1215,21 @@ int rq_dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *c
 
 int rq_scan_row_width(int m) { return scan_padded_m(m); }
 
+// host-only: how a base of n rows x m bytes would be ordered -- out[0..7] key bits per leading code byte, [8] total bits,
+// [9] rows per lane group, [10] rows per shuffle granule, [11] padded row width (tests; no device needed)
+int rq_order_plan(int64_t n, int m, int *out, int cap) {
+  if (!out || cap < 12) return fail(RQ_EINVAL, "rq_order_plan: out needs 12 ints");
+  const int mp = scan_padded_m(m);
+  if (mp < 0) return fail(RQ_EUNSUPPORTED, "the ADC scan kernels cover 1 <= m <= 64 sub-quantizers; got m=%d", m);
+  OrderTiling ot;
+  scan_order_tiling(mp, &ot);
+  int nb[8];
+  const int total = order_key_bits(n, mp, ot, nb);
+  for (int c = 0; c < 8; ++c) out[c] = nb[c];
+  out[8] = total; out[9] = ot.group; out[10] = ot.gran; out[11] = mp;
+  return RQ_OK;
+}
+
 int64_t rq_order_bytes(int64_t n, int m) {
   const int mp = scan_padded_m(m);
   return (mp < 0 || n < 1) ? 0 : (int64_t)order_base_bytes(n, mp);

@@ -487,23 +487,20 @@ int gram_launch(float *G, const float *X, const float *CB, int64_t n, int d, int
 
 // ------------------------------------------------------------------------------------------
 // Polar factor  R = U V'  of the d x d matrix G = X CB'  (src/OPQ.jl:112-113: U, S, VV = svd(X * CB'); R = U * VV') on the
-// device: one-sided Jacobi SVD in double, ONE workgroup, the whole matrix in LDS (d <= 128, even: 128 KiB at d = 128).
-// Round 3 ran the same algorithm on ONE host core: 6.6 ms of a 10.1 ms OPQ iteration at SIFT1M shape (bench.py --workload
-// train_opq); here the d/2 column pairs of a round rotate in parallel -- the round-robin ("circle") ordering gives d - 1
-// rounds of d/2 disjoint pairs per sweep -- 16 lanes per pair.
-//   A <- G V0 (V0 = the previous call's right singular vectors: successive G of an OPQ run differ little, 2-3 sweeps instead of
-//        ~10; identity on the first call);  sweeps until max |a_p . a_q| / (|a_p| |a_q|) < 1e-14;
-//   s_p = |a_p|, U = A / s;  V' = S^-1 U' G  (A = G V  =>  U' G = S V');  R = U V'.
-// Only A lives in LDS; V is never rotated along (it is recovered from U' G at the end and kept for the next warm start).
-// status: 0 ok, 1 = a vanishing singular value (the polar factor is not unique there: the caller falls back to the host
-// path, which completes the basis).
+// device: one-sided Jacobi SVD in double (d <= 128, even).  Round 3 ran the same algorithm on ONE host core: 6.6 ms of a
+// 10.1 ms OPQ iteration at SIFT1M shape (bench.py --workload train_opq).  Four kernels:
+//   (1) polar_prep    A0 = G V0 (V0 = the previous call's right singular vectors: successive G of an OPQ run differ little;
+//                     identity on the first call), column-major doubles, grid-wide
+//   (2) polar_jacobi  ONE workgroup, the matrix in LDS (columns padded by 8 doubles: 139 KiB at d = 128): sweeps of d - 1
+//                     round-robin ("circle") rounds, the d/2 disjoint column pairs of a round rotating in parallel, 8 lanes per
+//                     pair, until max |a_p . a_q| / (|a_p| |a_q|) < 1e-9 (G is an f32 accumulation, R is stored as f32);
+//                     s_p = |a_p|, U = A / s
+//   (3) polar_vt      V' = S^-1 U' G  (A = G V  =>  U' G = S V'), kept for the next warm start -- V never rotates along
+//   (4) polar_r       R = U V', written in the memory image the rotation kernel reads
+// status[0]: 0 ok, 1 = a vanishing singular value (the polar factor is not unique there: the caller falls back to the host
+// path, which completes the basis); status[1]: sweeps.  Measured: 1.7-1.9 ms per call (5.7 sweeps on average over an OPQ run,
+// each 127 latency-bound rounds), of which the three products are 30 us.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double group16_sum(double v) {
-#pragma unroll
-  for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
-  return v;
-}
-
 // (1) A0 = G V0, column-major doubles: A0[p * d + i] = sum_k G[i][k] V0[k][p]   (Vw[p * d + k] = V0[k][p]); warm == 0: A0 = G
 __global__ void polar_prep_kernel(double *__restrict__ A0, const float *__restrict__ G, const double *__restrict__ Vw, int warm, int d) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;

@@ -106,3 +106,30 @@ def test_xcd_window_plan_is_the_default_for_big_bases():
     p = _lib.scan_plan(125_000_000, 1024, 8, 128, 100)                # ... and one GPU's shard of it on 8 GPUs
     assert p["xcd"] == 1 and 16 <= p["slices"] <= 64, p
     assert _lib.scan_plan(1_000_000, 10_000, 8, 128, 1000)["xcd"] == 0   # SIFT1M shape: whole-base items
+
+
+def test_order_plan_host_logic():
+    """rq_order_plan (no device): the bank-aware row order spends log2(n / 32) key bits, 3 per leading code byte -- a
+    32-value window per byte = one LDS bank column each (csrc/rq_order.hip)."""
+    import ctypes as C
+    from rayuela_jl_amd import _lib
+    L = _lib.lib()
+
+    def plan(n, m):
+        out = (C.c_int * 12)()
+        assert L.rq_order_plan(n, m, C.cast(out, C.c_void_p), 12) == 0
+        return list(out)
+
+    p = plan(1_000_000, 8)
+    assert p[:8] == [3, 3, 3, 3, 3, 0, 0, 0] and p[8] == 15 and p[9] == 32 and p[11] == 8
+    p = plan(125_000_000, 8)                       # the per-GPU shard of BASELINE config 5: 22 bits
+    assert p[:8] == [3, 3, 3, 3, 3, 3, 3, 1] and p[8] == 22
+    assert plan(1_000_000_000, 8)[:9] == [3] * 8 + [24]            # every table conflict-free from 2^29 rows on
+    assert plan(1_000_000, 16)[:8] == [3, 3, 3, 3, 3, 0, 0, 0]     # m = 16: 5 of 16 tables
+    assert plan(500, 8)[8] == 0                                    # tiny base: no ordering
+    p = plan(200_000, 5)                                           # padded to 8 bytes, 13 bits
+    assert p[11] == 8 and p[8] == 13 and p[:5] == [3, 3, 3, 3, 1]
+    p = plan(65_536, 2)                                            # narrow rows: both bytes first get a window, then more bits
+    assert p[8] == 11 and p[0] + p[1] == 11 and p[2:8] == [0] * 6
+    out = (C.c_int * 12)()
+    assert L.rq_order_plan(1000, 65, C.cast(out, C.c_void_p), 12) != 0          # m > 64
