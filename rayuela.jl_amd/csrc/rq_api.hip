@@ -865,6 +865,9 @@ struct rq_lsq_index_impl {
   uint8_t *codes = nullptr;      // [n][mp] (zero-padded to a tiled row width)
   float *cb = nullptr, *norms = nullptr;
   uint8_t *normb = nullptr;      // prepared norm buffer (lsq_norm_bytes) or nullptr when the filter does not apply
+  void *ordered = nullptr;       // codes in bank-aware row order + perm (order_base), norms permuted alike; else nullptr
+  const uint8_t *ocodes = nullptr;
+  const uint32_t *perm = nullptr;
 };
 
 static void lsq_free(rq_lsq_index_impl *ix) {
@@ -877,6 +880,7 @@ static void lsq_free(rq_lsq_index_impl *ix) {
     if (ix->cb) (void)hipFree(ix->cb);
     if (ix->norms) (void)hipFree(ix->norms);
     if (ix->normb) (void)hipFree(ix->normb);
+    if (ix->ordered) (void)hipFree(ix->ordered);
   }
   if (have) (void)hipSetDevice(cur);
   (void)hipGetLastError();
@@ -910,9 +914,29 @@ rq_lsq_index *rq_lsq_prepare(const uint8_t *codes, const float *codebooks, const
       RQ_TRY(pad_codes_launch(ix->codes, raw.as<uint8_t>(), n, m, mp, nullptr));
       RQ_HIP(hipDeviceSynchronize());
     }
+    // the base is resident: bank-aware row order once (rq_order.hip), norms permuted alike -- row_bias and the filter's
+    // norm bytes are indexed by POSITION in the kernel, ids come from perm
+    if (tuning("INDEX_ORDER", 1) && order_pays(n, 0, 0)) {
+      RQ_HIP(hipMalloc(&ix->ordered, order_base_bytes(n, mp)));
+      RQ_TRY(order_base(&ix->ocodes, &ix->perm, ix->ordered, ix->codes, n, mp, nullptr));
+      if (ix->perm) {
+        float *pn = nullptr;
+        RQ_HIP(hipMalloc((void **)&pn, (size_t)n * 4));
+        RQ_TRY(gather_f32_launch(pn, ix->norms, ix->perm, n, nullptr));
+        RQ_HIP(hipDeviceSynchronize());
+        RQ_HIP(hipFree(ix->norms));
+        ix->norms = pn;
+        RQ_HIP(hipFree(ix->codes));
+        ix->codes = nullptr;
+      } else {
+        RQ_HIP(hipFree(ix->ordered));
+        ix->ordered = nullptr;
+      }
+    }
+    const uint8_t *cur = ix->perm ? ix->ocodes : ix->codes;
     if ((mp == 8 || mp == 16) && tuning("SCAN_FILTER", 1) && tuning("SCAN_FILTER_LSQ", 1)) {
       RQ_HIP(hipMalloc((void **)&ix->normb, lsq_norm_bytes(n)));
-      RQ_TRY(lsq_norm_prepare(ix->normb, ix->codes, ix->cb, ix->norms, n, mp, m, d, nullptr));
+      RQ_TRY(lsq_norm_prepare(ix->normb, cur, ix->cb, ix->norms, n, mp, m, d, nullptr));
       RQ_HIP(hipDeviceSynchronize());
     }
     return RQ_OK;
@@ -961,7 +985,8 @@ int rq_lsq_search(rq_lsq_index *handle, float *dists, uint32_t *ids, const float
     ScanBase sb;
     sb.padded = true;
     sb.norm_prepared = ix->normb;
-    return dev_linscan(ddp + (size_t)q0 * k, dip + (size_t)q0 * k, nullptr, ix->codes, ix->cb, qdev + (size_t)q0 * d, ix->n, nqc,
+    sb.perm = ix->perm;
+    return dev_linscan(ddp + (size_t)q0 * k, dip + (size_t)q0 * k, nullptr, ix->perm ? ix->ocodes : ix->codes, ix->cb, qdev + (size_t)q0 * d, ix->n, nqc,
                        ix->m, d, k, 0, id_base, stream, LUT_LSQ, ix->norms, &sb);
   }));
   g_t_total = tt.ms();

@@ -106,10 +106,13 @@ size_t order_base_bytes(int64_t n, int mp);
 int order_base(const uint8_t **out_codes, const uint32_t **out_perm, void *dst, const uint8_t *codes, int64_t n, int mp,
                hipStream_t stream);
 // ---- bank-aware row order (rq_order.hip) ---------------------------------------------------------
-struct OrderTiling { int rpt, gran, group, cbits; };                    // see scan_order_tiling (rq_scan.hip)
+struct OrderTiling { int rpt, gran, group, cbits, blk; };                    // see scan_order_tiling (rq_scan.hip)
 void scan_order_tiling(int mp, OrderTiling *t);
 int order_key_bits(int64_t n, int mp, const OrderTiling &t, int nb[8]);  // key layout; returns the total bits (0: no ordering)
 size_t order_scratch_bytes(int64_t n, int total_bits);
+int order_sample_stride();                                               // ORDER_SAMPLE_STRIDE (16; < 2: no sample blocks)
+uint32_t order_sample_rows(int64_t n, int blk, uint32_t *sgroups);   // arrival-order sample blocks of an ordered base
+int gather_f32_launch(float *dst, const float *src, const uint32_t *perm, int64_t n, hipStream_t stream);
 int order_rows_launch(uint8_t *dst, uint32_t *perm, const uint8_t *src, int64_t n, int mp, void *scratch,
                       const OrderTiling &t, hipStream_t stream);
 // [P][nq][k] -> [nq][P][k] (lists gathered shard-major, merged query-major)

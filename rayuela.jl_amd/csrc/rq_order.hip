@@ -45,7 +45,40 @@ struct OrderParams {
   uint32_t gran;          // shuffle granule (rows, multiple of tile)
   uint32_t ngran;         // full granules: n / gran
   uint32_t weyl;          // A: odd, coprime with ngran
+  // SAMPLE BLOCKS (see order_sample_rows): the positions are cut into groups of `stride` blocks of `blk` rows; the first
+  // block of each of the `sgroups` full groups holds every stride-th row of the base in ARRIVAL order, the sorted rows
+  // fill the rest
+  uint32_t stride, blk, sgroups;
+  uint32_t rnd_rows;      // sample rows in all: sgroups * blk
+  uint32_t nsorted;       // n - rnd_rows
 };
+
+// Is row i a sample row?  It is sample row number i / stride.
+__device__ __forceinline__ bool order_in_prefix(const OrderParams &p, uint32_t i) {
+  return p.rnd_rows && i % p.stride == 0u && i / p.stride < p.rnd_rows;
+}
+// position of sample row r / of sorted index t
+__device__ __forceinline__ uint32_t order_sample_pos(const OrderParams &p, uint32_t r) {
+  return (r / p.blk) * p.stride * p.blk + r % p.blk;
+}
+__device__ __forceinline__ uint32_t order_sorted_pos(const OrderParams &p, uint32_t t) {
+  if (!p.rnd_rows) return t;
+  const uint32_t per = (p.stride - 1u) * p.blk;          // sorted rows per full group
+  const uint32_t g = t / per;
+  if (g >= p.sgroups) return p.sgroups * p.stride * p.blk + (t - p.sgroups * per);
+  return g * p.stride * p.blk + p.blk + (t - g * per);
+}
+
+__device__ __forceinline__ void order_copy_row(const OrderParams &p, uint32_t row, uint32_t pos) {
+  const uint8_t *a = p.src + (size_t)row * p.mp;
+  uint8_t *b = p.dst + (size_t)pos * p.mp;
+  if (p.mp == 8) *reinterpret_cast<uint64_t *>(b) = *reinterpret_cast<const uint64_t *>(a);
+  else if (p.mp >= 16) {
+    for (int o = 0; o < p.mp; o += 16) *reinterpret_cast<uint4 *>(b + o) = *reinterpret_cast<const uint4 *>(a + o);
+  } else if (p.mp == 4) *reinterpret_cast<uint32_t *>(b) = *reinterpret_cast<const uint32_t *>(a);
+  else *reinterpret_cast<uint16_t *>(b) = *reinterpret_cast<const uint16_t *>(a);
+  p.perm[pos] = row;
+}
 
 constexpr int ORDER_SCAN_TILE = 16384;    // bins per scan workgroup (1024 threads x 16)
 
@@ -68,7 +101,7 @@ __device__ __forceinline__ uint32_t order_key_of(const OrderParams &p, uint32_t 
 // depend on the permutation)
 __global__ __launch_bounds__(256) void order_rank_kernel(OrderParams p) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += gridDim.x * blockDim.x)
-    p.rank[i] = atomicAdd(&p.hist[order_key_of(p, i)], 1u);
+    if (!order_in_prefix(p, i)) p.rank[i] = atomicAdd(&p.hist[order_key_of(p, i)], 1u);
 }
 
 // pass 2a: exclusive scan inside tiles of ORDER_SCAN_TILE bins, tile totals to hist[nbins + tile]
@@ -115,33 +148,30 @@ __global__ __launch_bounds__(1024) void order_scan_top_kernel(uint32_t *tot, uin
 // sorted rank -> position (see the header comment): `group` consecutive ranks become one lane group of the kernel --
 // lane l of a wavefront handles rows tile * T + l * RPT + r (r < RPT), the group (b, r) is lanes [b * group, (b + 1) * group)
 __device__ __forceinline__ uint32_t order_deal(const OrderParams &p, uint32_t s) {
+  // s: rank among the sorted rows.  Shuffle and dealing act on that index space (granules and tiles of it stay aligned in
+  // position space: block sizes are multiples of both); order_sorted_pos then steps over the sample blocks.
   uint32_t g = s / p.gran;
   if (g < p.ngran) {
     const uint32_t g2 = (uint32_t)(((uint64_t)g * p.weyl) % p.ngran);
     s = g2 * p.gran + (s - g * p.gran);
   }
   const uint32_t t = s / p.tile;
-  if ((uint64_t)(t + 1) * p.tile > p.n) return s;     // the ragged last tile stays in sort order
-  const uint32_t u = s - t * p.tile;
-  const uint32_t gi = u / p.group, j = u - gi * p.group;   // group inside the tile, row inside the group
-  const uint32_t b = gi / p.rpt, r = gi - b * p.rpt;
-  return t * p.tile + (b * p.group + j) * p.rpt + r;
+  if ((uint64_t)(t + 1) * p.tile <= p.nsorted) {            // (the ragged last tile stays in sort order)
+    const uint32_t u = s - t * p.tile;
+    const uint32_t gi = u / p.group, j = u - gi * p.group;   // group inside the tile, row inside the group
+    const uint32_t b = gi / p.rpt, r = gi - b * p.rpt;
+    s = t * p.tile + (b * p.group + j) * p.rpt + r;
+  }
+  return order_sorted_pos(p, s);
 }
 
 // pass 3: every row to its position, perm[position] = row
 __global__ __launch_bounds__(256) void order_scatter_kernel(OrderParams p) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += gridDim.x * blockDim.x) {
+    if (order_in_prefix(p, i)) { order_copy_row(p, i, order_sample_pos(p, i / p.stride)); continue; }
     const uint32_t key = order_key_of(p, i);
     const uint32_t s = p.hist[key] + p.hist[p.nbins + key / ORDER_SCAN_TILE] + p.rank[i];
-    const uint32_t pos = order_deal(p, s);
-    const uint8_t *a = p.src + (size_t)i * p.mp;
-    uint8_t *b = p.dst + (size_t)pos * p.mp;
-    if (p.mp == 8) *reinterpret_cast<uint64_t *>(b) = *reinterpret_cast<const uint64_t *>(a);
-    else if (p.mp >= 16) {
-      for (int o = 0; o < p.mp; o += 16) *reinterpret_cast<uint4 *>(b + o) = *reinterpret_cast<const uint4 *>(a + o);
-    } else if (p.mp == 4) *reinterpret_cast<uint32_t *>(b) = *reinterpret_cast<const uint32_t *>(a);
-    else *reinterpret_cast<uint16_t *>(b) = *reinterpret_cast<const uint16_t *>(a);
-    p.perm[pos] = i;
+    order_copy_row(p, i, order_deal(p, s));
   }
 }
 
@@ -194,7 +224,8 @@ __global__ __launch_bounds__(ORDER_SMALL_THREADS) void order_coarse_count_kernel
   if (tid < ORDER_COARSE) h[tid] = 0;
   __syncthreads();
   const uint32_t r0 = blockIdx.x * q.rows_per_wg, r1 = min(p.n, r0 + q.rows_per_wg);
-  for (uint32_t i = r0 + tid; i < r1; i += ORDER_SMALL_THREADS) atomicAdd(&h[order_key_of(p, i) >> q.fine_bits], 1u);
+  for (uint32_t i = r0 + tid; i < r1; i += ORDER_SMALL_THREADS)
+    if (!order_in_prefix(p, i)) atomicAdd(&h[order_key_of(p, i) >> q.fine_bits], 1u);
   __syncthreads();
   if (tid < ORDER_COARSE && h[tid]) atomicAdd(&q.ctot[tid], h[tid]);
 }
@@ -211,7 +242,11 @@ __global__ __launch_bounds__(ORDER_SMALL_THREADS) void order_coarse_scatter_kern
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const uint32_t i = r0 + u * ORDER_SMALL_THREADS + tid;
-    if (i < r1) { c[u] = order_key_of(p, i) >> q.fine_bits; lr[u] = atomicAdd(&h[c[u]], 1u); }
+    c[u] = 0xffffffffu;
+    if (i < r1) {
+      if (order_in_prefix(p, i)) order_copy_row(p, i, order_sample_pos(p, i / p.stride));   // a sample row: arrival order, no sort
+      else { c[u] = order_key_of(p, i) >> q.fine_bits; lr[u] = atomicAdd(&h[c[u]], 1u); }
+    }
   }
   __syncthreads();
   if (tid < ORDER_COARSE && h[tid]) base[tid] = starts[tid] + atomicAdd(&q.ctot[ORDER_COARSE + tid], h[tid]);
@@ -219,7 +254,7 @@ __global__ __launch_bounds__(ORDER_SMALL_THREADS) void order_coarse_scatter_kern
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const uint32_t i = r0 + u * ORDER_SMALL_THREADS + tid;
-    if (i < r1) q.idx[base[c[u]] + lr[u]] = i;
+    if (c[u] != 0xffffffffu) q.idx[base[c[u]] + lr[u]] = i;
   }
 }
 
@@ -249,15 +284,7 @@ __global__ __launch_bounds__(ORDER_SMALL_THREADS) void order_fine_kernel(OrderPa
   for (uint32_t i = b0 + tid; i < b1; i += ORDER_SMALL_THREADS) {
     const uint32_t row = q.idx[i];
     const uint32_t s = atomicAdd(&f[order_key_of(p, row) & fmask], 1u);
-    const uint32_t pos = order_deal(p, s);
-    const uint8_t *a = p.src + (size_t)row * p.mp;
-    uint8_t *b = p.dst + (size_t)pos * p.mp;
-    if (p.mp == 8) *reinterpret_cast<uint64_t *>(b) = *reinterpret_cast<const uint64_t *>(a);
-    else if (p.mp >= 16) {
-      for (int o = 0; o < p.mp; o += 16) *reinterpret_cast<uint4 *>(b + o) = *reinterpret_cast<const uint4 *>(a + o);
-    } else if (p.mp == 4) *reinterpret_cast<uint32_t *>(b) = *reinterpret_cast<const uint32_t *>(a);
-    else *reinterpret_cast<uint16_t *>(b) = *reinterpret_cast<const uint16_t *>(a);
-    p.perm[pos] = row;
+    order_copy_row(p, row, order_deal(p, s));
   }
 }
 
@@ -266,9 +293,32 @@ static uint32_t gcd_u32(uint32_t a, uint32_t b) { while (b) { const uint32_t t =
 // Key layout for n rows of mp bytes: `cbits` bits per leading code byte (the window 256 >> cbits = the bank columns one
 // gather of `group` lanes can hit without a conflict) while log2(n / group) bits last; what is left over goes to the next
 // byte (a wider window still lowers its passes).  0 bits: no ordering (tiny bases).
+// Sample blocks of an ordered base.  The scan's second threshold estimate treats the first 1/8 of a slice as a random sample
+// of it.  Sorted rows are anything but: a query's near neighbours share their leading code bytes and sit in a few buckets (on
+// 1e6 rows from 1024 tight clusters the whole top-1000 is one or two 1024-row granules: 640 of 1250 items fell back to the
+// exact redo, 4 -> 13.6 ms, whatever the shuffle granule).  So one block in every ORDER_SAMPLE_STRIDE (16) holds an
+// every-16th-row sample of the base in ARRIVAL order -- what the estimate saw before there was any ordering -- and the kernel
+// visits a slice's sample blocks first, re-estimates, then streams the sorted blocks (adc_scan_kernel: two_pass).  Any slice
+// or XCD window that starts on a block boundary has its share of them; a sixteenth of the rows keeps the old conflict rate.
+// (Measured, prepared SIFT1M base k = 1000 / 1.25e8-row shard: no sample blocks 1.94 / 15.1 ms -- and the cliff on clumped
+// data --, stride 8: 2.05 / 16.3, 16: 2.02 / 15.8, 32: 2.11 / 15.8.)  The first estimate of SLICED items (a systematic row
+// sample of the slice) was hit by the same clumping with 1024-row shuffle granules; with one wavefront tile per granule
+// (128 rows at m = 8) a cluster's rows are dealt over the whole base and it holds.
+// Returns the sample rows (a multiple of blk; 0: none) and, through *sgroups, the full groups of stride * blk positions.
+int order_sample_stride() { return tuning("ORDER_SAMPLE_STRIDE", 16); }
+
+uint32_t order_sample_rows(int64_t n, int blk, uint32_t *sgroups) {
+  const int stride = order_sample_stride();
+  uint32_t g = 0;
+  if (stride >= 2 && blk > 0) g = (uint32_t)(n / ((int64_t)stride * blk));
+  if (sgroups) *sgroups = g;
+  return g * (uint32_t)blk;
+}
+
 int order_key_bits(int64_t n, int mp, const OrderTiling &t, int nb[8]) {
   for (int c = 0; c < 8; ++c) nb[c] = 0;
   if (n < 1024) return 0;
+  n -= order_sample_rows(n, t.blk, nullptr);
   int budget = tuning("ORDER_BITS", 0);
   if (budget <= 0) budget = (int)std::floor(std::log2((double)n / (double)t.group) + 0.5);   // one bit per doubling of the group count
   budget = std::min(budget, 24);
@@ -306,7 +356,11 @@ int order_rows_launch(uint8_t *dst, uint32_t *perm, const uint8_t *src, int64_t 
   p.group = (uint32_t)t.group;
   p.tile = 64u * (uint32_t)rpt;
   p.gran = (uint32_t)std::max(gran, (int)p.tile) / p.tile * p.tile;
-  p.ngran = (uint32_t)(n / p.gran);
+  p.stride = (uint32_t)std::max(2, order_sample_stride());
+  p.blk = (uint32_t)t.blk;
+  p.rnd_rows = order_sample_rows(n, t.blk, &p.sgroups);
+  p.nsorted = (uint32_t)n - p.rnd_rows;
+  p.ngran = p.nsorted / p.gran;                 // full granules of the sorted index space
   p.weyl = 1;
   if (p.ngran > 2 && tuning("ORDER_SHUFFLE", 1)) {
     uint32_t a = (uint32_t)((double)p.ngran * 0.6180339887498949) | 1u;
@@ -335,6 +389,18 @@ int order_rows_launch(uint8_t *dst, uint32_t *perm, const uint8_t *src, int64_t 
   hipLaunchKernelGGL(order_scan_tiles_kernel, dim3(ntiles), dim3(1024), 0, stream, p.hist, p.nbins);
   hipLaunchKernelGGL(order_scan_top_kernel, dim3(1), dim3(1024), 0, stream, p.hist + p.nbins, ntiles);
   hipLaunchKernelGGL(order_scatter_kernel, dim3(grid), dim3(256), 0, stream, p);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+// dst[i] = src[perm[i]]  (per-row side arrays of an ordered base: LSQ norms)
+__global__ void gather_f32_kernel(float *__restrict__ dst, const float *__restrict__ src, const uint32_t *__restrict__ perm, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[perm[i]];
+}
+
+int gather_f32_launch(float *dst, const float *src, const uint32_t *perm, int64_t n, hipStream_t stream) {
+  if (n <= 0) return RQ_OK;
+  hipLaunchKernelGGL(gather_f32_kernel, dim3((uint32_t)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, stream, dst, src, perm, (uint32_t)n);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
 }

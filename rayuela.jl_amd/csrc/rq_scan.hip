@@ -171,7 +171,17 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
     // minimum beats the q-quantile is 1-(1-q)^gsz (~ q*gsz only while that is small); gsz shrinks
     // for large K so that the selected rank stays in the well-conditioned middle of the 512 minima.
     // slices long enough for the second estimate (retune_tau) start from a smaller sample
-    const bool will_retune = p.retune_z != 0 && p.K >= p.retune_min_k && rows >= 16u * (uint32_t)BLK;
+    // Ordered bases: sorted rows are no random sample of anything -- the estimate is taken from the slice's SAMPLE blocks
+    // (one block in every samp_stride below samp_end holds an arrival-order sample of the base, rq_order.hip), which the
+    // block loop visits first.  nsamp: those blocks inside [r_begin, r_end).
+    uint32_t nsamp = 0;
+    if (p.perm != nullptr && p.samp_end != 0u) {
+      const uint32_t b0 = r_begin / (uint32_t)BLK, b1 = min(r_end, p.samp_end) / (uint32_t)BLK;     // (samp_end is a block multiple)
+      const uint32_t s0 = (b0 + p.samp_stride - 1u) / p.samp_stride, s1 = (max(b1, b0) + p.samp_stride - 1u) / p.samp_stride;
+      nsamp = s1 > s0 ? s1 - s0 : 0u;
+    }
+    const bool will_retune = p.retune_z != 0 && p.K >= p.retune_min_k && rows >= 16u * (uint32_t)BLK &&
+                             (p.perm == nullptr || nsamp > 0u);
     uint32_t S = will_retune ? p.sample_rt : p.sample;
     uint32_t srank = 0;
     bool sampled = false;
@@ -256,9 +266,10 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
     }
     // second threshold estimate after ~1/8 of the rows (see retune_tau)
     uint32_t retune_at = 0xffffffffu, retune_rank = 0;
+    const bool two_pass = attempt == 0 && will_retune && p.perm != nullptr;      // sample blocks first, then the sorted ones
     if (attempt == 0 && will_retune) {
-      const uint32_t nb = max(1u, rows / ((uint32_t)p.retune_div * (uint32_t)BLK));
-      retune_at = r_begin + nb * (uint32_t)BLK;
+      const uint32_t nb = two_pass ? nsamp : max(1u, rows / ((uint32_t)p.retune_div * (uint32_t)BLK));
+      retune_at = two_pass ? nb : r_begin + nb * (uint32_t)BLK;     // two_pass: a count of processed blocks, else a position
       const float f = (float)(nb * (uint32_t)BLK) / (float)rows, mean = (float)p.K * f;
       const float rk = mean + (float)p.retune_z * sqrtf(mean * (1.0f - f)) + 2.0f;
       retune_rank = rk < 1.0f ? 1u : (uint32_t)ceilf(rk);
@@ -269,9 +280,20 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
     t_ph = RQ_STAT_T();
 
     // ---- stream the slice -----------------------------------------------------------------------
+    // (all of this loop control is wave-uniform: readfirstlane keeps it in SGPRs -- as VGPRs it spilled the block's code words)
+    uint32_t bi = 0;       // blocks processed in this attempt
+    const uint32_t npass = __builtin_amdgcn_readfirstlane(two_pass ? 2u : 1u);
+    const uint32_t samp_lim = __builtin_amdgcn_readfirstlane(two_pass ? min(r_end, p.samp_end) : 0u);
+    const uint32_t samp_step = __builtin_amdgcn_readfirstlane(p.samp_stride * (uint32_t)BLK);
+#pragma unroll 1
+    for (uint32_t pass = 0; pass < npass; pass = __builtin_amdgcn_readfirstlane(pass + 1u))
 #pragma unroll 1
     for (uint32_t base = r_begin; base < r_end; base += BLK) {
-      if (base == retune_at) {
+      if (npass == 2u) {
+        const bool smp = base < samp_lim && base % samp_step == 0u;
+        if (smp != (pass == 0u)) continue;
+      }
+      if (npass == 2u ? (pass == 1u && bi == retune_at) : (base == retune_at)) {
         if (FILT && filt_on) {
           while (qtail) {
             const uint32_t take = min(qtail, 64u);
@@ -291,7 +313,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
       // ONE barrier per VP blocks.  Capacity invariant: cnt[q] + VP * BLK <= cap for every q when a period starts.
       // The pre-barrier read of cnt may miss what slower wavefronts are still appending for the
       // previous period (at most VP * BLK keys), hence cap = trigger + 2 * VP * BLK; behind the barrier cnt is exact.
-      const bool vote_now = Cfg::VP == 1 || ((base - r_begin) / (uint32_t)BLK) % (uint32_t)Cfg::VP == 0u;
+      const bool vote_now = Cfg::VP == 1 || bi % (uint32_t)Cfg::VP == 0u;
       const bool maybe = ctrl->cnt[g] > p.trigger;
       if (vote_now && block_any(maybe, ctrl->st.vote, vseq)) {
         const unsigned long long t_c = RQ_STAT_T();
@@ -313,7 +335,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
         // The filter pays off while few rows pass it (0.5 - 5 % on clustered data).  Tables without contrast
         // (e.g. random codes against random codebooks at m = 16) let a large share through; the first block's
         // count decides for the rest of the item, and the exact loop takes over after the queues are drained.
-        if (filt_on && base == r_begin + (uint32_t)Cfg::VP * BLK) {
+        if (filt_on && bi == (uint32_t)Cfg::VP) {
           // (60 % since the exact evaluation is per pair: at Deep1M shape, k = 10000, 29 % of the first block's rows are alive
           // and the filter still wins -- 10.2 ms against 14.9 with the old 12 / 30 % limits)
           constexpr uint32_t MAX_SHARE_PCT = FILT_MAX_SHARE_PCT;
@@ -505,7 +527,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
           }
         }
         asm volatile("; RQ_FILTER_LOOP_END" ::: "memory");
-        if (base == r_begin && lane == 0) atomicAdd(&ctrl->fpush, npush);
+        if (bi == 0u && lane == 0) atomicAdd(&ctrl->fpush, npush);
       }
       }
       if (!filtered) {
@@ -533,6 +555,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
       }  // sub-steps
       }
       }  // sub-step chunks
+      bi = __builtin_amdgcn_readfirstlane(bi + 1u);
     }
     if (FILT && filt_on) {
       while (qtail) {          // slice end: the rest of the queue
@@ -771,6 +794,13 @@ __global__ void synth_codes_kernel(uint8_t *codes, size_t nbytes, uint64_t seed,
 template <int M>
 static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) {
   using Cfg = ScanCfg<M>;
+  p.samp_end = 0; p.samp_stride = 16;
+  if (p.perm) {       // the ordered base's sample blocks (the same arithmetic as order_rows_launch)
+    uint32_t groups = 0;
+    (void)order_sample_rows((int64_t)p.n, Cfg::BLK, &groups);
+    p.samp_stride = (uint32_t)std::max(2, order_sample_stride());
+    p.samp_end = groups * p.samp_stride * (uint32_t)Cfg::BLK;
+  }
   constexpr int CTRL_BYTES = (sizeof(ScanCtrl<Cfg::QG>) + 15) & ~15;
   size_t lds = CTRL_BYTES + (size_t)std::max<size_t>(Cfg::LUT_LDS_BYTES + (size_t)Cfg::QG * p.d * 4 + Cfg::AUX_BYTES,
                                                      (size_t)p.scratch_keys * 8);
@@ -1013,6 +1043,7 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
                 bool norm_ready) {
   ScanParams p;
   p.perm = perm;
+  p.samp_end = 0;           // set per row width below (launch_scan): positions below it hold a sample block in every 8
   p.codes = codes; p.centers = centers; p.queries = queries;
   p.n = (uint32_t)n; p.nq = (uint32_t)nq; p.sub = d / m; p.d = d; p.K = K;
   p.m_real = m;
@@ -1115,15 +1146,15 @@ int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t
   return RQ_OK;
 }
 
-// the row tiling rq_order.hip has to match: rows per lane and sub-step, rows per workgroup sub-step (the shuffle granule),
+// the row tiling rq_order.hip has to match: rows per lane and sub-step, rows of one wavefront tile (the shuffle granule),
 // rows that meet in one LDS gather and the key bits per code byte that make such a gather conflict-free.
 // Every LDS read width is served 32 lanes per pass on gfx950 (ds_read_b64: 256 B/clk; a dword gather moves half as much in
 // the same passes -- measured again in round 4 with byte tables split into [k][quad][256] dwords read by ds_read2st64_b32
 // and a 64-lane / 2-bit row order: 1.55 -> 2.65 ms), so the group is 32 rows and the window 32 values for all of them.
 void scan_order_tiling(int mp, OrderTiling *t) {
-  int r = 1, g = SCAN_THREADS;
+  int r = 1, g = SCAN_THREADS, bk = SCAN_THREADS;
   switch (mp) {
-#define RQ_OT(MM) case MM: r = ScanCfg<MM>::RPT; g = ScanCfg<MM>::SUB; break;
+#define RQ_OT(MM) case MM: r = ScanCfg<MM>::RPT; g = 64 * ScanCfg<MM>::RPT; bk = ScanCfg<MM>::BLK; break;
     RQ_OT(2) RQ_OT(4) RQ_OT(8) RQ_OT(16) RQ_OT(32) RQ_OT(64)
 #undef RQ_OT
   }
@@ -1132,6 +1163,7 @@ void scan_order_tiling(int mp, OrderTiling *t) {
   t->gran = tg > 0 ? tg : g;
   t->group = 32;
   t->cbits = 3;
+  t->blk = bk;
 }
 
 int pad_codes_launch(uint8_t *dst, const uint8_t *src, int64_t n, int m, int mp, hipStream_t stream) {

@@ -103,6 +103,8 @@ struct ScanParams {
   const float *norm_info;     // ... {nmin, nstep, max |.|} of the quantised quantity: norm[row] - sum_k |c_k[b_k]|^2
   const float *cnorm;         // ... |c_k[r]|^2, [M][256]: folded into the filter's tables (see build_qtab)
   const uint32_t *perm;     // bank-aware row order (rq_order.hip): perm[position] = original row, read for survivors only; or nullptr
+  uint32_t samp_end;        // ... below this position one block in every samp_stride is an arrival-order sample of the base
+  uint32_t samp_stride;     //     (order_sample_rows, rq_order.hip); samp_end == 0: none
   uint32_t id_offset;
   int id_base;
   uint32_t nslices, rows_per_slice, ngroups;

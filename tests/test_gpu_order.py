@@ -22,7 +22,8 @@ class _Tuning:
     def __exit__(self, *exc):
         defaults = {"SCAN_ORDER": 1, "ORDER_MIN_ROWS": 65536, "ORDER_MIN_NQ": 2048, "ORDER_BITS": 0, "ORDER_GRAN": 0,
                     "ORDER_SHUFFLE": 1, "SCAN_SRANK_MUL": 2, "SCAN_SLACK": 0, "SCAN_SLICES": 0, "SCAN_FILTER": 1,
-                    "SCAN_RETUNE_Z": 6, "INDEX_ORDER": 1, "SCAN_XCD_MIN_MB": 0, "SCAN_WINDOW_MB": 0}
+                    "SCAN_RETUNE_Z": 6, "INDEX_ORDER": 1, "SCAN_XCD_MIN_MB": 0, "SCAN_WINDOW_MB": 0, "ORDER_SAMPLE_STRIDE": 16,
+                    "SCAN_STATS": 0}
         for k in self.kv:
             self.rq.set_tuning(k, defaults[k])
 
@@ -59,7 +60,8 @@ def test_order_rows_is_a_permutation_with_fewer_bank_conflicts(rq, n, m):
         rpt = 2 if m == 8 else 1
         before, after = _lds_passes(codes, rpt), _lds_passes(oc[:, :m], rpt)
         # n = 1e6, m = 8: 3.15 -> 1.94 passes per gather (5 of 8 byte tables conflict-free)
-        assert after < (0.68 if m == 8 else 0.85) * before, (before, after)
+        # (a sixteenth of the rows -- the arrival-order sample blocks -- keeps the old rate)
+        assert after < (0.70 if m == 8 else 0.87) * before, (before, after)
 
 
 def _hostile_codes(kind, n, m, rng):
@@ -95,7 +97,8 @@ def test_ordered_scan_is_bit_exact(rq, oracle, kind, n, m, sub, nq, K):
 
 @pytest.mark.parametrize("knobs", [dict(SCAN_SRANK_MUL=0), dict(SCAN_SLACK=64, SCAN_SRANK_MUL=0), dict(SCAN_FILTER=0),
                                    dict(SCAN_SLICES=3), dict(SCAN_RETUNE_Z=-8), dict(ORDER_SHUFFLE=0),
-                                   dict(ORDER_BITS=9), dict(ORDER_BITS=20), dict(ORDER_GRAN=128)])
+                                   dict(ORDER_BITS=9), dict(ORDER_BITS=20), dict(ORDER_GRAN=1024), dict(ORDER_SAMPLE_STRIDE=0),
+                                   dict(ORDER_SAMPLE_STRIDE=3)])
 def test_ordered_scan_on_every_threshold_path(rq, oracle, knobs):
     """The exact fallback (tau = +inf with capacity cuts: emit_survivors reads perm), the unfiltered loop, row slices +
     merge, a second estimate that is too tight, an unshuffled (sorted) base -- the estimate then misses and the slice is
@@ -190,3 +193,33 @@ def test_xcd_windows_over_an_ordered_base(rq, oracle):
     with _Tuning(rq, SCAN_ORDER=2, ORDER_MIN_ROWS=1, SCAN_XCD_MIN_MB=1, SCAN_WINDOW_MB=1):
         d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
     assert np.array_equal(i0, i1) and _eq_bits(d0, d1)
+
+
+def test_clumped_base_does_not_fall_back(rq, oracle):
+    """1e6 rows from 1024 tight clusters: a query's top-1000 is one cluster = a handful of sort buckets.  On a plainly sorted base
+    the second threshold estimate (which takes the first part of a slice for a random sample) missed for half of the whole-base
+    items, and the first estimate of sliced items missed with 1024-row shuffle granules; the exact redo made those scans 3x
+    slower than in arrival order.  The arrival-order sample blocks and the tile-sized granules keep both estimates honest: no
+    fallbacks at any batch size, same answer."""
+    import torch
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import device as rqd, _lib
+    n, d, m, h, K = 1_000_000, 128, 8, 256, 1000
+    X = synth.sift_like(n, d, seed=synth.SEED_BASE)              # ncentres = 1024
+    C = synth.codebooks(synth.sift_like(20_000, d, seed=synth.SEED_BASE, row0=3_100_000_000), m, h, seed=synth.SEED_CODEBOOK,
+                        iters=5, sample=20000)
+    B = rq.quantize_pq_u8(X, C)
+    cen = torch.from_numpy(np.stack(C)).cuda()
+    ob = rqd.order_rows(torch.from_numpy(B).cuda())
+    for nq in (64, 512, 4096):             # sliced items (8 and 2 slices) and whole-base items
+        Q = synth.sift_like(nq, d, seed=synth.SEED_QUERY)
+        qd = torch.from_numpy(Q).cuda()
+        with _Tuning(rq, SCAN_STATS=1):
+            _lib.scan_stats()
+            d1, i1 = rqd.linscan(ob, cen, qd, K)
+            torch.cuda.synchronize()
+            st = _lib.scan_stats()
+        assert st["n_fallbacks"] == 0, (nq, st)
+        sel = np.arange(0, nq, max(1, nq // 32))
+        d0, i0 = oracle.linscan_aqd_query(B, np.stack(C), Q[sel], K)
+        assert np.array_equal(i1.cpu().numpy().view(np.uint32)[sel], i0) and _eq_bits(d1.cpu().numpy()[sel], d0), nq

@@ -58,8 +58,9 @@ def test_prefilter_hot_loop_has_no_scratch_traffic(scan_asm, m, fine):
     lines = scan_asm[start:scan_asm.index("s_endpgm", start)].splitlines()
     lo = [i for i, ln in enumerate(lines) if "RQ_FILTER_LOOP_BEGIN" in ln]
     hi = [i for i, ln in enumerate(lines) if "RQ_FILTER_LOOP_END" in ln]
-    assert len(lo) == 1 and len(hi) == 1 and lo[0] < hi[0], "filter loop markers not found in the generated code"
-    region = lines[lo[0]:hi[0]]
+    # (the END marker may be duplicated by tail duplication of the block loop's control flow: the region runs to the last one)
+    assert len(lo) == 1 and len(hi) >= 1 and lo[0] < hi[0], "filter loop markers not found in the generated code"
+    region = lines[lo[0]:hi[-1]]
     gathers = sum(1 for ln in region if re.search(r"\bds_read_b(64|32)\b", ln))
     assert gathers >= 64, gathers                     # 8 rows x 8 (m = 8) / 4 rows x 16 (m = 16) gathers per block
     stores = [ln for ln in region if "scratch_store" in ln]

@@ -45,6 +45,14 @@ for flt in (1, 0):
     same = np.array_equal(I[:64].astype(np.int64), i0.astype(np.int64)) and np.array_equal(D[:64].view(np.uint32), d0.view(np.uint32))
     print("m=%d k=%d filter=%d: kernel %.2f ms, same as the checker on 64 queries: %s" % (m, K, flt, best, same), flush=True)
 rq.set_tuning("SCAN_FILTER_LSQ", 1)
+# prepared base (rq_lsq_prepare): codes, norms, codebooks, the filter's O(n) pass and the bank-aware row order once
+with rq.LsqIndex(B, Cl, norms) as ix:
+    best = 1e9
+    for _ in range(4):
+        D, I = ix.search(Q, R, K)
+        best = min(best, rq.last_timing()["kernel_ms"])
+    same = np.array_equal(I[:64].astype(np.int64), i0.astype(np.int64)) and np.array_equal(D[:64].view(np.uint32), d0.view(np.uint32))
+    print("m=%d k=%d prepared base (LsqIndex): kernel %.2f ms, same as the checker on 64 queries: %s" % (m, K, best, same), flush=True)
 
 # resident timing + the kernel's own counters
 import torch  # noqa: E402

@@ -41,6 +41,7 @@ ap.add_argument("--uniform", action="store_true")
 ap.add_argument("--deep", action="store_true")
 ap.add_argument("--modes", default="raw0,raw1,ob")
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--qseed", type=int, default=0, help="queries from another stream (seed) instead of rows beyond the base")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 d, m = (96, 16) if a.deep else (128, 8)
@@ -48,6 +49,8 @@ h, n, nq = 256, a.n, a.nq
 gen = (lambda rows, row0: st.deep_like(rows, d, seed=synth.SEED_BASE, row0=row0, device=dev)) if a.deep else \
       (lambda rows, row0: st.sift_like(rows, d, seed=synth.SEED_BASE, ncentres=65536, row0=row0, device=dev))
 Q = gen(nq, 3_000_000_000)
+if a.qseed:
+    Q = (st.deep_like(nq, d, seed=a.qseed, row0=0, device=dev) if a.deep else st.sift_like(nq, d, seed=a.qseed, ncentres=65536, row0=0, device=dev))
 S = gen(20_000, 3_100_000_000)
 C = synth.codebooks(S.cpu().numpy(), m, h, seed=synth.SEED_CODEBOOK, iters=5, sample=20000)
 Ccat = torch.from_numpy(synth.cat_codebooks(C)).to(dev)
