@@ -196,13 +196,18 @@ def train_bench(a):
     fi = max(1.0, fine["iterations"])
     per_iter = {k: round(fine[k] / fi, 4) for k in ("qerror_ms", "gram_ms", "svd_ms", "rotate_ms", "update_centers_ms", "encode_ms",
                                                     "reconstruct_ms", "converge_ms") if fine[k] > 0}
-    # every device phase against its own roof (algorithmic bytes / flops per iteration, SURVEY 8d's style)
+    # (train_pq: qerror / reconstruct run ONCE after the loop; their entries are that one call's time / iterations)
+    # every device phase of the LOOP against its own roof (algorithmic bytes / flops per iteration, SURVEY 8d's style).  Phases
+    # that run once after the loop (train_pq: the final qerror / reconstruct) are not loop phases and get no roof.
     GB = 1e9
+    once = set() if opq else {"qerror_ms", "reconstruct_ms"}
     shapes = {"rotate_ms": ("mfma", 2.0 * d * d * n), "gram_ms": ("mfma", 2.0 * d * d * n), "encode_ms": ("mfma", 2.0 * d * h * n),
-              "update_centers_ms": ("hbm", (4.0 * d + m) * n), "reconstruct_ms": ("hbm", (4.0 * d + m) * n), "qerror_ms": ("hbm", 8.0 * d * n)}
+              "update_centers_ms": ("hbm", (4.0 * d + m) * n), "reconstruct_ms": ("hbm", (4.0 * d + m) * n),
+              # qerror: X and the n x d reconstruction, or X and the codes when CB is gathered inside the kernel (no reconstruct phase)
+              "qerror_ms": ("hbm", (8.0 * d if "reconstruct_ms" in per_iter else 4.0 * d + m) * n)}
     roofs = {}
     for k, (bound, work) in shapes.items():
-        if k not in per_iter:
+        if k not in per_iter or k in once:
             continue
         t = per_iter[k] * 1e-3
         if bound == "mfma":
@@ -211,10 +216,18 @@ def train_bench(a):
         else:
             ach = work / t / GB
             roofs[k[:-3]] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
-    dev_phases = {k: v for k, v in per_iter.items() if k not in ("svd_ms", "converge_ms")}
+    if "encode" in roofs:
+        # the assignment step is the split encode kernel: its products run as a FILTER on the bf16 matrix cores (3 K = 16 MFMAs per
+        # 32 x 32 tile at sub = 16), so the f32 matrix peak is a yardstick (frac may pass 1); the issued bf16 work is priced too
+        bf = 2.0 * 16 * 256 * (2 if d // m <= 8 else 3) * m * n / (per_iter["encode_ms"] * 1e-3) / 1e12
+        roofs["encode"]["note"] = "f32-equivalent flop vs the f32 matrix peak: a yardstick, the products run on the bf16 cores"
+        roofs["encode"]["bf16_mfma"] = {"issued_TFLOPs": round(bf, 1), "peak": 2500.0, "frac": round(bf / 2500.0, 4)}
+    dev_phases = {k: v for k, v in per_iter.items() if k not in ("svd_ms", "converge_ms") and k not in once}
     dom = max(dev_phases, key=dev_phases.get)[:-3] if dev_phases else None
     roof = dict(roofs.get(dom, {}), kernel=dom, traffic=None, per_phase=roofs,
-                note="the dominant DEVICE phase of an iteration; svd_ms (host, d x d polar factor) is not a kernel") if dom else None
+                note="the dominant throughput phase of an iteration; svd_ms is the d x d polar factor on the device (scaled "
+                     "Newton-Schulz, %.1f steps of two grid-synchronised d^3 products in double per iteration: latency-bound, "
+                     "no roof applies)" % (prof["ns_steps"] / iters)) if dom else None
     # CPU baseline: the numpy/oracle restatement of the same loop (oracle/train_oracle.py) on a bounded sample
     cpu = None
     if not a.no_cpu:
@@ -253,7 +266,9 @@ def train_bench(a):
         "outside_the_loop_ms": {"x_upload": round(prof["h2d_ms"] or fine["h2d_ms"], 2), "init": round(fine["init_ms"], 2),
                                 "results_download": round(fine["d2h_ms"], 2), "whole_call_wall": round(wall * 1e3, 1)},
         "profiled_loop_ms_per_step": round(fine["loop_ms"] / fi, 4),
-        "jacobi_sweeps_per_iteration": round(prof["jacobi_sweeps"] / iters, 2) if opq else None,
+        "polar_factor": {"newton_schulz_steps_per_iteration": round(prof["ns_steps"] / iters, 2),
+                         "jacobi_sweeps_per_iteration": round(prof["jacobi_sweeps"] / iters, 2),
+                         "host_fallbacks": int(prof["host_polar"])} if opq else None,
         "objective": obj,
         "roofline": roof, "cpu_baseline": cpu,
     }

@@ -225,6 +225,11 @@ int rq_dev_reconstruct(float *CB, const uint8_t *codes, const float *C, int64_t 
                        void *stream);
 int rq_dev_qerror(double *acc, const float *X, const float *CB, int64_t n, int d, void *stream);
 int rq_dev_gram(float *G, const float *X, const float *CB, int64_t n, int d, void *stream);
+/* The same two reductions with CB given as (codes [n][m] u8, C): CB[j][off_i + s] = C_i[codes[j][i]][s] is gathered inside the
+ * kernels instead of being written out by rq_dev_reconstruct first (src/OPQ.jl:101,108,112 without the n x d temporary).
+ * Shapes: d % 4 == 0, every sub-space starts on a multiple of 4, h <= 256, gram: d <= 256; RQ_EUNSUPPORTED otherwise. */
+int rq_dev_gram_codes(float *G, const float *X, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h, void *stream);
+int rq_dev_qerror_codes(double *acc, const float *X, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h, void *stream);
 
 /* train_pq (src/PQ.jl:68-99) and train_opq (src/OPQ.jl:49-139) on host pointers: X [n][d]; outputs
  * C (concat of the m [h][sub_i] codebooks), B1 [n][m] Int16 ONE-based, R [d][d] (memory image of Julia's R),
@@ -246,9 +251,15 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
 /* Phase clock of the calling thread's last rq_train_pq / rq_train_opq call, milliseconds (measurement aid, bench.py
  * --workload train_opq|train_pq): out[0] X upload, [1] initialisation, [2] qerror, [3] gram X'CB, [4] d x d polar factor
  * incl. its two small copies, [5] rotation, [6] update_centers, [7] encode, [8] reconstruct, [9] convergence check,
- * [10] results D2H, [11] wall time of the iteration loop, [12] iterations run.  [2]-[9] need tuning TRAIN_PROFILE = 1
- * (every phase is then bracketed by device synchronisations). */
+ * [10] results D2H, [11] wall time of the iteration loop, [12] iterations run, [13] Jacobi sweeps, [14] Newton-Schulz steps,
+ * [15] polar factors taken on the host.  [2]-[9] need tuning TRAIN_PROFILE = 1 (every phase is then bracketed by device
+ * synchronisations). */
 int rq_train_profile(double *out, int cap);
+/* The rotation update of src/OPQ.jl:112-113 (U, S, VV = svd(X * CB'); R = U * VV') as a device call: G [d][d] row-major f32 on
+ * the device, Rimg[i * d + k] = R[k][i] (the memory image of Julia's column-major R).  method 0 = scaled Newton-Schulz
+ * iteration in double (d <= 1024; what rq_train_opq uses), 1 = one-sided Jacobi SVD (even d <= 128).  status (host, 2 ints):
+ * [0] = 0 when Rimg was written, 1 when the method gave up (rank-deficient G); [1] = steps or sweeps.  Synchronous. */
+int rq_dev_polar_factor(float *Rimg, const float *G, int d, int method, int *status);
 
 /* ---- device-resident index handle: codes uploaded once, searched many times -- on one device, or
  * row-sharded over the GPUs of a node from ONE host process (what a Julia session is).

@@ -69,10 +69,13 @@ SIGNATURES = {
     "rq_dev_reconstruct": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rq_dev_qerror": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "rq_dev_gram": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "rq_dev_gram_codes": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "rq_dev_qerror_codes": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rq_kmpp_seeds": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _u64]),
     "rq_train_pq": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _u64]),
     "rq_train_opq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _u64, _vp, _vp]),
     "rq_train_profile": (_i32, [_vp, _i32]),
+    "rq_dev_polar_factor": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "rq_index_create": (_vp, [_i32, _i32, _vp]),
     "rq_index_create_sharded": (_vp, [_i32, _i32, _vp, _vp, _i32]),
     "rq_index_set_codes": (_i32, [_vp, _vp, _i64, _u32]),
@@ -177,7 +180,7 @@ def result_empty(shape, dtype):
 
 
 TRAIN_PHASES = ["h2d_ms", "init_ms", "qerror_ms", "gram_ms", "svd_ms", "rotate_ms", "update_centers_ms", "encode_ms",
-                "reconstruct_ms", "converge_ms", "d2h_ms", "loop_ms", "iterations", "jacobi_sweeps"]
+                "reconstruct_ms", "converge_ms", "d2h_ms", "loop_ms", "iterations", "jacobi_sweeps", "ns_steps", "host_polar"]
 
 
 def train_profile():

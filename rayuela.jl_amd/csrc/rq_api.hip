@@ -1335,4 +1335,18 @@ int rq_dev_gram(float *G, const float *X, const float *CB, int64_t n, int d, voi
   return gram_launch(G, X, CB, n, d, di.num_cu, (hipStream_t)stream);
 }
 
+// the same two reductions with CB given as (codes, C) -- no n x d reconstruction (what the training loops run when the shape
+// allows 16-byte gathers: d % 4 == 0, sub-spaces on multiples of 4, gram: d <= 256; RQ_EUNSUPPORTED otherwise)
+int rq_dev_gram_codes(float *G, const float *X, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h, void *stream) {
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  return gram_codes_launch(G, X, codes, C, n, d, m, h, di.num_cu, (hipStream_t)stream);
+}
+
+int rq_dev_qerror_codes(double *acc, const float *X, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h, void *stream) {
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  return qerror_codes_launch(acc, X, codes, C, n, d, m, h, di.num_cu, (hipStream_t)stream);
+}
+
 }  // extern "C"

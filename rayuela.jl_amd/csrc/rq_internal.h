@@ -155,6 +155,13 @@ int qerror_launch(double *acc_dev, const float *X, const float *CB, int64_t n, i
 int kmpp_init_launch(float *C, long long *seeds, float *mincost, double *partial, const double *u, const float *X,
                      int64_t n, int d, int m, int h, hipStream_t stream);
 int polar_factor_launch(float *Rimg, const float *G, double *Vw, int warm, int d, int *status, double *scratch, hipStream_t stream);
+bool codes_forms_ok(int d, int m, int h, bool for_gram);
+int gram_codes_launch(float *G, const float *X, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h, int num_cu,
+                      hipStream_t stream);
+int qerror_codes_launch(double *acc_dev, const float *X, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h,
+                        int num_cu, hipStream_t stream);
+size_t polar_ns_scratch_bytes(int d, int num_cu);
+int polar_ns_launch(float *Rimg, const float *G, int d, int *status, void *scratch, int num_cu, hipStream_t stream);
 int codes_changed_launch(unsigned long long *out, const uint8_t *a, const uint8_t *b, size_t nbytes, hipStream_t stream);
 int gram_launch(float *G, const float *X, const float *CB, int64_t n, int d, int num_cu, hipStream_t stream);
 

@@ -95,6 +95,128 @@ __global__ __launch_bounds__(1024) void centers_partial_kernel(TrainParams p, in
   }
 }
 
+// ---- update_centers, pass 1, round 4: ONE WAVEFRONT per (row slice, 64-dimension chunk), LDS atomics in row order ----------
+// The kernel above makes all 1024 threads walk every row although only the 128 owners of the row's codes have work: 8 VALU
+// and 2 vector-memory instructions per row and wavefront, 16 wavefronts per row -- 0.81 ms at SIFT1M shape, 8 % of the HBM
+// roof.  Here a wavefront owns 64 dimensions for ALL codes (sums [h][64] = 64 KiB of LDS, two wavefronts per CU), and a row
+// costs it a quarter of a load instruction: lane l = 16 g + c loads the float4 of dimensions 4 c .. 4 c + 3 of row r + g, so
+// one 16-byte load instruction covers 4 rows and 32 of them (2 batches of 64 rows, 32 KiB) are in flight per wavefront --
+// with one dword per lane and row the 63-entry load counter caps a wavefront at 16 KiB, and the kernel is latency-bound at a
+// quarter of the rate.  The four lane groups then add their rows ONE GROUP AFTER THE OTHER (`ds_add_f32` without return, 16
+// active lanes, distinct addresses): LDS instructions of a wavefront execute in issue order, so every accumulator still
+// receives its rows in ascending order -- the SAME sums, bit for bit, as the kernel above (same slices; tests/test_gpu_train.py
+// compares the two).  The code bytes of a 64-row batch are fetched by one lane per row and passed through LDS.
+// Needs d % 4 == 0 and sub-spaces on multiples of 4 (a lane's four dimensions share their sub-quantizer).
+constexpr int CENTERS_B = 64;                     // rows per batch
+__global__ __launch_bounds__(64) void centers_stream_kernel(TrainParams p, int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int slice = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk, nslice = gridDim.x / nchunk;
+  const int dc0 = chunk * 64, dcw = min(64, p.d - dc0);
+  float *sums = reinterpret_cast<float *>(smem);                                      // [h][64]
+  unsigned int *cnts = reinterpret_cast<unsigned int *>(sums + (size_t)p.h * 64);    // [q - q0][h], q0 = sub-quantizer of dc0
+  int q0 = 0;
+  while (q0 + 1 < p.m && dc0 >= p.off[q0 + 1]) ++q0;
+  int q1 = q0;
+  while (q1 + 1 < p.m && dc0 + dcw - 1 >= p.off[q1 + 1]) ++q1;
+  const int nq = q1 - q0 + 1;
+  uint8_t *cs = reinterpret_cast<uint8_t *>(cnts + (size_t)nq * p.h);                 // [2][64][nq] code bytes of two batches
+  for (int i = lane; i < p.h * 64 + nq * p.h; i += 64) sums[i] = 0.0f;            // 0.0f and 0u share the bit pattern
+  const int64_t rows_per = (p.n + nslice - 1) / nslice;
+  const int64_t r0 = (int64_t)slice * rows_per, r1 = min(p.n, r0 + rows_per);
+  const bool live = 4 * c < dcw;
+  const int dim = dc0 + (live ? 4 * c : 0);
+  int q = q0;
+  while (q + 1 < p.m && dim >= p.off[q + 1]) ++q;
+  const bool counts_here = live && dim == p.off[q];
+  const float *xd = p.X + dim;
+  unsigned int *cnt_q = cnts + (size_t)(q - q0) * p.h;
+  float *mine = sums + 4 * c;
+  const int ql = q - q0;
+  float4 x[2][CENTERS_B / 4];
+  auto load = [&](int b, int64_t r) {
+    // code bytes: lane l fetches the nq bytes of row r + l
+    {
+      const int64_t rr = r + lane < r1 ? r + lane : r1 - 1;
+      const uint8_t *src = p.codes + rr * p.m + q0;
+      uint8_t *dst = cs + ((size_t)b * CENTERS_B + lane) * nq;
+      for (int k = 0; k < nq; ++k) dst[k] = src[k];
+    }
+#pragma unroll
+    for (int u = 0; u < CENTERS_B / 4; ++u) {
+      const int64_t rr = r + 4 * u + g < r1 ? r + 4 * u + g : r1 - 1;
+      x[b][u] = *reinterpret_cast<const float4 *>(xd + rr * p.d);
+    }
+  };
+  auto add = [&](int b, int64_t r) {
+    __syncthreads();                        // (one wavefront: orders the LDS code bytes written above with the reads below)
+    int code[CENTERS_B / 4];
+#pragma unroll
+    for (int u = 0; u < CENTERS_B / 4; ++u) code[u] = cs[((size_t)b * CENTERS_B + 4 * u + g) * nq + ql];
+#pragma unroll
+    for (int u = 0; u < CENTERS_B / 4; ++u) {
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) {
+        if (g == gg && live && r + 4 * u + gg < r1) {
+          float *dst = mine + code[u] * 64;
+          __hip_atomic_fetch_add(dst + 0, x[b][u].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(dst + 1, x[b][u].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(dst + 2, x[b][u].z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(dst + 3, x[b][u].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (counts_here) __hip_atomic_fetch_add(cnt_q + code[u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  };
+  __syncthreads();
+  if (r0 < r1) {
+    constexpr int B = CENTERS_B;
+    load(0, r0);
+    int64_t r = r0;
+    for (; r + 2 * B < r1; r += 2 * B) {
+      load(1, r + B);
+      add(0, r);
+      load(0, r + 2 * B);
+      add(1, r + B);
+    }
+    // here buffer 0 holds rows r .. r + B - 1
+    if (r + B < r1) { load(1, r + B); add(0, r); add(1, r + B); }
+    else add(0, r);
+  }
+  __syncthreads();
+  // partial layout per slice: [h][d] sums, then [m][h] counts (u32 bit patterns) -- as centers_partial_kernel writes it
+  float *out = p.partial + (size_t)slice * ((size_t)p.h * p.d + (size_t)p.m * p.h);
+  for (int i = lane; i < p.h * 16; i += 64) {
+    const int code = i >> 4, c4 = 4 * (i & 15);
+    if (c4 < dcw) *reinterpret_cast<float4 *>(out + (size_t)code * p.d + dc0 + c4) = *reinterpret_cast<const float4 *>(sums + code * 64 + c4);
+  }
+  unsigned int *oc = reinterpret_cast<unsigned int *>(out + (size_t)p.h * p.d);
+  for (int i = lane; i < nq * p.h; i += 64) {
+    const int qq = q0 + i / p.h;
+    if (p.off[qq] >= dc0 && p.off[qq] < dc0 + dcw) oc[(size_t)qq * p.h + i % p.h] = cnts[i];
+  }
+}
+
+// dst[i] = sum over the nparts slices of src[w * stride + i] in a FIXED order (16 interleaved groups of slices, then the 16
+// group sums in ascending order): the serial loop over 256-512 slices per element of round 3 took 70-140 us per call
+template <class T>
+__global__ __launch_bounds__(1024) void partials_reduce_kernel(T *__restrict__ dst, const T *__restrict__ src, size_t stride, int nparts, int count) {
+  __shared__ T red[16][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
+  T s = 0;
+  if (i < count)
+    for (int w = g; w < nparts; w += 16) s += src[(size_t)w * stride + i];
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < count) {
+    T t = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k][e];
+    dst[i] = t;
+  }
+}
+
 // pass 2: fixed-order sum over the workgroup partials, mean, write C (empty clusters keep their value)
 __global__ void centers_finish_kernel(TrainParams p, int nparts) {
   const int hd = p.h * p.d, mh = p.m * p.h;
@@ -218,12 +340,168 @@ __global__ __launch_bounds__(NWAVES * 64) void gram_partial_kernel(GramParams p)
   }
 }
 
-__global__ void gram_finish_kernel(GramParams p, int nparts) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.d * p.d) return;
-  float s = 0.0f;
-  for (int w = 0; w < nparts; ++w) s += p.partial[(size_t)w * p.d * p.d + i];
-  p.G[i] = s;
+
+// ---- round 4: G = X' CB and the objective WITHOUT the n x d reconstruction ---------------------------------------------
+// CB is a gather: CB[row][off_q + s] = C_q[b(row, q)][s].  Writing it (0.5 ms at SIFT1M shape) only to read it back twice
+// (gram, qerror) is HBM traffic the loop does not need: the two kernels below take (codes, C) instead.
+//   gram_codes   per stage of 32 rows the workgroup puts the X rows and the gathered CB rows into LDS (16-byte loads; the CB
+//                gather hits the L2-resident codebooks), then every wavefront runs its 32 x 32 output tiles over the stage:
+//                two conflict-free ds_read_b32 per v_mfma_f32_32x32x2_f32.  The round-3 kernel fetched both MFMA operands
+//                with strided global loads (2 vector-memory instructions per 64-cycle MFMA, every X column block read NT
+//                times): 0.99 ms = 21 % of the f32 matrix rate; the matrix pipe's floor for 2 d^2 n flop is 0.21 ms.
+//                The loads of stage s+1 (and the code bytes of stage s+2) are in flight while stage s is multiplied.
+//   qerror_codes sum (X - C[code])^2 in double, 16 bytes of X and one gather per thread and step
+// Both need d % 4 == 0 and sub-spaces that start and end on multiples of 4 (16-byte gathers); gram_codes needs d <= 256.
+// Other shapes keep reconstruct + the kernels above.
+struct CodesParams {
+  const float *X;        // [n][d]
+  const uint8_t *codes;  // [n][m]
+  const float *C;        // concat of [h][sub_q]
+  float *partial;        // gram: [grid][d*d]
+  double *dpartial;      // qerror: [grid]
+  int64_t n;
+  int d, m, h, NT;
+  int off[33];
+};
+
+__device__ __forceinline__ int codes_subq(const CodesParams &p, int dim) {
+  int q = 0;
+  while (q + 1 < p.m && dim >= p.off[q + 1]) ++q;
+  return q;
+}
+
+constexpr int GRAMC_ROWS = 32;
+
+template <int NWAVES, int TPW, int UPT>
+__global__ __launch_bounds__(NWAVES * 64) void gram_codes_kernel(CodesParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NTHREADS = NWAVES * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  const int d = p.d, NT = p.NT, ntile = NT * NT, ld = NT * 32, d4 = d >> 2;
+  float *Xs = reinterpret_cast<float *>(smem);          // [32][ld]
+  float *Hs = Xs + GRAMC_ROWS * ld;                     // [32][ld]
+  for (int i = tid; i < 2 * GRAMC_ROWS * ld; i += NTHREADS) Xs[i] = 0.0f;     // the padding columns stay zero
+  const int64_t rows_per = (((p.n + gridDim.x - 1) / gridDim.x) + GRAMC_ROWS - 1) / GRAMC_ROWS * GRAMC_ROWS;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(p.n, r0 + rows_per);
+  const int nstage = r1 > r0 ? (int)((r1 - r0 + GRAMC_ROWS - 1) / GRAMC_ROWS) : 0;
+  const int units = GRAMC_ROWS * d4;
+  // this thread's units of a stage: (row, 4 dimensions); their sub-quantizer and gather base never change
+  int urow[UPT], ucol[UPT], uq[UPT], ubase[UPT];
+#pragma unroll
+  for (int u = 0; u < UPT; ++u) {
+    const int e = tid + u * NTHREADS;
+    urow[u] = e < units ? e / d4 : -1;
+    ucol[u] = e < units ? 4 * (e % d4) : 0;
+    uq[u] = codes_subq(p, ucol[u]);
+    ubase[u] = p.h * p.off[uq[u]] + (ucol[u] - p.off[uq[u]]);      // + code * sub
+  }
+  int usub[UPT];
+#pragma unroll
+  for (int u = 0; u < UPT; ++u) usub[u] = p.off[uq[u] + 1] - p.off[uq[u]];
+  int cd[UPT];
+  float4 xv[UPT], hv[UPT];
+  auto load_codes = [&](int s) {
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      const int64_t row = r0 + (int64_t)s * GRAMC_ROWS + urow[u];
+      cd[u] = (urow[u] >= 0 && row < r1) ? (int)p.codes[row * p.m + uq[u]] : 0;
+    }
+  };
+  auto load_data = [&](int s) {
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      const int64_t row = r0 + (int64_t)s * GRAMC_ROWS + urow[u];
+      const bool in = urow[u] >= 0 && row < r1;
+      xv[u] = in ? *reinterpret_cast<const float4 *>(p.X + row * d + ucol[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      hv[u] = in ? *reinterpret_cast<const float4 *>(p.C + ubase[u] + cd[u] * usub[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  // the wavefront's tiles (wave-uniform, in SGPRs).  A wavefront without a tile in slot i multiplies tile 0 there and drops the
+  // result: the K loop stays free of branches (exec-masked MFMAs made the compiler copy the accumulators around every one)
+  int ta[TPW], tb[TPW];
+  bool tv[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = __builtin_amdgcn_readfirstlane(wave + i * NWAVES);
+    tv[i] = t < ntile;
+    ta[i] = tv[i] ? t / NT : 0;
+    tb[i] = tv[i] ? t % NT : 0;
+  }
+  if (nstage > 0) {
+    load_codes(0);
+    load_data(0);
+    if (nstage > 1) load_codes(1);
+  }
+  for (int s = 0; s < nstage; ++s) {
+    __syncthreads();                       // the previous stage has been multiplied (first trip: LDS zeroed)
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      if (urow[u] >= 0) {
+        *reinterpret_cast<float4 *>(Xs + urow[u] * ld + ucol[u]) = xv[u];
+        *reinterpret_cast<float4 *>(Hs + urow[u] * ld + ucol[u]) = hv[u];
+      }
+    }
+    __syncthreads();
+    if (s + 1 < nstage) {
+      load_data(s + 1);                    // cd holds the codes of stage s + 1, loaded one trip ago
+      if (s + 2 < nstage) load_codes(s + 2);
+    }
+    // 8 K steps at a time: all operands first, then the MFMAs back to back
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float av[TPW][8], bv[TPW][8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int ro = (2 * (8 * half + u) + hi) * ld + j;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) { av[i][u] = Xs[ro + 32 * ta[i]]; bv[i][u] = Hs[ro + 32 * tb[i]]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][u], bv[i][u], acc[i], 0, 0, 0);
+    }
+  }
+  float *out = p.partial + (size_t)blockIdx.x * d * d;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    if (!tv[i]) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ii = 32 * ta[i] + (r & 3) + 8 * (r >> 2) + 4 * hi, jj = 32 * tb[i] + j;
+      if (ii < d && jj < d) out[(size_t)ii * d + jj] = acc[i][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void qerror_codes_kernel(CodesParams p) {
+  __shared__ double red[256];
+  const int d4 = p.d >> 2;
+  const int64_t total = p.n * d4;
+  double s = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t row = e / d4;
+    const int col = 4 * (int)(e - row * d4);
+    const int q = codes_subq(p, col);
+    const int code = p.codes[row * p.m + q];
+    const float4 x = *reinterpret_cast<const float4 *>(p.X + row * p.d + col);
+    const float4 c = *reinterpret_cast<const float4 *>(p.C + (size_t)p.h * p.off[q] + (size_t)code * (p.off[q + 1] - p.off[q]) + (col - p.off[q]));
+    const double a0 = (double)x.x - (double)c.x, a1 = (double)x.y - (double)c.y, a2 = (double)x.z - (double)c.z, a3 = (double)x.w - (double)c.w;
+    s += a0 * a0; s += a1 * a1; s += a2 * a2; s += a3 * a3;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p.dpartial[blockIdx.x] = red[0];
 }
 
 // ---- kmeans++ seeding (D^2 sampling) ------------------------------------------------------------------------
@@ -412,6 +690,26 @@ static void fill_offsets(int *off, int d, int m) {
   off[m] = pos;
 }
 
+template <class T>
+static int partials_reduce(T *dst, const T *src, size_t stride, int nparts, int count, hipStream_t stream) {
+  hipLaunchKernelGGL(partials_reduce_kernel<T>, dim3((count + 63) / 64), dim3(1024), 0, stream, dst, src, stride, nparts, count);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+// slices [grid][h*d + m*h] -> one reduced slice behind them -> means
+static int centers_finish(TrainParams p, int grid, hipStream_t stream) {
+  const size_t hd = (size_t)p.h * p.d, mh = (size_t)p.m * p.h, stride = hd + mh;
+  float *red = p.partial + (size_t)grid * stride;
+  RQ_TRY(partials_reduce<float>(red, p.partial, stride, grid, (int)hd, stream));
+  RQ_TRY(partials_reduce<unsigned int>(reinterpret_cast<unsigned int *>(red + hd), reinterpret_cast<const unsigned int *>(p.partial + hd), stride,
+                                       grid, (int)mh, stream));
+  p.partial = red;
+  hipLaunchKernelGGL(centers_finish_kernel, dim3((p.h * p.d + 255) / 256), dim3(256), 0, stream, p, 1);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
 int update_centers_launch(float *C, unsigned int *counts, const float *X, const uint8_t *codes, int64_t n, int d,
                           int m, int h, int num_cu, hipStream_t stream) {
   if (n <= 0) return RQ_OK;
@@ -422,8 +720,21 @@ int update_centers_launch(float *C, unsigned int *counts, const float *X, const 
   fill_offsets(p.off, d, m);
   const int grid = (int)std::min<int64_t>(num_cu, (n + 1023) / 1024);
   void *part = nullptr;
-  RQ_TRY(workspace(WS_TMP, (size_t)grid * ((size_t)h * d + (size_t)m * h) * sizeof(float), &part, stream));
+  RQ_TRY(workspace(WS_TMP, (size_t)(grid + 1) * ((size_t)h * d + (size_t)m * h) * sizeof(float), &part, stream));
   p.partial = (float *)part;
+  bool aligned = (d & 3) == 0;
+  for (int q = 0; q <= m; ++q) aligned = aligned && (p.off[q] & 3) == 0;
+  if (aligned && tuning("TRAIN_CENTERS_STREAM", 1)) {
+    // one wavefront per (slice, 64-dimension chunk); the slices are the ones of the kernel below, so are the sums
+    const int nchunk = (d + 63) / 64;
+    const int nqmax = std::min(m, 16);         // sub-quantizers a 64-dimension chunk can touch (sub-spaces >= 4 wide)
+    const size_t lds = ((size_t)h * 64 + (size_t)nqmax * h) * sizeof(float) + (size_t)2 * CENTERS_B * nqmax;
+    RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(centers_stream_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(centers_stream_kernel, dim3(grid * nchunk), dim3(64), lds, stream, p, nchunk);
+    RQ_HIP(hipGetLastError());
+    return centers_finish(p, grid, stream);
+  }
   // dimension chunks of <= 128: h * 128 * 4 B of sums (+ m * h counters in the first chunk) always fit the LDS
   for (int dc0 = 0; dc0 < d; dc0 += 128) {
     const int dcw = std::min(128, d - dc0);
@@ -433,9 +744,7 @@ int update_centers_launch(float *C, unsigned int *counts, const float *X, const 
     hipLaunchKernelGGL(centers_partial_kernel, dim3(grid), dim3(1024), lds, stream, p, dc0, dcw);
     RQ_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(centers_finish_kernel, dim3((h * d + 255) / 256), dim3(256), 0, stream, p, grid);
-  RQ_HIP(hipGetLastError());
-  return RQ_OK;
+  return centers_finish(p, grid, stream);
 }
 
 int reconstruct_launch(float *CB, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h,
@@ -469,6 +778,72 @@ int qerror_launch(double *acc_dev, const float *X, const float *CB, int64_t n, i
   return RQ_OK;
 }
 
+// can the (codes, C) forms of gram / qerror serve this shape?  (16-byte gathers: every sub-space starts and ends on a multiple of 4)
+bool codes_forms_ok(int d, int m, int h, bool for_gram) {
+  if (!tuning("TRAIN_FUSED_CB", 1)) return false;
+  if (m < 1 || m > 32 || d < m || (d & 3) || h < 1 || h > 256) return false;
+  if (for_gram && d > 256) return false;
+  int off[33];
+  fill_offsets(off, d, m);
+  for (int q = 0; q <= m; ++q) if (off[q] & 3) return false;
+  return true;
+}
+
+static void fill_codes_params(CodesParams &p, const float *X, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h) {
+  p.X = X; p.codes = codes; p.C = C; p.partial = nullptr; p.dpartial = nullptr; p.n = n; p.d = d; p.m = m; p.h = h; p.NT = (d + 31) / 32;
+  fill_offsets(p.off, d, m);
+}
+
+template <int NW, int TPW, int UPT>
+static int gram_codes_run(CodesParams &p, int grid, size_t lds, hipStream_t stream) {
+  auto kern = gram_codes_kernel<NW, TPW, UPT>;
+  RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, p);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+// G = X' CB with CB given as (codes, C); codes_forms_ok(d, m, h, true) must hold
+int gram_codes_launch(float *G, const float *X, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h, int num_cu,
+                      hipStream_t stream) {
+  if (!codes_forms_ok(d, m, h, true)) return fail(RQ_EUNSUPPORTED, "gram_codes: d=%d m=%d h=%d", d, m, h);
+  CodesParams p;
+  fill_codes_params(p, X, codes, C, n, d, m, h);
+  const int ntile = p.NT * p.NT;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(2 * (int64_t)num_cu, (n + 255) / 256));
+  void *part = nullptr;
+  RQ_TRY(workspace(WS_TMP, (size_t)grid * d * d * sizeof(float), &part, stream));
+  p.partial = (float *)part;
+  const size_t lds = (size_t)2 * GRAMC_ROWS * p.NT * 32 * sizeof(float);
+  const int units = GRAMC_ROWS * (d / 4);
+  if (ntile <= 8) RQ_TRY((units <= 512 ? gram_codes_run<8, 1, 1> : gram_codes_run<8, 1, 2>)(p, grid, lds, stream));
+  else if (ntile <= 16) RQ_TRY((units <= 1024 ? gram_codes_run<8, 2, 2> : gram_codes_run<8, 2, 4>)(p, grid, lds, stream));
+  else if (ntile <= 32) RQ_TRY((gram_codes_run<8, 4, 4>)(p, grid, lds, stream));
+  else RQ_TRY((gram_codes_run<16, 4, 2>)(p, grid, lds, stream));
+  return partials_reduce<float>(G, p.partial, (size_t)d * d, grid, d * d, stream);
+}
+
+// acc = sum |X - CB|^2 with CB given as (codes, C); codes_forms_ok(d, m, h, false) must hold
+int qerror_codes_launch(double *acc_dev, const float *X, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h,
+                        int num_cu, hipStream_t stream) {
+  if (!codes_forms_ok(d, m, h, false)) return fail(RQ_EUNSUPPORTED, "qerror_codes: d=%d m=%d h=%d", d, m, h);
+  if (n <= 0) {
+    RQ_HIP(hipMemsetAsync(acc_dev, 0, sizeof(double), stream));
+    return RQ_OK;
+  }
+  CodesParams p;
+  fill_codes_params(p, X, codes, C, n, d, m, h);
+  const int grid = num_cu * 8;
+  void *part = nullptr;
+  RQ_TRY(workspace(WS_MERGE, (size_t)grid * sizeof(double), &part, stream));
+  p.dpartial = (double *)part;
+  hipLaunchKernelGGL(qerror_codes_kernel, dim3(grid), dim3(256), 0, stream, p);
+  RQ_HIP(hipGetLastError());
+  hipLaunchKernelGGL(qerror_finish_kernel, dim3(1), dim3(256), 0, stream, acc_dev, (const double *)part, grid);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
 int gram_launch(float *G, const float *X, const float *CB, int64_t n, int d, int num_cu, hipStream_t stream) {
   if (d < 1 || d > 1024) return fail(RQ_EUNSUPPORTED, "gram: d=%d", d);
   GramParams p;
@@ -480,9 +855,7 @@ int gram_launch(float *G, const float *X, const float *CB, int64_t n, int d, int
   p.partial = (float *)part;
   hipLaunchKernelGGL(gram_partial_kernel<NW>, dim3(grid), dim3(NW * 64), 0, stream, p);
   RQ_HIP(hipGetLastError());
-  hipLaunchKernelGGL(gram_finish_kernel, dim3((d * d + 255) / 256), dim3(256), 0, stream, p, grid);
-  RQ_HIP(hipGetLastError());
-  return RQ_OK;
+  return partials_reduce<float>(G, p.partial, (size_t)d * d, grid, d * d, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -674,6 +1047,201 @@ int polar_factor_launch(float *Rimg, const float *G, double *Vw, int warm, int d
   hipLaunchKernelGGL(polar_jacobi_kernel, dim3(1), dim3(POLAR_THREADS), lds, stream, AU, sv, d, status);
   hipLaunchKernelGGL(polar_vt_kernel, dim3(nb), dim3(256), 0, stream, Vw, (const double *)AU, G, (const double *)sv, d, (const int *)status);
   hipLaunchKernelGGL(polar_r_kernel, dim3(nb), dim3(256), 0, stream, Rimg, (const double *)AU, (const double *)Vw, d, (const int *)status);
+  RQ_HIP(hipGetLastError());
+  return RQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// The same polar factor by a SCALED NEWTON-SCHULZ iteration (round 4, the default; the Jacobi SVD above is its fallback).
+// The Jacobi sweeps are 127 latency-bound rounds each inside ONE workgroup: 1.74 ms of a 4.96 ms OPQ iteration.  The
+// orthogonal polar factor of G (= U V' of src/OPQ.jl:112-113 whenever G has full rank) needs no SVD:
+//      X_0 = G / |G|_F          (singular values in (0, 1])
+//      X_{k+1} = X_k (a_k I + b_k X_k' X_k),     a_k = 1.5 rho_k,  b_k = -0.5 rho_k^3,  rho_k^2 = 3 / (1 + l_k + l_k^2)
+// where l_k is a lower bound of the singular values of X_k (l_{k+1} = rho l (1.5 - 0.5 rho^2 l^2); Chen & Chow's scaling of
+// the cubic Newton-Schulz map g(y) = 1.5 y - 0.5 y^3: rho stretches [l, 1] so that both ends land on the same value).  Every
+// singular value in [0, 1] stays in [0, 1] for ANY l (g <= 1 on [0, sqrt 3]), so a wrong guess of l_0 only costs iterations;
+// small values grow by up to 2.6x per step instead of 1.5x, and from l ~ 1 on the map is the plain one with its quadratic
+// convergence.  Two d x d x d products in double per step, all matrix work spread over (d/16)^2 tiles: ONE persistent
+// launch of min(tiles, CUs) workgroups with a grid barrier (a monotone counter in global memory, agent-scope release /
+// acquire) between products -- every workgroup is resident (grid <= number of CUs), so the barrier cannot starve.
+// Convergence: |X'X - I|_F < 1e-9 (the same 1e-9 as the Jacobi's angle test; R is stored as f32), measured on the product
+// the step computes anyway; the per-workgroup parts are summed in a fixed order by everyone, so the iteration count -- and
+// with it every bit of R -- is reproducible.  status[0] = 1 when the iteration does not get there in `maxit` steps (a
+// singular G: the factor is not unique) or |G|_F is not a positive finite number: the caller falls back.
+// ------------------------------------------------------------------------------------------
+constexpr int NS_T = 16, NS_KC = 128, NS_THREADS = 256, NS_LDA = 17;
+
+struct NsParams {
+  const float *G;        // [d][d] row-major
+  double *X0, *X1, *Y;   // [d][d] each
+  double *part;          // [maxit + 1][nwg] per-workgroup parts of |X'X - I|_F^2
+  unsigned int *bar;     // barrier counter, zeroed before the launch
+  float *Rimg;           // Rimg[i * d + k] = R[k][i]
+  int *status;           // [0] 0 = R written, 1 = fall back; [1] steps taken
+  int d, maxit;
+  double l0, tol2;
+};
+
+__device__ __forceinline__ void ns_grid_barrier(unsigned int *bar, unsigned int &target, unsigned int nwg) {
+  // __syncthreads waits for every thread's stores to be acknowledged by the L2; thread 0 alone then releases (writes this XCD's
+  // L2 back: the XCDs have their own) and, after the wait, acquires (drops this CU's L1 and the stale L2 lines) for everybody
+  // -- the L1 is the CU's, so one invalidate serves all wavefronts of the workgroup.  (Fences by all 256 threads of all
+  // workgroups cost ~15 us per barrier.)
+  __syncthreads();
+  target += nwg;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+// sum of v over the workgroup, the same fixed tree everywhere
+__device__ __forceinline__ double ns_block_sum(double v, double *red) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  red[tid] = v;
+  __syncthreads();
+  for (int w = NS_THREADS / 2; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  return red[0];
+}
+
+// one 16 x 16 output tile: out(ti, tj) = sum_k A(k, ti) B(k, tj), k over the d rows in chunks of NS_KC through LDS.
+//   MODE 0 (Y = X'X):          A(k, c) = X[k][16 I + c]         B(k, c) = X[k][16 J + c]
+//   MODE 1 (X (a I + b Y)):    A(k, c) = X[16 I + c][k]         B(k, c) = b Y[k][16 J + c] + a [k == 16 J + c]   (Y is symmetric)
+template <int MODE>
+__device__ __forceinline__ double ns_tile(const double *__restrict__ X, const double *__restrict__ Y, int d, int I, int J, double a,
+                                          double b, double *As, double *Bs) {
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+  for (int k0 = 0; k0 < d; k0 += NS_KC) {
+    __syncthreads();
+    if (MODE == 0) {
+      const int c = tid & 15;
+      for (int k = tid >> 4; k < NS_KC; k += NS_THREADS / 16) {
+        const int kk = k0 + k;
+        As[k * NS_LDA + c] = (kk < d && 16 * I + c < d) ? X[(size_t)kk * d + 16 * I + c] : 0.0;
+        Bs[k * NS_T + c] = (kk < d && 16 * J + c < d) ? X[(size_t)kk * d + 16 * J + c] : 0.0;
+      }
+    } else {
+      const int k = tid & (NS_KC - 1);
+      for (int c = tid >> 7; c < NS_T; c += NS_THREADS / NS_KC)
+        As[k * NS_LDA + c] = (k0 + k < d && 16 * I + c < d) ? X[(size_t)(16 * I + c) * d + k0 + k] : 0.0;
+      const int c = tid & 15;
+      for (int kq = tid >> 4; kq < NS_KC; kq += NS_THREADS / 16) {
+        const int kk = k0 + kq, col = 16 * J + c;
+        double v = 0.0;
+        if (kk < d && col < d) v = __builtin_fma(b, Y[(size_t)kk * d + col], kk == col ? a : 0.0);
+        Bs[kq * NS_T + c] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < NS_KC; k += 4) {
+      acc0 = __builtin_fma(As[(k + 0) * NS_LDA + ti], Bs[(k + 0) * NS_T + tj], acc0);
+      acc1 = __builtin_fma(As[(k + 1) * NS_LDA + ti], Bs[(k + 1) * NS_T + tj], acc1);
+      acc2 = __builtin_fma(As[(k + 2) * NS_LDA + ti], Bs[(k + 2) * NS_T + tj], acc2);
+      acc3 = __builtin_fma(As[(k + 3) * NS_LDA + ti], Bs[(k + 3) * NS_T + tj], acc3);
+    }
+  }
+  return (acc0 + acc1) + (acc2 + acc3);
+}
+
+__global__ __launch_bounds__(NS_THREADS) void polar_ns_kernel(NsParams p) {
+  __shared__ double As[NS_KC * NS_LDA];
+  __shared__ double Bs[NS_KC * NS_T];
+  __shared__ double red[NS_THREADS];
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  const int d = p.d, T = (d + NS_T - 1) / NS_T, ntile = T * T;
+  const unsigned int nwg = gridDim.x, wg = blockIdx.x;
+  unsigned int target = 0;
+  // |G|_F^2, by every workgroup in the same order
+  double f = 0.0;
+  for (int e = tid; e < d * d; e += NS_THREADS) { const double g = (double)p.G[e]; f = __builtin_fma(g, g, f); }
+  const double fro2 = ns_block_sum(f, red);
+  if (!(fro2 > 0.0) || !(fro2 < 1.0e300)) {
+    if (wg == 0 && tid == 0) { p.status[0] = 1; p.status[1] = 0; }
+    return;
+  }
+  const double inv = 1.0 / sqrt(fro2);
+  for (int t = wg; t < ntile; t += nwg) {
+    const int i = NS_T * (t / T) + ti, j = NS_T * (t % T) + tj;
+    if (i < d && j < d) p.X0[(size_t)i * d + j] = (double)p.G[(size_t)i * d + j] * inv;
+  }
+  ns_grid_barrier(p.bar, target, nwg);
+  double *cur = p.X0, *nxt = p.X1;
+  double l = p.l0;
+  int it = 0, ok = 0;
+  for (;; ++it) {
+    double perr = 0.0;
+    for (int t = wg; t < ntile; t += nwg) {
+      const int I = t / T, J = t % T;
+      const double y = ns_tile<0>(cur, nullptr, d, I, J, 0.0, 0.0, As, Bs);
+      const int i = NS_T * I + ti, j = NS_T * J + tj;
+      if (i < d && j < d) {
+        p.Y[(size_t)i * d + j] = y;
+        const double dv = y - (i == j ? 1.0 : 0.0);
+        perr = __builtin_fma(dv, dv, perr);
+      }
+    }
+    const double mine = ns_block_sum(perr, red);
+    if (tid == 0) p.part[(size_t)it * nwg + wg] = mine;
+    ns_grid_barrier(p.bar, target, nwg);
+    double e = 0.0;
+    for (unsigned int w = tid; w < nwg; w += NS_THREADS) e += p.part[(size_t)it * nwg + w];
+    e = ns_block_sum(e, red);
+    if (e < p.tol2) { ok = 1; break; }
+    if (it >= p.maxit || !(e < 1.0e300)) break;
+    double a = 1.5, b = -0.5;
+    if (l < 1.0 - 1e-9) {
+      const double rho2 = 3.0 / (1.0 + l + l * l), rho = sqrt(rho2);
+      a = 1.5 * rho; b = -0.5 * rho * rho2;
+      l = rho * l * (1.5 - 0.5 * rho2 * l * l);
+      if (!(l < 1.0)) l = 1.0;
+    }
+    for (int t = wg; t < ntile; t += nwg) {
+      const int I = t / T, J = t % T;
+      const double x = ns_tile<1>(cur, p.Y, d, I, J, a, b, As, Bs);
+      const int i = NS_T * I + ti, j = NS_T * J + tj;
+      if (i < d && j < d) nxt[(size_t)i * d + j] = x;
+    }
+    ns_grid_barrier(p.bar, target, nwg);
+    double *tmp = cur; cur = nxt; nxt = tmp;
+  }
+  if (wg == 0 && tid == 0) { p.status[0] = ok ? 0 : 1; p.status[1] = it; }
+  if (!ok) return;
+  for (int t = wg; t < ntile; t += nwg) {
+    const int i = NS_T * (t / T) + ti, j = NS_T * (t % T) + tj;          // X[i][j] = R[i][j]  ->  Rimg[j * d + i]
+    if (i < d && j < d) p.Rimg[(size_t)j * d + i] = (float)cur[(size_t)i * d + j];
+  }
+}
+
+// scratch: polar_ns_scratch_bytes(d, num_cu) bytes; status two ints (read after the stream has drained)
+size_t polar_ns_scratch_bytes(int d, int num_cu) {
+  const int maxit = 96;
+  return ((size_t)3 * d * d + (size_t)(maxit + 2) * (size_t)std::max(1, num_cu)) * sizeof(double) + 64;
+}
+
+int polar_ns_launch(float *Rimg, const float *G, int d, int *status, void *scratch, int num_cu, hipStream_t stream) {
+  if (d < 1 || d > 1024) return fail(RQ_EUNSUPPORTED, "device polar factor: d <= 1024; got %d", d);
+  NsParams p;
+  const int T = (d + NS_T - 1) / NS_T;
+  const int nwg = std::max(1, std::min(T * T, num_cu));
+  p.G = G; p.Rimg = Rimg; p.status = status; p.d = d;
+  p.maxit = 96;
+  p.l0 = (double)tuning("TRAIN_NS_L0_MICRO", 1000) * 1e-6;
+  if (!(p.l0 > 0.0) || p.l0 > 1.0) p.l0 = 1e-3;
+  p.tol2 = 1e-18;
+  double *s = reinterpret_cast<double *>(scratch);
+  p.X0 = s; p.X1 = s + (size_t)d * d; p.Y = s + (size_t)2 * d * d;
+  p.part = s + (size_t)3 * d * d;
+  p.bar = reinterpret_cast<unsigned int *>(p.part + (size_t)(p.maxit + 2) * nwg);
+  RQ_HIP(hipMemsetAsync(p.bar, 0, 4, stream));
+  hipLaunchKernelGGL(polar_ns_kernel, dim3(nwg), dim3(NS_THREADS), 0, stream, p);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
 }

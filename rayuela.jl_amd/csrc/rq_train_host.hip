@@ -154,7 +154,7 @@ static void polar_factor(const double *G, double *out, int d, std::vector<double
 // recorded -- two device synchronisations per call; with tuning TRAIN_PROFILE = 1 every phase is bracketed by
 // synchronisations too, so the per-phase figures are exact and the loop total a little longer than an unprofiled run's.
 enum { TP_H2D = 0, TP_INIT, TP_QERROR, TP_GRAM, TP_SVD, TP_ROTATE, TP_CENTERS, TP_ENCODE, TP_RECONSTRUCT, TP_CONVERGE,
-       TP_D2H, TP_LOOP, TP_ITERS, TP_SWEEPS, TP_SLOTS = 16 };
+       TP_D2H, TP_LOOP, TP_ITERS, TP_SWEEPS, TP_NS_STEPS, TP_HOST_POLAR, TP_SLOTS = 16 };
 static thread_local double g_train_prof[TP_SLOTS];
 struct TrainProf {
   bool fine;
@@ -258,7 +258,7 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
   Rng rng{seed * 0x9E3779B97F4A7C15ull + 1};
   DevMem dX, dC, dcodes, dprev, dcnt, dCB, dacc, d16;
   RQ_TRY(dX.alloc((size_t)n * d * 4)); RQ_TRY(dC.alloc((size_t)h * d * 4)); RQ_TRY(dcodes.alloc((size_t)n * m));
-  RQ_TRY(dprev.alloc((size_t)n * m)); RQ_TRY(dcnt.alloc((size_t)m * h * 4)); RQ_TRY(dCB.alloc((size_t)n * d * 4));
+  RQ_TRY(dprev.alloc((size_t)n * m)); RQ_TRY(dcnt.alloc((size_t)m * h * 4));
   RQ_TRY(dacc.alloc(8)); RQ_TRY(d16.alloc((size_t)n * m * 2));
   TrainProf prof;
   RQ_PH(TP_H2D, RQ_HIP(hipMemcpy(dX.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice)));
@@ -296,8 +296,13 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
   }
   prof.loop_end(iters_done);
   RQ_PH(TP_ENCODE, RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr)));
-  RQ_PH(TP_RECONSTRUCT, RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr)));
-  RQ_PH(TP_QERROR, RQ_TRY(qerror_launch(dacc.as<double>(), dX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr)));
+  if (codes_forms_ok(d, m, h, false)) {
+    RQ_PH(TP_QERROR, RQ_TRY(qerror_codes_launch(dacc.as<double>(), dX.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr)));
+  } else {
+    RQ_TRY(dCB.alloc((size_t)n * d * 4));
+    RQ_PH(TP_RECONSTRUCT, RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr)));
+    RQ_PH(TP_QERROR, RQ_TRY(qerror_launch(dacc.as<double>(), dX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr)));
+  }
   RQ_TRY(widen_codes_launch(d16.as<int16_t>(), dcodes.as<uint8_t>(), n * m, nullptr));
   double acc = 0;
   RQ_HIP(hipMemcpy(&acc, dacc.p, 8, hipMemcpyDeviceToHost));
@@ -387,7 +392,10 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
   DevMem dX, dRX, dR, dC, dcodes, dcnt, dCB, dacc, dG, d16;
   RQ_TRY(dX.alloc((size_t)n * d * 4)); RQ_TRY(dRX.alloc((size_t)n * d * 4)); RQ_TRY(dR.alloc((size_t)d * d * 4));
   RQ_TRY(dC.alloc((size_t)h * d * 4)); RQ_TRY(dcodes.alloc((size_t)n * m)); RQ_TRY(dcnt.alloc((size_t)m * h * 4));
-  RQ_TRY(dCB.alloc((size_t)n * d * 4)); RQ_TRY(dacc.alloc(8)); RQ_TRY(dG.alloc((size_t)d * d * 4));
+  // CB = reconstruct(codes, C) is only materialised for shapes the (codes, C) forms of gram / qerror do not cover
+  const bool fused_cb = codes_forms_ok(d, m, h, true);
+  if (!fused_cb) RQ_TRY(dCB.alloc((size_t)n * d * 4));
+  RQ_TRY(dacc.alloc(8)); RQ_TRY(dG.alloc((size_t)d * d * 4));
   RQ_TRY(d16.alloc((size_t)n * m * 2));
   TrainProf prof;
   RQ_PH(TP_H2D, RQ_HIP(hipMemcpy(dX.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice)));
@@ -397,30 +405,46 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
   if (C0) RQ_HIP(hipMemcpy(dC.p, C0, (size_t)h * d * 4, hipMemcpyHostToDevice));
   else RQ_TRY(init_centers(dC.as<float>(), dRX.as<float>(), n, d, m, h, off, rng));
   RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dRX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
-  RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr));
+  if (!fused_cb) RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr));
   prof.stop(TP_INIT);
   std::vector<float> Gf((size_t)d * d);
   std::vector<double> Vwarm;   // empty on the first iteration: cold start
-  // the d x d polar factor on the device (rq_train.hip: polar_factor_kernel) for even d <= 128; the host Jacobi otherwise,
-  // and whenever the device kernel reports a vanishing singular value (the host code completes the basis there)
-  const bool dev_polar = tuning("TRAIN_GPU_POLAR", 1) && d >= 2 && d <= 128 && (d & 1) == 0;
-  DevMem dVw, dscr, dstat;
-  if (dev_polar) { RQ_TRY(dVw.alloc((size_t)d * d * 8)); RQ_TRY(dscr.alloc(((size_t)d * d + d) * 8)); RQ_TRY(dstat.alloc(8)); }
+  // the d x d polar factor on the device (rq_train.hip): scaled Newton-Schulz (any d <= 1024), then -- should it not converge:
+  // a singular G -- the one-sided Jacobi SVD (even d <= 128), then the host Jacobi, which completes the basis.
+  // TRAIN_GPU_POLAR: 0 = host only, 1 = the chain above, 2 = skip Newton-Schulz
+  const int polar_mode = tuning("TRAIN_GPU_POLAR", 1);
+  const bool dev_ns = polar_mode == 1 && d <= 1024;
+  const bool dev_polar = polar_mode != 0 && d >= 2 && d <= 128 && (d & 1) == 0;
+  DevMem dVw, dscr, dstat, dns;
+  RQ_TRY(dstat.alloc(8));
+  if (dev_polar) { RQ_TRY(dVw.alloc((size_t)d * d * 8)); RQ_TRY(dscr.alloc(((size_t)d * d + d) * 8)); }
+  if (dev_ns) RQ_TRY(dns.alloc(polar_ns_scratch_bytes(d, di.num_cu)));
   bool dev_warm = false;
   prof.loop_begin();
   for (int it = 0; it <= niter; ++it) {
     // objective |R CB - X|^2 / n == |CB - R'X|^2 / n (src/OPQ.jl:108)
     prof.start();
-    RQ_TRY(qerror_launch(dacc.as<double>(), dRX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr));
+    if (fused_cb) RQ_TRY(qerror_codes_launch(dacc.as<double>(), dRX.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
+    else RQ_TRY(qerror_launch(dacc.as<double>(), dRX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr));
     double acc = 0;
     RQ_HIP(hipMemcpy(&acc, dacc.p, 8, hipMemcpyDeviceToHost));
     prof.stop(TP_QERROR);
     if (obj) obj[it] = (float)(acc / (double)n);
-    // update R (src/OPQ.jl:112-113): G = X CB' on the device, polar factor on the host
-    RQ_PH(TP_GRAM, RQ_TRY(gram_launch(dG.as<float>(), dX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr)));
+    // update R (src/OPQ.jl:112-113): G = X CB' and its polar factor U V' on the device
+    prof.start();
+    if (fused_cb) RQ_TRY(gram_codes_launch(dG.as<float>(), dX.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
+    else RQ_TRY(gram_launch(dG.as<float>(), dX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr));
+    prof.stop(TP_GRAM);
     prof.start();
     int pstat = 1;
-    if (dev_polar) {
+    if (dev_ns) {
+      RQ_TRY(polar_ns_launch(dR.as<float>(), dG.as<float>(), d, dstat.as<int>(), dns.p, di.num_cu, nullptr));
+      int st2[2] = {1, 0};
+      RQ_HIP(hipMemcpy(st2, dstat.p, 8, hipMemcpyDeviceToHost));
+      pstat = st2[0];
+      g_train_prof[TP_NS_STEPS] += st2[1];
+    }
+    if (pstat != 0 && dev_polar) {
       RQ_TRY(polar_factor_launch(dR.as<float>(), dG.as<float>(), dVw.as<double>(), dev_warm ? 1 : 0, d, dstat.as<int>(),
                                  dscr.as<double>(), nullptr));
       int st2[2] = {1, 0};
@@ -436,13 +460,14 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
       for (int i = 0; i < d; ++i)
         for (int k = 0; k < d; ++k) Rh[(size_t)i * d + k] = (float)P[(size_t)k * d + i];
       RQ_HIP(hipMemcpy(dR.p, Rh.data(), (size_t)d * d * 4, hipMemcpyHostToDevice));
+      g_train_prof[TP_HOST_POLAR] += 1;
     }
     prof.stop(TP_SVD);
     RQ_PH(TP_ROTATE, RQ_TRY(rotate_launch(dRX.as<float>(), dR.as<float>(), dX.as<float>(), d, n, di.num_cu, nullptr)));
     RQ_PH(TP_CENTERS, RQ_TRY(update_centers_launch(dC.as<float>(), dcnt.as<unsigned int>(), dRX.as<float>(), dcodes.as<uint8_t>(), n, d,
                                  m, h, di.num_cu, nullptr)));
     RQ_PH(TP_ENCODE, RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dRX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr)));
-    RQ_PH(TP_RECONSTRUCT, RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr)));
+    if (!fused_cb) RQ_PH(TP_RECONSTRUCT, RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr)));
   }
   prof.loop_end(niter + 1);
   RQ_TRY(widen_codes_launch(d16.as<int16_t>(), dcodes.as<uint8_t>(), n * m, nullptr));
@@ -455,10 +480,36 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
   return RQ_OK;
 }
 
+// Rimg[i * d + k] = R[k][i], R = U V' of the d x d matrix G (row-major) -- the rotation update of src/OPQ.jl:112-113 on the
+// device.  method 0: scaled Newton-Schulz (d <= 1024), 1: one-sided Jacobi SVD (even d <= 128).  status[0] = 0 when Rimg was
+// written, 1 when the method gave up (rank-deficient G: rq_train_opq then falls back); status[1] = steps / sweeps.  Synchronous.
+int rq_dev_polar_factor(float *Rimg, const float *G, int d, int method, int *status_host) {
+  if (!Rimg || !G || !status_host) return fail(RQ_EINVAL, "rq_dev_polar_factor: null pointer");
+  DeviceInfo di;
+  RQ_TRY(device_info(&di));
+  DevMem dstat, dscr, dVw;
+  RQ_TRY(dstat.alloc(8));
+  RQ_HIP(hipMemset(dstat.p, 0, 8));
+  if (method == 0) {
+    RQ_TRY(dscr.alloc(polar_ns_scratch_bytes(d, di.num_cu)));
+    RQ_TRY(polar_ns_launch(Rimg, G, d, dstat.as<int>(), dscr.p, di.num_cu, nullptr));
+  } else if (method == 1) {
+    if (d < 2 || d > 128 || (d & 1)) return fail(RQ_EUNSUPPORTED, "rq_dev_polar_factor: Jacobi needs an even d <= 128");
+    RQ_TRY(dscr.alloc(((size_t)d * d + d) * 8));
+    RQ_TRY(dVw.alloc((size_t)d * d * 8));
+    RQ_TRY(polar_factor_launch(Rimg, G, dVw.as<double>(), 0, d, dstat.as<int>(), dscr.as<double>(), nullptr));
+  } else {
+    return fail(RQ_EINVAL, "rq_dev_polar_factor: method %d", method);
+  }
+  RQ_HIP(hipMemcpy(status_host, dstat.p, 8, hipMemcpyDeviceToHost));
+  return RQ_OK;
+}
+
 // Phase clock of the calling thread's last rq_train_pq / rq_train_opq call, milliseconds:
 //   [0] X upload  [1] initialisation (seeding / first rotation + encode)  [2] qerror  [3] gram X'CB  [4] host SVD incl. its
 //   two small copies  [5] rotation  [6] update_centers  [7] encode  [8] reconstruct  [9] convergence check  [10] results D2H
-//   [11] wall time of the iteration loop  [12] iterations run.  [2]-[9] are filled with tuning TRAIN_PROFILE = 1 only.
+//   [11] wall time of the iteration loop  [12] iterations run  [13] Jacobi sweeps  [14] Newton-Schulz steps  [15] polar factors
+//   that fell back to the host.  [2]-[9] are filled with tuning TRAIN_PROFILE = 1 only.
 int rq_train_profile(double *out, int cap) {
   if (!out || cap < 1) return fail(RQ_EINVAL, "rq_train_profile: bad arguments");
   for (int i = 0; i < cap && i < TP_SLOTS; ++i) out[i] = g_train_prof[i];

@@ -35,6 +35,19 @@ def encode_pq_filter_w(X, Ccat, m, h):
     return out, W
 
 
+def polar_factor(G, method=0):
+    """R = U V' of the d x d matrix G (src/OPQ.jl:112-113) -> (R as a torch [d][d] tensor with R[k][i] = Julia's R[k, i],
+    ok, steps).  method 0 = Newton-Schulz, 1 = Jacobi SVD."""
+    import ctypes
+    d = G.shape[0]
+    Rimg = torch.empty((d, d), dtype=torch.float32, device=G.device)
+    st = (ctypes.c_int * 2)()
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().rq_dev_polar_factor(Rimg.data_ptr(), _chk(G, torch.float32, "G"), d, method,
+                                              ctypes.cast(st, ctypes.c_void_p)))
+    return Rimg.t().contiguous(), st[0] == 0, int(st[1])
+
+
 def rotate_T(R, X, out=None):
     n, d = X.shape
     out = torch.empty_like(X) if out is None else out
@@ -226,6 +239,26 @@ def qerror(X, CB):
     _lib.check(_lib.lib().rq_dev_qerror(acc.data_ptr(), _chk(X, torch.float32, "X"), _chk(CB, torch.float32, "CB"),
                                         n, d, _stream()))
     return float(acc.item()) / n
+
+
+def qerror_codes(X, codes, Ccat, h):
+    """mean_j |X_j - CB_j|^2 with CB given as (codes, C): no n x d reconstruction."""
+    n, d = X.shape
+    m = codes.shape[1]
+    acc = torch.zeros((1,), dtype=torch.float64, device=X.device)
+    _lib.check(_lib.lib().rq_dev_qerror_codes(acc.data_ptr(), _chk(X, torch.float32, "X"), _chk(codes, torch.uint8, "codes"),
+                                              _chk(Ccat, torch.float32, "C"), n, d, m, h, _stream()))
+    return float(acc.item()) / n
+
+
+def gram_codes(X, codes, Ccat, h):
+    """G = X' CB with CB given as (codes, C)."""
+    n, d = X.shape
+    m = codes.shape[1]
+    G = torch.empty((d, d), dtype=torch.float32, device=X.device)
+    _lib.check(_lib.lib().rq_dev_gram_codes(G.data_ptr(), _chk(X, torch.float32, "X"), _chk(codes, torch.uint8, "codes"),
+                                            _chk(Ccat, torch.float32, "C"), n, d, m, h, _stream()))
+    return G
 
 
 def gram(X, CB):

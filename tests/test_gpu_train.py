@@ -229,3 +229,162 @@ def test_results_survive_an_hdf5_round_trip(rq, tmp_path):
     assert np.array_equal(rq.quantize_opq(Xb, R2, C2), B_base)
     d2, i2 = rq.linscan_opq(Bb2, Xq, C2, 8 * m, R2, knn)
     assert np.array_equal(i2, idx) and np.array_equal(d2.view(np.uint32), dists.view(np.uint32))
+
+
+def _polar_ref(G):
+    U, s, Vt = np.linalg.svd(G.astype(np.float64))
+    return U @ Vt, s
+
+
+def _polar_cases(d, rng):
+    Q1, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    Q2, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    yield "gaussian", rng.standard_normal((d, d))
+    yield "kappa1e6", Q1 @ np.diag(np.logspace(0, -6, d)) @ Q2
+    yield "pca_like", (Q1 * (1.0 / (1.0 + np.arange(d)) ** 1.5)) @ Q1.T * 3.0e7      # a covariance: symmetric, fast decay, big norm
+    yield "flat", Q1 * 1e-5                                                          # all singular values equal, tiny norm
+    yield "orthogonal_already", Q2
+
+
+@pytest.mark.parametrize("d", [2, 6, 30, 96, 128, 130, 200])
+def test_device_polar_factor_matches_the_svd(rq, d):
+    """src/OPQ.jl:112-113: U, S, VV = svd(X * CB'); R = U * VV'.  The Newton-Schulz kernel (what rq_train_opq runs) and the
+    Jacobi kernel against LAPACK's SVD in float64: |R - U V'| <= 1e-6 (f32 storage of R and of G; the factor's condition
+    number is 1 / sigma_min, so the ill-conditioned case gets a tolerance scaled by it), R orthogonal to f32 rounding."""
+    import torch
+    from rayuela_jl_amd import device as rqd
+    rng = np.random.default_rng(d)
+    for name, G in _polar_cases(d, rng):
+        G32 = np.ascontiguousarray(G, dtype=np.float32)
+        P, s = _polar_ref(G32)
+        tol = max(2e-6, 4e-7 * s[0] / s[-1] * 0.01) if name != "kappa1e6" else 5e-2
+        for method in ([0, 1] if (d % 2 == 0 and d <= 128) else [0]):
+            R, ok, steps = rqd.polar_factor(torch.from_numpy(G32).cuda(), method)
+            assert ok, (name, d, method, steps)
+            R = R.cpu().numpy().astype(np.float64)
+            assert np.abs(R @ R.T - np.eye(d)).max() < 5e-7 * max(1, d ** 0.5), (name, d, method)
+            assert np.abs(R - P).max() < tol, (name, d, method, steps, np.abs(R - P).max())
+            if method == 0:
+                assert steps <= (60 if name == "kappa1e6" else 30), (name, d, steps)
+
+
+def test_device_polar_factor_gives_up_on_a_singular_matrix_and_training_falls_back(rq):
+    """A rank-deficient G has no unique polar factor: the Newton-Schulz iteration cannot converge and says so (status 1);
+    rq_train_opq then takes the Jacobi / host path (which completes the basis) -- a base with a constant dimension does that
+    from the first iteration on."""
+    import torch
+    from rayuela_jl_amd import device as rqd
+    from rayuela_jl_amd import _lib
+    rng = np.random.default_rng(3)
+    G = rng.standard_normal((64, 64)).astype(np.float32)
+    G[:, 5] = 0.0
+    R, ok, steps = rqd.polar_factor(torch.from_numpy(G).cuda(), 0)
+    assert not ok
+    R, ok, steps = rqd.polar_factor(torch.zeros((64, 64), device="cuda"), 0)
+    assert not ok and steps == 0
+    import rayuela_jl_amd.synth as synth
+    X = synth.deep_like(5000, 32, seed=4)
+    X[:, 7] = 0.0
+    C, B, Rm, obj = rq.train_opq(X, 4, 16, 3, "natural", seed=1)
+    prof = _lib.train_profile()
+    assert prof["host_polar"] + prof["jacobi_sweeps"] > 0
+    assert np.abs(Rm @ Rm.T - np.eye(32)).max() < 1e-5
+    assert (np.diff(obj) <= 1e-5 * obj[:-1]).all()
+
+
+def test_train_opq_newton_schulz_and_jacobi_agree(rq):
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import _lib
+    X = synth.sift_like(30000, 64, seed=9)
+    a = rq.train_opq(X, 8, 64, 5, "natural", seed=2)
+    pa = _lib.train_profile()
+    assert pa["ns_steps"] > 0 and pa["jacobi_sweeps"] == 0 and pa["host_polar"] == 0
+    rq.set_tuning("TRAIN_GPU_POLAR", 2)
+    try:
+        b = rq.train_opq(X, 8, 64, 5, "natural", seed=2)
+        pb = _lib.train_profile()
+    finally:
+        rq.set_tuning("TRAIN_GPU_POLAR", 1)
+    assert pb["ns_steps"] == 0 and pb["jacobi_sweeps"] > 0
+    assert np.abs(a[2] - b[2]).max() < 2e-3               # the rotations (chaotic over iterations: codes flip on 1e-7 differences)
+    assert np.allclose(a[3], b[3], rtol=2e-4)             # the objective curves
+
+
+@pytest.mark.parametrize("n,d,m,h", [(50_000, 128, 8, 256), (20_001, 96, 16, 256), (7_000, 64, 8, 64), (3_003, 30, 5, 17),
+                                     (70_000, 200, 4, 256), (999, 8, 8, 256), (40_000, 130, 2, 100)])
+def test_update_centers_stream_kernel_is_bit_identical(rq, n, d, m, h):
+    """The one-wavefront-per-chunk kernel (LDS atomics issued in row order) and the round-3 owner-thread kernel add the same
+    rows to the same accumulators in the same order: identical centres and counts, and both within 1e-5 of float64."""
+    import torch
+    from rayuela_jl_amd import device as rqd
+    from oracle import train_oracle as to
+    rng = np.random.default_rng(n + d)
+    X = (rng.standard_normal((n, d)) * 30).astype(np.float32)
+    codes = rng.integers(0, h, (n, m), dtype=np.uint8)
+    codes[:, 0] = np.minimum(codes[:, 0], h // 2)            # leaves empty clusters: they keep their value
+    off = to.offsets(d, m)
+    C0 = rng.standard_normal(h * d).astype(np.float32)
+    Xd, cd = torch.from_numpy(X).cuda(), torch.from_numpy(codes).cuda()
+    outs = []
+    for stream in (1, 0):
+        rq.set_tuning("TRAIN_CENTERS_STREAM", stream)
+        try:
+            Cd = torch.from_numpy(C0.copy()).cuda()
+            cnt = rqd.update_centers(Cd, Xd, cd, m, h)
+            outs.append((Cd.cpu().numpy(), cnt.cpu().numpy()))
+        finally:
+            rq.set_tuning("TRAIN_CENTERS_STREAM", 1)
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    # against float64
+    pos = 0
+    for q in range(m):
+        sub = off[q + 1] - off[q]
+        Cq = C0[pos:pos + h * sub].reshape(h, sub).astype(np.float64).copy()
+        cnt = np.bincount(codes[:, q], minlength=h)
+        sums = np.zeros((h, sub))
+        np.add.at(sums, codes[:, q], X[:, off[q]:off[q + 1]].astype(np.float64))
+        Cq[cnt > 0] = sums[cnt > 0] / cnt[cnt > 0, None]
+        got = outs[0][0][pos:pos + h * sub].reshape(h, sub)
+        assert np.allclose(got, Cq, rtol=1e-5, atol=1e-4), q
+        assert np.array_equal(outs[0][1][q], cnt)
+        pos += h * sub
+
+
+@pytest.mark.parametrize("n,d,m,h", [(30_000, 128, 8, 256), (20_001, 96, 8, 256), (5_000, 64, 8, 64), (12_345, 160, 4, 100),
+                                     (9_000, 256, 8, 256), (7_777, 32, 2, 16), (100, 8, 2, 4), (31, 128, 8, 256)])
+def test_gram_and_qerror_from_codes_match_the_reconstructed_forms(rq, n, d, m, h):
+    """gram_codes / qerror_codes gather CB[j] = C[codes[j]] inside the kernel (src/OPQ.jl:101,108,112 without the n x d
+    temporary): against float64 on the explicitly reconstructed CB, 1e-5 relative (f32 accumulation in another order)."""
+    import torch
+    from rayuela_jl_amd import device as rqd
+    from oracle import train_oracle as to
+    rng = np.random.default_rng(n + d + m)
+    X = (rng.standard_normal((n, d)) * 20 + 3).astype(np.float32)
+    codes = rng.integers(0, h, (n, m), dtype=np.uint8)
+    off = to.offsets(d, m)
+    C = [rng.standard_normal((h, off[q + 1] - off[q])).astype(np.float32) * 20 for q in range(m)]
+    Ccat = np.concatenate([c.reshape(-1) for c in C])
+    CB = to.reconstruct(C, codes, off, d)
+    Xd, cd, Cd = torch.from_numpy(X).cuda(), torch.from_numpy(codes).cuda(), torch.from_numpy(Ccat).cuda()
+    G0 = X.astype(np.float64).T @ CB.astype(np.float64)
+    G = rqd.gram_codes(Xd, cd, Cd, h).cpu().numpy()
+    assert np.allclose(G, G0, rtol=1e-5, atol=1e-5 * np.abs(G0).max())
+    e0 = ((X.astype(np.float64) - CB) ** 2).sum() / n
+    assert abs(rqd.qerror_codes(Xd, cd, Cd, h) - e0) <= 1e-9 * e0
+    # and the reconstructed forms agree with them
+    CBd = rqd.reconstruct(cd, Cd, d, h)
+    assert np.allclose(rqd.gram(Xd, CBd).cpu().numpy(), G, rtol=1e-5, atol=1e-5 * np.abs(G0).max())
+    assert abs(rqd.qerror(Xd, CBd) - e0) <= 1e-9 * e0
+
+
+def test_codes_forms_refuse_shapes_without_aligned_subspaces(rq):
+    import torch
+    from rayuela_jl_amd import device as rqd
+    X = torch.zeros((100, 30), device="cuda")
+    codes = torch.zeros((100, 5), dtype=torch.uint8, device="cuda")
+    C = torch.zeros((16 * 30,), device="cuda")
+    with pytest.raises(Exception):
+        rqd.gram_codes(X, codes, C, 16)
+    with pytest.raises(Exception):
+        rqd.qerror_codes(X, codes, C, 16)
