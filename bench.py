@@ -216,6 +216,12 @@ def train_bench(a):
         else:
             ach = work / t / GB
             roofs[k[:-3]] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+    if "update_centers" in roofs:
+        # the segment sums run as one-hot products on the bf16 matrix cores (csrc/rq_train.hip: centers_mfma_kernel): 4 MFMAs
+        # of 16 x 16 x 32 per (32 rows, 16-dimension block, 16-code tile); the HBM roof above is the algorithmic one
+        units = sum((sz + 15) // 16 for sz in [d // m + (1 if i < d % m else 0) for i in range(m)])
+        mf = 4 * 2.0 * 16 * 16 * 32 * ((h + 15) // 16) * units * (n / 32.0) / (per_iter["update_centers_ms"] * 1e-3) / 1e12
+        roofs["update_centers"]["bf16_mfma"] = {"issued_TFLOPs": round(mf, 1), "peak": 2500.0, "frac": round(mf / 2500.0, 4)}
     if "encode" in roofs:
         # the assignment step is the split encode kernel: its products run as a FILTER on the bf16 matrix cores (3 K = 16 MFMAs per
         # 32 x 32 tile at sub = 16), so the f32 matrix peak is a yardstick (frac may pass 1); the issued bf16 work is priced too

@@ -197,6 +197,142 @@ __global__ __launch_bounds__(64) void centers_stream_kernel(TrainParams p, int n
   }
 }
 
+// ---- update_centers, pass 1 on the MATRIX CORES (round 4, the default) ---------------------------------------------------
+// Measured on the two kernels above: 0.78-0.81 ms at SIFT1M shape whichever way the rows are walked, because the LDS
+// read-modify-write is the bound (`ds_add_f32`: ~3.4 cycles per lane and CU; without the adds the streaming kernel needs
+// 0.34 ms, without its loads 0.78).  A segment sum is also a product with a one-hot matrix,
+//      sums_q[code][s] = sum_rows [b(row, q) == code] x[row][off_q + s],
+// and one-hot entries and products are EXACT in bf16 arithmetic if x is split into three bf16 pieces (8 + 8 + 8 mantissa
+// bits: x = p1 + p2 + p3 exactly), so v_mfma_f32_16x16x32_bf16 adds exactly the f32 values the scatter would add -- in the
+// matrix core's fixed order: deterministic, no atomics, no LDS.  Per (32 rows, sub-quantizer, 16-code tile): one A operand
+// (16 codes x 32 rows of 0 / 2: a row keeps the 16-bit mask 1 << (code >> 4) if its code's low nibble is the lane's, and
+// tile t's entry is that mask's bit t moved to bit 14 -- the bf16 number 2.0 -- by one shift and one AND per register: 8
+// VALU instructions per tile; compare + select + pack took 24 and bound the kernel; the factor 2 is taken out exactly at
+// the end) and four MFMAs (the three pieces of the 32 x 16 block of x, and a column of ones that counts the rows).  A wavefront owns one
+// (sub-quantizer, 16-dimension block) for all codes: 16 + 16 accumulator tiles = 128 VGPRs; a workgroup = 8 such units over
+// one row slice, blockIdx.y = further units.  Matrix time at SIFT1M shape: 64 MFMAs x 16 cycles per 32 rows and unit = 0.10 ms.
+// Non-finite or > 3.3e38 inputs turn into NaN in EVERY centre of their sub-space (0 x inf), not only in their own.
+typedef __bf16 cm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short cm_u16x2 __attribute__((ext_vector_type(2)));
+using f32x4 = float __attribute__((ext_vector_type(4)));
+using f32x2t = float __attribute__((ext_vector_type(2)));
+
+template <int NT>
+__global__ __launch_bounds__(512) void centers_mfma_kernel(TrainParams p, int nunits) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int unit = blockIdx.y * 8 + wave;
+  if (unit >= nunits) return;                 // (no barriers in this kernel)
+  int q = 0, cb = 0;
+  {
+    int before = 0;
+    for (q = 0; q < p.m; ++q) {
+      const int nb = (p.off[q + 1] - p.off[q] + 15) >> 4;
+      if (unit < before + nb) { cb = unit - before; break; }
+      before += nb;
+    }
+  }
+  const int sub = p.off[q + 1] - p.off[q], col0 = p.off[q] + 16 * cb, width = min(16, sub - 16 * cb);
+  const int i = lane & 15, kg = lane >> 4;
+  const int nslice = gridDim.x;
+  const int64_t rows_per = (p.n + nslice - 1) / nslice;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(p.n, r0 + rows_per);
+  f32x4 acc[NT], cnt[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cnt[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const bool colok = i < width;
+  const float *xb = p.X + col0 + (colok ? i : 0);
+  const uint8_t *cq = p.codes + q;
+  const uint32_t ones = i == 0 ? 0x3F803F80u : 0u;
+  const cm_bf16x8 Bc = __builtin_bit_cast(cm_bf16x8, make_uint4(ones, ones, ones, ones));
+  uint32_t cr[2][2][8];
+  float xr[2][2][8];
+  auto load = [&](int b, int64_t r) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t row = r + 32 * s + 8 * kg + u;
+        const int64_t rr = row < r1 ? row : r1 - 1;
+        cr[b][s][u] = cq[rr * p.m];
+        xr[b][s][u] = xb[rr * p.d];
+      }
+  };
+  auto step = [&](int b, int s, int64_t r) {
+    // A side: mask of row u = 1 << (code >> 4) if the code's low nibble is this lane's (and the row exists), else 0
+    uint32_t K[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      uint32_t k2[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int u = 2 * pp + e;
+        const uint32_t c = cr[b][s][u];
+        const bool hit = (c & 15u) == (uint32_t)i && r + 32 * s + 8 * kg + u < r1;
+        k2[e] = hit ? (1u << (c >> 4)) : 0u;
+      }
+      K[pp] = k2[0] | (k2[1] << 16);
+    }
+    // B side: the lane's 8 values of x in three bf16 pieces (exact: 8 + 8 + 8 mantissa bits)
+    uint32_t P1[4], P2[4], P3[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      f32x2t v = {colok ? xr[b][s][2 * pp] : 0.0f, colok ? xr[b][s][2 * pp + 1] : 0.0f};
+      const cm_bf16x2 h1 = __builtin_convertvector(v, cm_bf16x2);
+      v = v - __builtin_convertvector(h1, f32x2t);
+      const cm_bf16x2 h2 = __builtin_convertvector(v, cm_bf16x2);
+      v = v - __builtin_convertvector(h2, f32x2t);
+      const cm_bf16x2 h3 = __builtin_convertvector(v, cm_bf16x2);
+      P1[pp] = __builtin_bit_cast(uint32_t, h1);
+      P2[pp] = __builtin_bit_cast(uint32_t, h2);
+      P3[pp] = __builtin_bit_cast(uint32_t, h3);
+    }
+    const cm_bf16x8 B1 = __builtin_bit_cast(cm_bf16x8, make_uint4(P1[0], P1[1], P1[2], P1[3]));
+    const cm_bf16x8 B2 = __builtin_bit_cast(cm_bf16x8, make_uint4(P2[0], P2[1], P2[2], P2[3]));
+    const cm_bf16x8 B3 = __builtin_bit_cast(cm_bf16x8, make_uint4(P3[0], P3[1], P3[2], P3[3]));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      // bit t of each 16-bit mask -> bit 14 of its half = bf16 2.0.  (A 32-bit shift serves both halves: a left shift by
+      // 14 - t <= 14 moves no bit of the low half up to bit 30.)
+      uint32_t a[4];
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) a[pp] = (t <= 14 ? K[pp] << (14 - t) : K[pp] >> 1) & 0x40004000u;
+      const cm_bf16x8 A = __builtin_bit_cast(cm_bf16x8, make_uint4(a[0], a[1], a[2], a[3]));
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B1, acc[t], 0, 0, 0);
+      cnt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bc, cnt[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B2, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B3, acc[t], 0, 0, 0);
+    }
+  };
+  if (r0 < r1) {
+    load(0, r0);
+    for (int64_t r = r0; r < r1; r += 128) {
+      if (r + 64 < r1) load(1, r + 64);
+      step(0, 0, r);
+      if (r + 32 < r1) step(0, 1, r);
+      if (r + 64 < r1) {
+        if (r + 128 < r1) load(0, r + 128);
+        step(1, 0, r + 64);
+        if (r + 96 < r1) step(1, 1, r + 64);
+      }
+    }
+  }
+  // D tile t: lane (i, kg) holds codes 16 t + 4 kg + r (r = 0..3) of column i
+  float *out = p.partial + (size_t)blockIdx.x * ((size_t)p.h * p.d + (size_t)p.m * p.h);
+  unsigned int *oc = reinterpret_cast<unsigned int *>(out + (size_t)p.h * p.d);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int code = 16 * t + 4 * kg + r;
+      if (code < p.h) {                      // (the one-hot entries were 2.0: halve, exactly)
+        if (colok) out[(size_t)code * p.d + col0 + i] = 0.5f * acc[t][r];
+        if (cb == 0 && i == 0) oc[(size_t)q * p.h + code] = (unsigned int)(0.5f * cnt[t][r] + 0.5f);
+      }
+    }
+  }
+}
+
 // dst[i] = sum over the nparts slices of src[w * stride + i] in a FIXED order (16 interleaved groups of slices, then the 16
 // group sums in ascending order): the serial loop over 256-512 slices per element of round 3 took 70-140 us per call
 template <class T>
@@ -372,13 +508,18 @@ __device__ __forceinline__ int codes_subq(const CodesParams &p, int dim) {
 
 constexpr int GRAMC_ROWS = 32;
 
-template <int NWAVES, int TPW, int UPT>
+template <int W> struct VecW;
+template <> struct VecW<4> { using T = float4; static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); } };
+template <> struct VecW<2> { using T = float2; static __device__ __forceinline__ T zero() { return make_float2(0.f, 0.f); } };
+
+template <int NWAVES, int TPW, int UPT, int W>
 __global__ __launch_bounds__(NWAVES * 64) void gram_codes_kernel(CodesParams p) {
+  using V = typename VecW<W>::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NTHREADS = NWAVES * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hi = lane >> 5;
-  const int d = p.d, NT = p.NT, ntile = NT * NT, ld = NT * 32, d4 = d >> 2;
+  const int d = p.d, NT = p.NT, ntile = NT * NT, ld = NT * 32, d4 = d / W;      // d4: W-wide units per row
   float *Xs = reinterpret_cast<float *>(smem);          // [32][ld]
   float *Hs = Xs + GRAMC_ROWS * ld;                     // [32][ld]
   for (int i = tid; i < 2 * GRAMC_ROWS * ld; i += NTHREADS) Xs[i] = 0.0f;     // the padding columns stay zero
@@ -392,7 +533,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gram_codes_kernel(CodesParams p) 
   for (int u = 0; u < UPT; ++u) {
     const int e = tid + u * NTHREADS;
     urow[u] = e < units ? e / d4 : -1;
-    ucol[u] = e < units ? 4 * (e % d4) : 0;
+    ucol[u] = e < units ? W * (e % d4) : 0;
     uq[u] = codes_subq(p, ucol[u]);
     ubase[u] = p.h * p.off[uq[u]] + (ucol[u] - p.off[uq[u]]);      // + code * sub
   }
@@ -400,7 +541,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gram_codes_kernel(CodesParams p) 
 #pragma unroll
   for (int u = 0; u < UPT; ++u) usub[u] = p.off[uq[u] + 1] - p.off[uq[u]];
   int cd[UPT];
-  float4 xv[UPT], hv[UPT];
+  V xv[UPT], hv[UPT];
   auto load_codes = [&](int s) {
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
@@ -413,8 +554,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gram_codes_kernel(CodesParams p) 
     for (int u = 0; u < UPT; ++u) {
       const int64_t row = r0 + (int64_t)s * GRAMC_ROWS + urow[u];
       const bool in = urow[u] >= 0 && row < r1;
-      xv[u] = in ? *reinterpret_cast<const float4 *>(p.X + row * d + ucol[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
-      hv[u] = in ? *reinterpret_cast<const float4 *>(p.C + ubase[u] + cd[u] * usub[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xv[u] = in ? *reinterpret_cast<const V *>(p.X + row * d + ucol[u]) : VecW<W>::zero();
+      hv[u] = in ? *reinterpret_cast<const V *>(p.C + ubase[u] + cd[u] * usub[u]) : VecW<W>::zero();
     }
   };
   f32x16 acc[TPW];
@@ -443,8 +584,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gram_codes_kernel(CodesParams p) 
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
       if (urow[u] >= 0) {
-        *reinterpret_cast<float4 *>(Xs + urow[u] * ld + ucol[u]) = xv[u];
-        *reinterpret_cast<float4 *>(Hs + urow[u] * ld + ucol[u]) = hv[u];
+        *reinterpret_cast<V *>(Xs + urow[u] * ld + ucol[u]) = xv[u];
+        *reinterpret_cast<V *>(Hs + urow[u] * ld + ucol[u]) = hv[u];
       }
     }
     __syncthreads();
@@ -480,20 +621,26 @@ __global__ __launch_bounds__(NWAVES * 64) void gram_codes_kernel(CodesParams p) 
   }
 }
 
+template <int W>
 __global__ __launch_bounds__(256) void qerror_codes_kernel(CodesParams p) {
+  using V = typename VecW<W>::T;
   __shared__ double red[256];
-  const int d4 = p.d >> 2;
+  const int d4 = p.d / W;
   const int64_t total = p.n * d4;
   double s = 0.0;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t row = e / d4;
-    const int col = 4 * (int)(e - row * d4);
+    const int col = W * (int)(e - row * d4);
     const int q = codes_subq(p, col);
     const int code = p.codes[row * p.m + q];
-    const float4 x = *reinterpret_cast<const float4 *>(p.X + row * p.d + col);
-    const float4 c = *reinterpret_cast<const float4 *>(p.C + (size_t)p.h * p.off[q] + (size_t)code * (p.off[q + 1] - p.off[q]) + (col - p.off[q]));
-    const double a0 = (double)x.x - (double)c.x, a1 = (double)x.y - (double)c.y, a2 = (double)x.z - (double)c.z, a3 = (double)x.w - (double)c.w;
-    s += a0 * a0; s += a1 * a1; s += a2 * a2; s += a3 * a3;
+    const V x = *reinterpret_cast<const V *>(p.X + row * p.d + col);
+    const V c = *reinterpret_cast<const V *>(p.C + (size_t)p.h * p.off[q] + (size_t)code * (p.off[q + 1] - p.off[q]) + (col - p.off[q]));
+    const double a0 = (double)x.x - (double)c.x, a1 = (double)x.y - (double)c.y;
+    s += a0 * a0; s += a1 * a1;
+    if constexpr (W == 4) {
+      const double a2 = (double)x.z - (double)c.z, a3 = (double)x.w - (double)c.w;
+      s += a2 * a2; s += a3 * a3;
+    }
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -722,6 +869,19 @@ int update_centers_launch(float *C, unsigned int *counts, const float *X, const 
   void *part = nullptr;
   RQ_TRY(workspace(WS_TMP, (size_t)(grid + 1) * ((size_t)h * d + (size_t)m * h) * sizeof(float), &part, stream));
   p.partial = (float *)part;
+  if (tuning("TRAIN_CENTERS_MFMA", 1) && n / std::max(1, num_cu) < (1 << 23)) {
+    // one-hot products on the bf16 matrix cores; a wavefront per (sub-quantizer, 16-dimension block), 8 of them per workgroup.
+    // (counts ride in f32 accumulators: exact below 2^24 rows per slice)
+    int nunits = 0;
+    for (int q = 0; q < m; ++q) nunits += (p.off[q + 1] - p.off[q] + 15) / 16;
+    const int nslice = grid;
+    const dim3 g3(nslice, (nunits + 7) / 8);
+    if (h <= 64) hipLaunchKernelGGL(centers_mfma_kernel<4>, g3, dim3(512), 0, stream, p, nunits);
+    else if (h <= 128) hipLaunchKernelGGL(centers_mfma_kernel<8>, g3, dim3(512), 0, stream, p, nunits);
+    else hipLaunchKernelGGL(centers_mfma_kernel<16>, g3, dim3(512), 0, stream, p, nunits);
+    RQ_HIP(hipGetLastError());
+    return centers_finish(p, grid, stream);
+  }
   bool aligned = (d & 3) == 0;
   for (int q = 0; q <= m; ++q) aligned = aligned && (p.off[q] & 3) == 0;
   if (aligned && tuning("TRAIN_CENTERS_STREAM", 1)) {
@@ -778,55 +938,79 @@ int qerror_launch(double *acc_dev, const float *X, const float *CB, int64_t n, i
   return RQ_OK;
 }
 
-// can the (codes, C) forms of gram / qerror serve this shape?  (16-byte gathers: every sub-space starts and ends on a multiple of 4)
-bool codes_forms_ok(int d, int m, int h, bool for_gram) {
-  if (!tuning("TRAIN_FUSED_CB", 1)) return false;
-  if (m < 1 || m > 32 || d < m || (d & 3) || h < 1 || h > 256) return false;
-  if (for_gram && d > 256) return false;
+// can the (codes, C) forms of gram / qerror serve this shape?  Returns the gather width in floats: 4 (every sub-space starts on
+// a multiple of 4: 16-byte gathers), 2 (multiples of 2, e.g. Deep1M's d = 96, m = 16: 8-byte gathers) or 0 (no)
+int codes_forms_width(int d, int m, int h, bool for_gram) {
+  if (!tuning("TRAIN_FUSED_CB", 1)) return 0;
+  if (m < 1 || m > 32 || d < m || (d & 1) || h < 1 || h > 256) return 0;
+  if (for_gram && d > 256) return 0;
   int off[33];
   fill_offsets(off, d, m);
-  for (int q = 0; q <= m; ++q) if (off[q] & 3) return false;
-  return true;
+  int w = 4;
+  for (int q = 0; q <= m; ++q) {
+    if (off[q] & 1) return 0;
+    if (off[q] & 3) w = 2;
+  }
+  return w;
 }
+bool codes_forms_ok(int d, int m, int h, bool for_gram) { return codes_forms_width(d, m, h, for_gram) != 0; }
 
 static void fill_codes_params(CodesParams &p, const float *X, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h) {
   p.X = X; p.codes = codes; p.C = C; p.partial = nullptr; p.dpartial = nullptr; p.n = n; p.d = d; p.m = m; p.h = h; p.NT = (d + 31) / 32;
   fill_offsets(p.off, d, m);
 }
 
-template <int NW, int TPW, int UPT>
+template <int NW, int TPW, int UPT, int W>
 static int gram_codes_run(CodesParams &p, int grid, size_t lds, hipStream_t stream) {
-  auto kern = gram_codes_kernel<NW, TPW, UPT>;
+  auto kern = gram_codes_kernel<NW, TPW, UPT, W>;
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, p);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
 }
 
+template <int W>
+static int gram_codes_pick(CodesParams &p, int grid, size_t lds, hipStream_t stream) {
+  const int ntile = p.NT * p.NT;
+  const int units = GRAMC_ROWS * (p.d / W);       // W-wide units of a 32-row stage; UPT >= units / threads
+  if (ntile <= 8) {                               // d <= 64: 8 wavefronts, one tile each
+    if (units <= 512) return gram_codes_run<8, 1, 1, W>(p, grid, lds, stream);
+    return gram_codes_run<8, 1, 2, W>(p, grid, lds, stream);
+  }
+  if (ntile <= 16) {                              // d <= 128
+    if (units <= 1024) return gram_codes_run<8, 2, 2, W>(p, grid, lds, stream);
+    return gram_codes_run<8, 2, 4, W>(p, grid, lds, stream);
+  }
+  if (ntile <= 32) {                              // d <= 160
+    if (units <= 2048) return gram_codes_run<8, 4, 4, W>(p, grid, lds, stream);
+    return gram_codes_run<8, 4, 5, W>(p, grid, lds, stream);
+  }
+  if (units <= 2048) return gram_codes_run<16, 4, 2, W>(p, grid, lds, stream);      // d <= 256: 16 wavefronts
+  return gram_codes_run<16, 4, 4, W>(p, grid, lds, stream);
+}
+
 // G = X' CB with CB given as (codes, C); codes_forms_ok(d, m, h, true) must hold
 int gram_codes_launch(float *G, const float *X, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h, int num_cu,
                       hipStream_t stream) {
-  if (!codes_forms_ok(d, m, h, true)) return fail(RQ_EUNSUPPORTED, "gram_codes: d=%d m=%d h=%d", d, m, h);
+  const int w = codes_forms_width(d, m, h, true);
+  if (!w) return fail(RQ_EUNSUPPORTED, "gram_codes: d=%d m=%d h=%d", d, m, h);
   CodesParams p;
   fill_codes_params(p, X, codes, C, n, d, m, h);
-  const int ntile = p.NT * p.NT;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(2 * (int64_t)num_cu, (n + 255) / 256));
   void *part = nullptr;
   RQ_TRY(workspace(WS_TMP, (size_t)grid * d * d * sizeof(float), &part, stream));
   p.partial = (float *)part;
   const size_t lds = (size_t)2 * GRAMC_ROWS * p.NT * 32 * sizeof(float);
-  const int units = GRAMC_ROWS * (d / 4);
-  if (ntile <= 8) RQ_TRY((units <= 512 ? gram_codes_run<8, 1, 1> : gram_codes_run<8, 1, 2>)(p, grid, lds, stream));
-  else if (ntile <= 16) RQ_TRY((units <= 1024 ? gram_codes_run<8, 2, 2> : gram_codes_run<8, 2, 4>)(p, grid, lds, stream));
-  else if (ntile <= 32) RQ_TRY((gram_codes_run<8, 4, 4>)(p, grid, lds, stream));
-  else RQ_TRY((gram_codes_run<16, 4, 2>)(p, grid, lds, stream));
+  if (w == 4) RQ_TRY(gram_codes_pick<4>(p, grid, lds, stream));
+  else RQ_TRY(gram_codes_pick<2>(p, grid, lds, stream));
   return partials_reduce<float>(G, p.partial, (size_t)d * d, grid, d * d, stream);
 }
 
 // acc = sum |X - CB|^2 with CB given as (codes, C); codes_forms_ok(d, m, h, false) must hold
 int qerror_codes_launch(double *acc_dev, const float *X, const uint8_t *codes, const float *C, int64_t n, int d, int m, int h,
                         int num_cu, hipStream_t stream) {
-  if (!codes_forms_ok(d, m, h, false)) return fail(RQ_EUNSUPPORTED, "qerror_codes: d=%d m=%d h=%d", d, m, h);
+  const int w = codes_forms_width(d, m, h, false);
+  if (!w) return fail(RQ_EUNSUPPORTED, "qerror_codes: d=%d m=%d h=%d", d, m, h);
   if (n <= 0) {
     RQ_HIP(hipMemsetAsync(acc_dev, 0, sizeof(double), stream));
     return RQ_OK;
@@ -837,7 +1021,8 @@ int qerror_codes_launch(double *acc_dev, const float *X, const uint8_t *codes, c
   void *part = nullptr;
   RQ_TRY(workspace(WS_MERGE, (size_t)grid * sizeof(double), &part, stream));
   p.dpartial = (double *)part;
-  hipLaunchKernelGGL(qerror_codes_kernel, dim3(grid), dim3(256), 0, stream, p);
+  if (w == 4) hipLaunchKernelGGL(qerror_codes_kernel<4>, dim3(grid), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(qerror_codes_kernel<2>, dim3(grid), dim3(256), 0, stream, p);
   RQ_HIP(hipGetLastError());
   hipLaunchKernelGGL(qerror_finish_kernel, dim3(1), dim3(256), 0, stream, acc_dev, (const double *)part, grid);
   RQ_HIP(hipGetLastError());

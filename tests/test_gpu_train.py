@@ -312,30 +312,37 @@ def test_train_opq_newton_schulz_and_jacobi_agree(rq):
 
 @pytest.mark.parametrize("n,d,m,h", [(50_000, 128, 8, 256), (20_001, 96, 16, 256), (7_000, 64, 8, 64), (3_003, 30, 5, 17),
                                      (70_000, 200, 4, 256), (999, 8, 8, 256), (40_000, 130, 2, 100)])
-def test_update_centers_stream_kernel_is_bit_identical(rq, n, d, m, h):
-    """The one-wavefront-per-chunk kernel (LDS atomics issued in row order) and the round-3 owner-thread kernel add the same
-    rows to the same accumulators in the same order: identical centres and counts, and both within 1e-5 of float64."""
+def test_update_centers_kernels_agree(rq, n, d, m, h):
+    """Three kernels for Clustering.update_centers! (call site src/OPQ.jl:121).  The one-wavefront-per-chunk kernel (LDS atomics
+    issued in row order) and the round-3 owner-thread kernel add the same rows to the same accumulators in the same order:
+    identical centres and counts.  The matrix-core kernel (one-hot x three exact bf16 pieces of x; the default) adds the same
+    f32 values in the MFMA's order: identical counts, centres within 1e-5 of float64 like the others."""
     import torch
     from rayuela_jl_amd import device as rqd
     from oracle import train_oracle as to
     rng = np.random.default_rng(n + d)
     X = (rng.standard_normal((n, d)) * 30).astype(np.float32)
+    X[::7] *= 1e-3                                           # mixed magnitudes: all three bf16 pieces matter
     codes = rng.integers(0, h, (n, m), dtype=np.uint8)
     codes[:, 0] = np.minimum(codes[:, 0], h // 2)            # leaves empty clusters: they keep their value
     off = to.offsets(d, m)
     C0 = rng.standard_normal(h * d).astype(np.float32)
     Xd, cd = torch.from_numpy(X).cuda(), torch.from_numpy(codes).cuda()
     outs = []
-    for stream in (1, 0):
+    for mfma, stream in ((0, 1), (0, 0), (1, 1)):
+        rq.set_tuning("TRAIN_CENTERS_MFMA", mfma)
         rq.set_tuning("TRAIN_CENTERS_STREAM", stream)
         try:
             Cd = torch.from_numpy(C0.copy()).cuda()
             cnt = rqd.update_centers(Cd, Xd, cd, m, h)
             outs.append((Cd.cpu().numpy(), cnt.cpu().numpy()))
         finally:
+            rq.set_tuning("TRAIN_CENTERS_MFMA", 1)
             rq.set_tuning("TRAIN_CENTERS_STREAM", 1)
     assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
     assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[2][1], outs[1][1])
+    assert np.allclose(outs[2][0], outs[1][0], rtol=1e-5, atol=1e-4)
     # against float64
     pos = 0
     for q in range(m):
@@ -345,13 +352,15 @@ def test_update_centers_stream_kernel_is_bit_identical(rq, n, d, m, h):
         sums = np.zeros((h, sub))
         np.add.at(sums, codes[:, q], X[:, off[q]:off[q + 1]].astype(np.float64))
         Cq[cnt > 0] = sums[cnt > 0] / cnt[cnt > 0, None]
-        got = outs[0][0][pos:pos + h * sub].reshape(h, sub)
-        assert np.allclose(got, Cq, rtol=1e-5, atol=1e-4), q
-        assert np.array_equal(outs[0][1][q], cnt)
+        for o in (outs[0], outs[2]):
+            got = o[0][pos:pos + h * sub].reshape(h, sub)
+            assert np.allclose(got, Cq, rtol=1e-5, atol=1e-4), q
+            assert np.array_equal(o[1][q], cnt)
         pos += h * sub
 
 
-@pytest.mark.parametrize("n,d,m,h", [(30_000, 128, 8, 256), (20_001, 96, 8, 256), (5_000, 64, 8, 64), (12_345, 160, 4, 100),
+@pytest.mark.parametrize("n,d,m,h", [(30_000, 128, 8, 256), (20_001, 96, 16, 256), (20_001, 96, 8, 256), (5_000, 64, 8, 64), (12_345, 160, 4, 100),
+                                     (8_000, 128, 32, 256), (6_000, 256, 32, 64), (4_000, 30, 5, 17),
                                      (9_000, 256, 8, 256), (7_777, 32, 2, 16), (100, 8, 2, 4), (31, 128, 8, 256)])
 def test_gram_and_qerror_from_codes_match_the_reconstructed_forms(rq, n, d, m, h):
     """gram_codes / qerror_codes gather CB[j] = C[codes[j]] inside the kernel (src/OPQ.jl:101,108,112 without the n x d
@@ -381,8 +390,8 @@ def test_gram_and_qerror_from_codes_match_the_reconstructed_forms(rq, n, d, m, h
 def test_codes_forms_refuse_shapes_without_aligned_subspaces(rq):
     import torch
     from rayuela_jl_amd import device as rqd
-    X = torch.zeros((100, 30), device="cuda")
-    codes = torch.zeros((100, 5), dtype=torch.uint8, device="cuda")
+    X = torch.zeros((100, 30), device="cuda")                    # d = 30, m = 4: sub-spaces 8, 8, 7, 7 -- the last starts at 23
+    codes = torch.zeros((100, 4), dtype=torch.uint8, device="cuda")
     C = torch.zeros((16 * 30,), device="cuda")
     with pytest.raises(Exception):
         rqd.gram_codes(X, codes, C, 16)
