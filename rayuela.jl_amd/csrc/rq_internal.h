@@ -151,7 +151,7 @@ int reconstruct_launch(float *CB, const uint8_t *codes, const float *C, int64_t 
 int qerror_launch(double *acc_dev, const float *X, const float *CB, int64_t n, int d, int num_cu,
                   hipStream_t stream);
 // kmeans++ seeding of all m sub-spaces (Clustering.jl init=:kmpp): seeds [m][h] rows, C = their sub-vectors;
-// mincost [m][n] floats and partial [m][1024] doubles are scratch, u [m][h] uniforms in [0,1) (device pointers)
+// mincost [n][m] floats and partial [m][1024] doubles are scratch, u [m][h] uniforms in [0,1) (device pointers)
 int kmpp_init_launch(float *C, long long *seeds, float *mincost, double *partial, const double *u, const float *X,
                      int64_t n, int d, int m, int h, hipStream_t stream);
 int polar_factor_launch(float *Rimg, const float *G, double *Vw, int warm, int d, int *status, double *scratch, hipStream_t stream);

@@ -95,112 +95,11 @@ __global__ __launch_bounds__(1024) void centers_partial_kernel(TrainParams p, in
   }
 }
 
-// ---- update_centers, pass 1, round 4: ONE WAVEFRONT per (row slice, 64-dimension chunk), LDS atomics in row order ----------
-// The kernel above makes all 1024 threads walk every row although only the 128 owners of the row's codes have work: 8 VALU
-// and 2 vector-memory instructions per row and wavefront, 16 wavefronts per row -- 0.81 ms at SIFT1M shape, 8 % of the HBM
-// roof.  Here a wavefront owns 64 dimensions for ALL codes (sums [h][64] = 64 KiB of LDS, two wavefronts per CU), and a row
-// costs it a quarter of a load instruction: lane l = 16 g + c loads the float4 of dimensions 4 c .. 4 c + 3 of row r + g, so
-// one 16-byte load instruction covers 4 rows and 32 of them (2 batches of 64 rows, 32 KiB) are in flight per wavefront --
-// with one dword per lane and row the 63-entry load counter caps a wavefront at 16 KiB, and the kernel is latency-bound at a
-// quarter of the rate.  The four lane groups then add their rows ONE GROUP AFTER THE OTHER (`ds_add_f32` without return, 16
-// active lanes, distinct addresses): LDS instructions of a wavefront execute in issue order, so every accumulator still
-// receives its rows in ascending order -- the SAME sums, bit for bit, as the kernel above (same slices; tests/test_gpu_train.py
-// compares the two).  The code bytes of a 64-row batch are fetched by one lane per row and passed through LDS.
-// Needs d % 4 == 0 and sub-spaces on multiples of 4 (a lane's four dimensions share their sub-quantizer).
-constexpr int CENTERS_B = 64;                     // rows per batch
-__global__ __launch_bounds__(64) void centers_stream_kernel(TrainParams p, int nchunk) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-  const int slice = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk, nslice = gridDim.x / nchunk;
-  const int dc0 = chunk * 64, dcw = min(64, p.d - dc0);
-  float *sums = reinterpret_cast<float *>(smem);                                      // [h][64]
-  unsigned int *cnts = reinterpret_cast<unsigned int *>(sums + (size_t)p.h * 64);    // [q - q0][h], q0 = sub-quantizer of dc0
-  int q0 = 0;
-  while (q0 + 1 < p.m && dc0 >= p.off[q0 + 1]) ++q0;
-  int q1 = q0;
-  while (q1 + 1 < p.m && dc0 + dcw - 1 >= p.off[q1 + 1]) ++q1;
-  const int nq = q1 - q0 + 1;
-  uint8_t *cs = reinterpret_cast<uint8_t *>(cnts + (size_t)nq * p.h);                 // [2][64][nq] code bytes of two batches
-  for (int i = lane; i < p.h * 64 + nq * p.h; i += 64) sums[i] = 0.0f;            // 0.0f and 0u share the bit pattern
-  const int64_t rows_per = (p.n + nslice - 1) / nslice;
-  const int64_t r0 = (int64_t)slice * rows_per, r1 = min(p.n, r0 + rows_per);
-  const bool live = 4 * c < dcw;
-  const int dim = dc0 + (live ? 4 * c : 0);
-  int q = q0;
-  while (q + 1 < p.m && dim >= p.off[q + 1]) ++q;
-  const bool counts_here = live && dim == p.off[q];
-  const float *xd = p.X + dim;
-  unsigned int *cnt_q = cnts + (size_t)(q - q0) * p.h;
-  float *mine = sums + 4 * c;
-  const int ql = q - q0;
-  float4 x[2][CENTERS_B / 4];
-  auto load = [&](int b, int64_t r) {
-    // code bytes: lane l fetches the nq bytes of row r + l
-    {
-      const int64_t rr = r + lane < r1 ? r + lane : r1 - 1;
-      const uint8_t *src = p.codes + rr * p.m + q0;
-      uint8_t *dst = cs + ((size_t)b * CENTERS_B + lane) * nq;
-      for (int k = 0; k < nq; ++k) dst[k] = src[k];
-    }
-#pragma unroll
-    for (int u = 0; u < CENTERS_B / 4; ++u) {
-      const int64_t rr = r + 4 * u + g < r1 ? r + 4 * u + g : r1 - 1;
-      x[b][u] = *reinterpret_cast<const float4 *>(xd + rr * p.d);
-    }
-  };
-  auto add = [&](int b, int64_t r) {
-    __syncthreads();                        // (one wavefront: orders the LDS code bytes written above with the reads below)
-    int code[CENTERS_B / 4];
-#pragma unroll
-    for (int u = 0; u < CENTERS_B / 4; ++u) code[u] = cs[((size_t)b * CENTERS_B + 4 * u + g) * nq + ql];
-#pragma unroll
-    for (int u = 0; u < CENTERS_B / 4; ++u) {
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg) {
-        if (g == gg && live && r + 4 * u + gg < r1) {
-          float *dst = mine + code[u] * 64;
-          __hip_atomic_fetch_add(dst + 0, x[b][u].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(dst + 1, x[b][u].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(dst + 2, x[b][u].z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(dst + 3, x[b][u].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (counts_here) __hip_atomic_fetch_add(cnt_q + code[u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-    }
-  };
-  __syncthreads();
-  if (r0 < r1) {
-    constexpr int B = CENTERS_B;
-    load(0, r0);
-    int64_t r = r0;
-    for (; r + 2 * B < r1; r += 2 * B) {
-      load(1, r + B);
-      add(0, r);
-      load(0, r + 2 * B);
-      add(1, r + B);
-    }
-    // here buffer 0 holds rows r .. r + B - 1
-    if (r + B < r1) { load(1, r + B); add(0, r); add(1, r + B); }
-    else add(0, r);
-  }
-  __syncthreads();
-  // partial layout per slice: [h][d] sums, then [m][h] counts (u32 bit patterns) -- as centers_partial_kernel writes it
-  float *out = p.partial + (size_t)slice * ((size_t)p.h * p.d + (size_t)p.m * p.h);
-  for (int i = lane; i < p.h * 16; i += 64) {
-    const int code = i >> 4, c4 = 4 * (i & 15);
-    if (c4 < dcw) *reinterpret_cast<float4 *>(out + (size_t)code * p.d + dc0 + c4) = *reinterpret_cast<const float4 *>(sums + code * 64 + c4);
-  }
-  unsigned int *oc = reinterpret_cast<unsigned int *>(out + (size_t)p.h * p.d);
-  for (int i = lane; i < nq * p.h; i += 64) {
-    const int qq = q0 + i / p.h;
-    if (p.off[qq] >= dc0 && p.off[qq] < dc0 + dcw) oc[(size_t)qq * p.h + i % p.h] = cnts[i];
-  }
-}
-
 // ---- update_centers, pass 1 on the MATRIX CORES (round 4, the default) ---------------------------------------------------
-// Measured on the two kernels above: 0.78-0.81 ms at SIFT1M shape whichever way the rows are walked, because the LDS
-// read-modify-write is the bound (`ds_add_f32`: ~3.4 cycles per lane and CU; without the adds the streaming kernel needs
-// 0.34 ms, without its loads 0.78).  A segment sum is also a product with a one-hot matrix,
+// The owner-thread kernel above takes 0.81 ms at SIFT1M shape (8 % of the HBM roof).  A second scatter design was measured
+// and dropped: one wavefront per (slice, 64 dimensions), every row one `ds_add_f32` per lane in row order, 16-byte loads, 32
+// KiB in flight per wavefront -- 0.78 ms; without its adds 0.34 ms, without its loads 0.78: LDS float atomics retire ~1 lane
+// per 3.4 cycles and CU, the read-modify-write IS the bound of any scatter.  A segment sum is also a product with a one-hot matrix,
 //      sums_q[code][s] = sum_rows [b(row, q) == code] x[row][off_q + s],
 // and one-hot entries and products are EXACT in bf16 arithmetic if x is split into three bf16 pieces (8 + 8 + 8 mantissa
 // bits: x = p1 + p2 + p3 exactly), so v_mfma_f32_16x16x32_bf16 adds exactly the f32 values the scatter would add -- in the
@@ -664,7 +563,7 @@ __global__ __launch_bounds__(256) void qerror_codes_kernel(CodesParams p) {
 struct KmppParams {
   const float *X;       // [n][d]
   float *C;             // concat of [h][sub_i]
-  float *mincost;       // [m][n]
+  float *mincost;       // [n][m]
   double *partial;      // [m][nblk]
   long long *seeds;     // [m][h]
   const double *u;      // [m][h] uniforms in [0, 1)
@@ -688,28 +587,58 @@ __device__ __forceinline__ double block_sum_1024(double v, double *red) {
   return r;
 }
 
-__global__ __launch_bounds__(KMPP_THREADS) void kmpp_update_kernel(KmppParams p, int step) {
-  __shared__ double red[KMPP_THREADS];
-  const int i = blockIdx.y, o = p.off[i], sub = p.off[i + 1] - o;
-  const long long seed = p.seeds[(size_t)i * p.h + step - 1];       // the seed chosen in the previous step
-  const float *xs = p.X + (size_t)seed * p.d + o;
-  float *mc = p.mincost + (size_t)i * p.n;
+// One workgroup per block of rows, ALL sub-spaces at once: thread t = (row slot t / m, sub-space t % m), so a wavefront reads
+// whole rows (consecutive lanes = consecutive sub-vectors of a row) and X crosses the memory system once per step.  (Round 3
+// ran a 1024-thread workgroup per (block, sub-space), one row per thread and a 10-level tree per 977 rows: 1.16 ms per step,
+// 0.3 s for h = 256 seeds at SIFT1M shape -- 13 x the 25 Lloyd iterations that follow.)  mincost is [n][m].
+__global__ __launch_bounds__(256) void kmpp_update_kernel(KmppParams p, int step) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kmpp_smem[];
+  float *xs = reinterpret_cast<float *>(kmpp_smem);                     // [d] the sub-vectors of the seeds of the previous step
+  double *red = reinterpret_cast<double *>(xs + ((p.d + 3) & ~3));         // [T]
+  const int T = blockDim.x, tid = threadIdx.x, m = p.m;
+  for (int e = tid; e < p.d; e += T) {
+    int q = 0;
+    while (q + 1 < m && e >= p.off[q + 1]) ++q;
+    xs[e] = p.X[(size_t)p.seeds[(size_t)q * p.h + step - 1] * p.d + e];
+  }
+  __syncthreads();
+  const int q = tid % m, slot = tid / m, rpi = T / m;
+  const int o = p.off[q], sub = p.off[q + 1] - o;
+  const long long seed = p.seeds[(size_t)q * p.h + step - 1];
   const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_blk, r1 = min(p.n, r0 + p.rows_per_blk);
+  const bool vec = (sub & 3) == 0 && (o & 3) == 0 && (p.d & 3) == 0;
   double acc = 0.0;
-  for (int64_t r = r0 + threadIdx.x; r < r1; r += KMPP_THREADS) {
+  for (int64_t r = r0 + slot; r < r1; r += rpi) {
     const float *x = p.X + (size_t)r * p.d + o;
     float dist = 0.0f;
-    for (int s = 0; s < sub; ++s) {
-      const float df = x[s] - xs[s];
-      dist = __builtin_fmaf(df, df, dist);
+    if (vec) {
+      for (int s4 = 0; s4 < sub; s4 += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(x + s4);
+        const float4 w = *reinterpret_cast<const float4 *>(xs + o + s4);
+        float df = v.x - w.x; dist = __builtin_fmaf(df, df, dist);
+        df = v.y - w.y; dist = __builtin_fmaf(df, df, dist);
+        df = v.z - w.z; dist = __builtin_fmaf(df, df, dist);
+        df = v.w - w.w; dist = __builtin_fmaf(df, df, dist);
+      }
+    } else {
+      for (int s = 0; s < sub; ++s) {
+        const float df = x[s] - xs[o + s];
+        dist = __builtin_fmaf(df, df, dist);
+      }
     }
-    float c = (step == 1) ? dist : fminf(mc[r], dist);
+    float *mc = p.mincost + (size_t)r * m + q;
+    float c = (step == 1) ? dist : fminf(*mc, dist);
     if (r == seed) c = 0.0f;
-    mc[r] = c;
+    *mc = c;
     acc += (double)c;
   }
-  const double tot = block_sum_1024(acc, red);
-  if (threadIdx.x == 0) p.partial[(size_t)i * p.nblk + blockIdx.x] = tot;
+  red[tid] = acc;
+  __syncthreads();
+  if (tid < m) {                       // the rpi row slots of sub-space tid, in slot order
+    double tot = 0.0;
+    for (int k = 0; k < rpi; ++k) tot += red[tid + k * m];
+    p.partial[(size_t)tid * p.nblk + blockIdx.x] = tot;
+  }
 }
 
 // first seed: row floor(u * n)
@@ -729,7 +658,8 @@ __global__ __launch_bounds__(KMPP_THREADS) void kmpp_select_kernel(KmppParams p,
   __shared__ double resid;
   const int tid = threadIdx.x, i = blockIdx.x, o = p.off[i], sub = p.off[i + 1] - o;
   const double *part = p.partial + (size_t)i * p.nblk;
-  const float *mc = p.mincost + (size_t)i * p.n;
+  const float *mcq = p.mincost + i;              // [n][m]: the cost of row r in this sub-space is mcq[r * m]
+  const int64_t ms = p.m;
   // inclusive scan of the block sums (nblk <= 1024: one per thread), Hillis-Steele in double
   scan[tid] = tid < p.nblk ? part[tid] : 0.0;
   __syncthreads();
@@ -767,7 +697,7 @@ __global__ __launch_bounds__(KMPP_THREADS) void kmpp_select_kernel(KmppParams p,
     const int64_t chunk = (r1 - r0 + KMPP_THREADS - 1) / KMPP_THREADS;
     const int64_t c0 = min(r1, r0 + (int64_t)tid * chunk), c1 = min(r1, c0 + chunk);
     double cs = 0.0;
-    for (int64_t r = c0; r < c1; ++r) cs += (double)mc[r];
+    for (int64_t r = c0; r < c1; ++r) cs += (double)mcq[r * ms];
     red[tid] = cs;
     scan[tid] = cs;
     __syncthreads();
@@ -783,16 +713,16 @@ __global__ __launch_bounds__(KMPP_THREADS) void kmpp_select_kernel(KmppParams p,
       double run = cbefore;
       long long rr = -1;
       for (int64_t r = c0; r < c1; ++r) {
-        run += (double)mc[r];
-        if (run > rthr && mc[r] > 0.0f) { rr = r; break; }
+        run += (double)mcq[r * ms];
+        if (run > rthr && mcq[r * ms] > 0.0f) { rr = r; break; }
       }
       if (rr < 0)
-        for (int64_t r = c1 - 1; r >= c0; --r) if (mc[r] > 0.0f) { rr = r; break; }
+        for (int64_t r = c1 - 1; r >= c0; --r) if (mcq[r * ms] > 0.0f) { rr = r; break; }
       pick[1] = rr;
     }
     __syncthreads();
     if (pick[1] < 0 && tid == 0) {      // threshold beyond the block's re-summed total: last row with a cost
-      for (int64_t r = r1 - 1; r >= r0; --r) if (mc[r] > 0.0f) { pick[1] = r; break; }
+      for (int64_t r = r1 - 1; r >= r0; --r) if (mcq[r * ms] > 0.0f) { pick[1] = r; break; }
       if (pick[1] < 0) pick[1] = r0;
     }
     __syncthreads();
@@ -818,10 +748,12 @@ int kmpp_init_launch(float *C, long long *seeds, float *mincost, double *partial
     for (int i = 0; i < m; ++i) { p.off[i] = pos; pos += per + (i < extra ? 1 : 0); }
     p.off[m] = pos;
   }
+  const int upd_threads = m * (256 / m);           // a multiple of m: every thread keeps one sub-space
+  const size_t upd_lds = (size_t)((d + 3) & ~3) * sizeof(float) + (size_t)upd_threads * sizeof(double);
   hipLaunchKernelGGL(kmpp_first_kernel, dim3(m), dim3(64), 0, stream, p);
   RQ_HIP(hipGetLastError());
   for (int step = 1; step < h; ++step) {
-    hipLaunchKernelGGL(kmpp_update_kernel, dim3(p.nblk, m), dim3(KMPP_THREADS), 0, stream, p, step);
+    hipLaunchKernelGGL(kmpp_update_kernel, dim3(p.nblk), dim3(upd_threads), upd_lds, stream, p, step);
     hipLaunchKernelGGL(kmpp_select_kernel, dim3(m), dim3(KMPP_THREADS), 0, stream, p, step);
   }
   RQ_HIP(hipGetLastError());
@@ -879,19 +811,6 @@ int update_centers_launch(float *C, unsigned int *counts, const float *X, const 
     if (h <= 64) hipLaunchKernelGGL(centers_mfma_kernel<4>, g3, dim3(512), 0, stream, p, nunits);
     else if (h <= 128) hipLaunchKernelGGL(centers_mfma_kernel<8>, g3, dim3(512), 0, stream, p, nunits);
     else hipLaunchKernelGGL(centers_mfma_kernel<16>, g3, dim3(512), 0, stream, p, nunits);
-    RQ_HIP(hipGetLastError());
-    return centers_finish(p, grid, stream);
-  }
-  bool aligned = (d & 3) == 0;
-  for (int q = 0; q <= m; ++q) aligned = aligned && (p.off[q] & 3) == 0;
-  if (aligned && tuning("TRAIN_CENTERS_STREAM", 1)) {
-    // one wavefront per (slice, 64-dimension chunk); the slices are the ones of the kernel below, so are the sums
-    const int nchunk = (d + 63) / 64;
-    const int nqmax = std::min(m, 16);         // sub-quantizers a 64-dimension chunk can touch (sub-spaces >= 4 wide)
-    const size_t lds = ((size_t)h * 64 + (size_t)nqmax * h) * sizeof(float) + (size_t)2 * CENTERS_B * nqmax;
-    RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(centers_stream_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(centers_stream_kernel, dim3(grid * nchunk), dim3(64), lds, stream, p, nchunk);
     RQ_HIP(hipGetLastError());
     return centers_finish(p, grid, stream);
   }
