@@ -140,24 +140,34 @@ __global__ __launch_bounds__(512) void centers_mfma_kernel(TrainParams p, int nu
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cnt[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const bool colok = i < width;
-  const float *xb = p.X + col0 + (colok ? i : 0);
-  const uint8_t *cq = p.codes + q;
+  // Buffer loads: a slice-wide resource (base = the slice's first row, range = its bytes: rows past r1 read as 0), a 32-bit lane
+  // offset (the lane's 8 rows of a 32-row step start at row 8 kg; its column is col0 + i -- an idle lane reads column col0 and
+  // multiplies it by zero) and a wave-uniform row offset in an SGPR: no 64-bit address arithmetic per load (it was 280 of the
+  // 408 VALU instructions of a step, and the kernel is bound by VALU + MFMA issue)
+  const int64_t nrows = r1 > r0 ? r1 - r0 : 0;
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.X + r0 * p.d), 0, (int)(nrows * p.d * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.codes + r0 * p.m), 0, (int)(nrows * p.m), 0x00020000);
+  const int xoff = ((8 * kg) * p.d + col0 + (colok ? i : 0)) * 4;
+  const int coff = (8 * kg) * p.m + q;
   const uint32_t ones = i == 0 ? 0x3F803F80u : 0u;
   const cm_bf16x8 Bc = __builtin_bit_cast(cm_bf16x8, make_uint4(ones, ones, ones, ones));
-  uint32_t cr[2][2][8];
-  float xr[2][2][8];
-  auto load = [&](int b, int64_t r) {
+  // raw operands of ONE pair of 32-row steps; a step re-loads its half for the next pair as soon as it has turned the values
+  // into its A mask and B pieces, so the loads fly during the two tile loops that follow (two buffers cost 32 VGPRs more
+  // and spilled)
+  uint32_t cr[2][8];
+  float xr[2][8];
+  auto load = [&](int s, int64_t r) {              // rows r + 32 s .. + 31
+    const int L0 = (int)(r - r0) + 32 * s;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t row = r + 32 * s + 8 * kg + u;
-        const int64_t rr = row < r1 ? row : r1 - 1;
-        cr[b][s][u] = cq[rr * p.m];
-        xr[b][s][u] = xb[rr * p.d];
-      }
+    for (int u = 0; u < 8; ++u) {
+      const int L = L0 + u;                                         // wave-uniform
+      cr[s][u] = __builtin_amdgcn_raw_buffer_load_b8(rC, coff, L * p.m, 0);
+      xr[s][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, xoff, L * p.d * 4, 0));
+    }
   };
-  auto step = [&](int b, int s, int64_t r) {
+  // TAIL: the 64 rows from r on may pass r1 (their loads return 0; their one-hot entries are masked here)
+  auto step = [&](int s, int64_t r, bool more, auto tail) {     // more: pre-load this half for the pair at r + 64
+    constexpr bool TAIL = decltype(tail)::value;
     // A side: mask of row u = 1 << (code >> 4) if the code's low nibble is this lane's (and the row exists), else 0
     uint32_t K[4];
 #pragma unroll
@@ -166,8 +176,9 @@ __global__ __launch_bounds__(512) void centers_mfma_kernel(TrainParams p, int nu
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int u = 2 * pp + e;
-        const uint32_t c = cr[b][s][u];
-        const bool hit = (c & 15u) == (uint32_t)i && r + 32 * s + 8 * kg + u < r1;
+        const uint32_t c = cr[s][u];
+        bool hit = (c & 15u) == (uint32_t)i;
+        if constexpr (TAIL) hit = hit && r + 32 * s + 8 * kg + u < r1;
         k2[e] = hit ? (1u << (c >> 4)) : 0u;
       }
       K[pp] = k2[0] | (k2[1] << 16);
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(512) void centers_mfma_kernel(TrainParams p, int nu
     uint32_t P1[4], P2[4], P3[4];
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
-      f32x2t v = {colok ? xr[b][s][2 * pp] : 0.0f, colok ? xr[b][s][2 * pp + 1] : 0.0f};
+      f32x2t v = {colok ? xr[s][2 * pp] : 0.0f, colok ? xr[s][2 * pp + 1] : 0.0f};
       const cm_bf16x2 h1 = __builtin_convertvector(v, cm_bf16x2);
       v = v - __builtin_convertvector(h1, f32x2t);
       const cm_bf16x2 h2 = __builtin_convertvector(v, cm_bf16x2);
@@ -189,10 +200,11 @@ __global__ __launch_bounds__(512) void centers_mfma_kernel(TrainParams p, int nu
     const cm_bf16x8 B1 = __builtin_bit_cast(cm_bf16x8, make_uint4(P1[0], P1[1], P1[2], P1[3]));
     const cm_bf16x8 B2 = __builtin_bit_cast(cm_bf16x8, make_uint4(P2[0], P2[1], P2[2], P2[3]));
     const cm_bf16x8 B3 = __builtin_bit_cast(cm_bf16x8, make_uint4(P3[0], P3[1], P3[2], P3[3]));
+    if (more) load(s, r + 64);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       // bit t of each 16-bit mask -> bit 14 of its half = bf16 2.0.  (A 32-bit shift serves both halves: a left shift by
-      // 14 - t <= 14 moves no bit of the low half up to bit 30.)
+      // 14 - t <= 14 moves no bit of the low half up to bit 30.)  (Two tiles at a time with alternating MFMAs: no faster.)
       uint32_t a[4];
 #pragma unroll
       for (int pp = 0; pp < 4; ++pp) a[pp] = (t <= 14 ? K[pp] << (14 - t) : K[pp] >> 1) & 0x40004000u;
@@ -203,17 +215,22 @@ __global__ __launch_bounds__(512) void centers_mfma_kernel(TrainParams p, int nu
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B3, acc[t], 0, 0, 0);
     }
   };
-  if (r0 < r1) {
-    load(0, r0);
-    for (int64_t r = r0; r < r1; r += 128) {
-      if (r + 64 < r1) load(1, r + 64);
-      step(0, 0, r);
-      if (r + 32 < r1) step(0, 1, r);
-      if (r + 64 < r1) {
-        if (r + 128 < r1) load(0, r + 128);
-        step(1, 0, r + 64);
-        if (r + 96 < r1) step(1, 1, r + 64);
-      }
+  {
+    const std::false_type F{};
+    const std::true_type T{};
+    const int64_t nfull = nrows / 64;          // pairs of 32-row steps without a row test
+    const bool tail = nfull * 64 < nrows;      // (its loads past r1 return 0)
+    if (nrows > 0) { load(0, r0); load(1, r0); }
+    for (int64_t k = 0; k < nfull; ++k) {
+      const int64_t ra = r0 + 64 * k;
+      const bool more = k + 1 < nfull || tail;
+      step(0, ra, more, F);
+      step(1, ra, more, F);
+    }
+    if (tail) {
+      const int64_t rt = r0 + 64 * nfull;
+      step(0, rt, false, T);
+      if (rt + 32 < r1) step(1, rt, false, T);
     }
   }
   // D tile t: lane (i, kg) holds codes 16 t + 4 kg + r (r = 0..3) of column i
@@ -801,7 +818,7 @@ int update_centers_launch(float *C, unsigned int *counts, const float *X, const 
   void *part = nullptr;
   RQ_TRY(workspace(WS_TMP, (size_t)(grid + 1) * ((size_t)h * d + (size_t)m * h) * sizeof(float), &part, stream));
   p.partial = (float *)part;
-  if (tuning("TRAIN_CENTERS_MFMA", 1) && n / std::max(1, num_cu) < (1 << 23)) {
+  if (tuning("TRAIN_CENTERS_MFMA", 1) && n / std::max(1, grid) < (1 << 23) && ((n + grid - 1) / grid) * (int64_t)d * 4 < (1ll << 31)) {
     // one-hot products on the bf16 matrix cores; a wavefront per (sub-quantizer, 16-dimension block), 8 of them per workgroup.
     // (counts ride in f32 accumulators: exact below 2^24 rows per slice)
     int nunits = 0;
