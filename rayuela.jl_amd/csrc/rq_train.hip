@@ -1356,7 +1356,7 @@ int polar_ns_launch(float *Rimg, const float *G, int d, int *status, void *scrat
   p.maxit = 96;
   p.l0 = (double)tuning("TRAIN_NS_L0_MICRO", 1000) * 1e-6;
   if (!(p.l0 > 0.0) || p.l0 > 1.0) p.l0 = 1e-3;
-  p.tol2 = 1e-18;
+  p.tol2 = 1e-18;     // (1e-12 saves no step at kappa ~ 1e3: the last step goes from ~1e-4 straight below 1e-9)
   double *s = reinterpret_cast<double *>(scratch);
   p.X0 = s; p.X1 = s + (size_t)d * d; p.Y = s + (size_t)2 * d * d;
   p.part = s + (size_t)3 * d * d;

@@ -266,25 +266,32 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
   std::vector<unsigned int> counts((size_t)m * h);
   // convergence = "no assignment changed" (Clustering.kmeans' tol on these magnitudes): the codes of two consecutive
   // iterations are compared ON THE DEVICE (a D2H of n*m bytes + a host compare per iteration cost more than the encode)
-  DevMem dchg;
-  RQ_TRY(dchg.alloc(8));
+  // The change counter sits right behind the cluster counts: ONE small read-back per iteration serves the convergence test
+  // and the empty-cluster check (the centres are recomputed before the test is known; with unchanged assignments that
+  // reproduces them bit for bit).  The two code buffers swap roles instead of being copied.
+  DevMem dcc;
+  const size_t cnt_bytes = (size_t)m * h * 4;
+  RQ_TRY(dcc.alloc(cnt_bytes + 8));
+  unsigned int *dcnt_p = dcc.as<unsigned int>();
+  unsigned long long *dchg_p = reinterpret_cast<unsigned long long *>(dcc.as<unsigned char>() + cnt_bytes);
+  std::vector<unsigned char> back(cnt_bytes + 8);
+  uint8_t *cur = dcodes.as<uint8_t>(), *prev = dprev.as<uint8_t>();
   int iters_done = 0;
   prof.loop_begin();
   for (int it = 0; it < niter; ++it) {
-    RQ_PH(TP_ENCODE, RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr)));
-    unsigned long long changed = 1;
+    RQ_PH(TP_ENCODE, RQ_TRY(encode_launch(cur, dX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr)));
     prof.start();
-    if (it > 0) {
-      RQ_TRY(codes_changed_launch(dchg.as<unsigned long long>(), dcodes.as<uint8_t>(), dprev.as<uint8_t>(), (size_t)n * m, nullptr));
-      RQ_HIP(hipMemcpy(&changed, dchg.p, 8, hipMemcpyDeviceToHost));
-    }
-    if (changed) RQ_HIP(hipMemcpyAsync(dprev.p, dcodes.p, (size_t)n * m, hipMemcpyDeviceToDevice, nullptr));
+    if (it > 0) RQ_TRY(codes_changed_launch(dchg_p, cur, prev, (size_t)n * m, nullptr));
+    prof.stop(TP_CONVERGE);
+    RQ_PH(TP_CENTERS, RQ_TRY(update_centers_launch(dC.as<float>(), dcnt_p, dX.as<float>(), cur, n, d, m, h, di.num_cu, nullptr)));
+    prof.start();
+    RQ_HIP(hipMemcpy(back.data(), dcc.p, cnt_bytes + 8, hipMemcpyDeviceToHost));
+    unsigned long long changed = 1;
+    if (it > 0) memcpy(&changed, back.data() + cnt_bytes, 8);
     prof.stop(TP_CONVERGE);
     if (!changed) break;   // assignments stable: Lloyd has converged
     ++iters_done;
-    RQ_PH(TP_CENTERS, RQ_TRY(update_centers_launch(dC.as<float>(), dcnt.as<unsigned int>(), dX.as<float>(), dcodes.as<uint8_t>(), n, d,
-                                 m, h, di.num_cu, nullptr)));
-    RQ_HIP(hipMemcpy(counts.data(), dcnt.p, (size_t)m * h * 4, hipMemcpyDeviceToHost));
+    memcpy(counts.data(), back.data(), cnt_bytes);
     for (int i = 0; i < m; ++i)               // re-seed empty clusters from sampled rows
       for (int k = 0; k < h; ++k)
         if (counts[(size_t)i * h + k] == 0) {
@@ -293,7 +300,9 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
           RQ_HIP(hipMemcpy(dC.as<float>() + (size_t)h * off[i] + (size_t)k * sub, dX.as<float>() + row * d + off[i],
                            sizeof(float) * sub, hipMemcpyDeviceToDevice));
         }
+    std::swap(cur, prev);
   }
+  if (cur != dcodes.as<uint8_t>()) std::swap(dcodes.p, dprev.p);      // the final encode below writes (and the download reads) dcodes
   prof.loop_end(iters_done);
   RQ_PH(TP_ENCODE, RQ_TRY(encode_launch(dcodes.as<uint8_t>(), dX.as<float>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr)));
   if (codes_forms_ok(d, m, h, false)) {
