@@ -1196,14 +1196,18 @@ struct NsParams {
   const float *G;        // [d][d] row-major
   double *X0, *X1, *Y;   // [d][d] each
   double *part;          // [maxit + 1][nwg] per-workgroup parts of |X'X - I|_F^2
-  unsigned int *bar;     // barrier counter, zeroed before the launch
+  unsigned int *bar;     // [0] barrier counter, [1] abandon flag; zeroed before the launch
   float *Rimg;           // Rimg[i * d + k] = R[k][i]
   int *status;           // [0] 0 = R written, 1 = fall back; [1] steps taken
   int d, maxit;
   double l0, tol2;
 };
 
-__device__ __forceinline__ void ns_grid_barrier(unsigned int *bar, unsigned int &target, unsigned int nwg) {
+// Returns false when the barrier was abandoned: a workgroup that waits longer than ~2 s (a grid that is not fully resident
+// for some reason this code did not foresee) raises bar[1], everybody else sees it at its next poll, the kernel reports
+// status 1 and the caller falls back -- a wrong assumption must cost a fallback, not a hung device.
+constexpr unsigned int NS_SPIN_LIMIT = 1u << 21;
+__device__ __forceinline__ bool ns_grid_barrier(unsigned int *bar, unsigned int &target, unsigned int nwg, int *s_ok) {
   // __syncthreads waits for every thread's stores to be acknowledged by the L2; thread 0 alone then releases (writes this XCD's
   // L2 back: the XCDs have their own) and, after the wait, acquires (drops this CU's L1 and the stale L2 lines) for everybody
   // -- the L1 is the CU's, so one invalidate serves all wavefronts of the workgroup.  (Fences by all 256 threads of all
@@ -1211,11 +1215,21 @@ __device__ __forceinline__ void ns_grid_barrier(unsigned int *bar, unsigned int 
   __syncthreads();
   target += nwg;
   if (threadIdx.x == 0) {
+    int ok = 1;
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    unsigned int spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023u) == 0u) {
+        if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        if (spins > NS_SPIN_LIMIT) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *s_ok = ok;
   }
   __syncthreads();
+  return *s_ok != 0;
 }
 
 // sum of v over the workgroup, the same fixed tree everywhere
@@ -1276,6 +1290,7 @@ __global__ __launch_bounds__(NS_THREADS) void polar_ns_kernel(NsParams p) {
   __shared__ double As[NS_KC * NS_LDA];
   __shared__ double Bs[NS_KC * NS_T];
   __shared__ double red[NS_THREADS];
+  __shared__ int s_ok;
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
   const int d = p.d, T = (d + NS_T - 1) / NS_T, ntile = T * T;
   const unsigned int nwg = gridDim.x, wg = blockIdx.x;
@@ -1293,7 +1308,7 @@ __global__ __launch_bounds__(NS_THREADS) void polar_ns_kernel(NsParams p) {
     const int i = NS_T * (t / T) + ti, j = NS_T * (t % T) + tj;
     if (i < d && j < d) p.X0[(size_t)i * d + j] = (double)p.G[(size_t)i * d + j] * inv;
   }
-  ns_grid_barrier(p.bar, target, nwg);
+  if (!ns_grid_barrier(p.bar, target, nwg, &s_ok)) { if (tid == 0) p.status[0] = 1; return; }
   double *cur = p.X0, *nxt = p.X1;
   double l = p.l0;
   int it = 0, ok = 0;
@@ -1311,7 +1326,7 @@ __global__ __launch_bounds__(NS_THREADS) void polar_ns_kernel(NsParams p) {
     }
     const double mine = ns_block_sum(perr, red);
     if (tid == 0) p.part[(size_t)it * nwg + wg] = mine;
-    ns_grid_barrier(p.bar, target, nwg);
+    if (!ns_grid_barrier(p.bar, target, nwg, &s_ok)) { if (tid == 0) p.status[0] = 1; return; }
     double e = 0.0;
     for (unsigned int w = tid; w < nwg; w += NS_THREADS) e += p.part[(size_t)it * nwg + w];
     e = ns_block_sum(e, red);
@@ -1330,7 +1345,7 @@ __global__ __launch_bounds__(NS_THREADS) void polar_ns_kernel(NsParams p) {
       const int i = NS_T * I + ti, j = NS_T * J + tj;
       if (i < d && j < d) nxt[(size_t)i * d + j] = x;
     }
-    ns_grid_barrier(p.bar, target, nwg);
+    if (!ns_grid_barrier(p.bar, target, nwg, &s_ok)) { if (tid == 0) p.status[0] = 1; return; }
     double *tmp = cur; cur = nxt; nxt = tmp;
   }
   if (wg == 0 && tid == 0) { p.status[0] = ok ? 0 : 1; p.status[1] = it; }
@@ -1361,7 +1376,7 @@ int polar_ns_launch(float *Rimg, const float *G, int d, int *status, void *scrat
   p.X0 = s; p.X1 = s + (size_t)d * d; p.Y = s + (size_t)2 * d * d;
   p.part = s + (size_t)3 * d * d;
   p.bar = reinterpret_cast<unsigned int *>(p.part + (size_t)(p.maxit + 2) * nwg);
-  RQ_HIP(hipMemsetAsync(p.bar, 0, 4, stream));
+  RQ_HIP(hipMemsetAsync(p.bar, 0, 8, stream));
   hipLaunchKernelGGL(polar_ns_kernel, dim3(nwg), dim3(NS_THREADS), 0, stream, p);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
