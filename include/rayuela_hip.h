@@ -235,7 +235,8 @@ int rq_dev_qerror_codes(double *acc, const float *X, const uint8_t *codes, const
  * C (concat of the m [h][sub_i] codebooks), B1 [n][m] Int16 ONE-based, R [d][d] (memory image of Julia's R),
  * obj [niter+1], *error = qerror_pq of the result.  init: 0 "natural", 1 "random".  R0 / C0 may be NULL;
  * when given they replace the random initialisation.  Every training entry point is bit-reproducible for a
- * given seed / start (fixed-order segment sums in update_centers, fixed reduction trees).  `seed` feeds the library's own
+ * given seed / start (segment sums in the matrix cores' fixed order, fixed reduction trees, a reproducible step count of the
+ * polar iteration).  `seed` feeds the library's own
  * splitmix64 stream -- the reference uses Julia's global RNG, so equal seeds do not mean equal draws. */
 int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n, int d, int m, int h,
                 int niter, uint64_t seed);
