@@ -392,3 +392,22 @@ def test_codes_forms_refuse_shapes_without_aligned_subspaces(rq):
         rqd.gram_codes(X, codes, C, 16)
     with pytest.raises(Exception):
         rqd.qerror_codes(X, codes, C, 16)
+
+
+def test_train_opq_on_a_shape_without_aligned_subspaces(rq):
+    """d = 30, m = 4: sub-spaces of 8, 8, 7, 7 dimensions (src/utils.jl:179-203) -- the (codes, C) forms of gram / qerror do
+    not apply, the loop materialises CB as in round 3; same objective curve as the torch front end on the same start."""
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import train as tr
+    from oracle import train_oracle as to
+    X = synth.deep_like(8000, 30, seed=31)
+    rng = np.random.default_rng(0)
+    off = to.offsets(30, 4)
+    C0 = [X[rng.choice(8000, 16, replace=False)][:, off[i]:off[i + 1]].copy() for i in range(4)]
+    R0 = np.eye(30, dtype=np.float32)
+    C, B, R, obj = rq.train_opq(X, 4, 16, 4, "natural", R0=R0, C0=C0)
+    C2, B2, R2, obj2 = tr.train_opq(X, 4, 16, 4, "natural", R0=R0, C0=C0)
+    assert np.allclose(obj, obj2, rtol=3e-4)
+    assert (np.diff(obj) <= 1e-5 * obj[:-1]).all()
+    assert np.abs(R @ R.T - np.eye(30)).max() < 1e-5
+    assert np.array_equal(rq.quantize_opq(X, R, C), B)
