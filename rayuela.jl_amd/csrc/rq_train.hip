@@ -428,14 +428,20 @@ template <int W> struct VecW;
 template <> struct VecW<4> { using T = float4; static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); } };
 template <> struct VecW<2> { using T = float2; static __device__ __forceinline__ T zero() { return make_float2(0.f, 0.f); } };
 
-template <int NWAVES, int TPW, int UPT, int W>
-__global__ __launch_bounds__(NWAVES * 64) void gram_codes_kernel(CodesParams p) {
+// NTT = d / 32 rounded up: NTT wavefronts, wavefront w owns the output row block a = w with ALL NTT column blocks b (NTT
+// accumulator tiles): its A operand (the X column block) is read once per K step for NTT MFMAs -- (1 + NTT) / NTT LDS reads
+// per MFMA instead of 2 -- and no wavefront idles whatever NTT is (the first layout gave 8 wavefronts 2 slots each: 16 slots
+// for Deep1M's 9 tiles).
+template <int NTT, int W>
+__global__ __launch_bounds__(NTT * 64) void gram_codes_kernel(CodesParams p) {
   using V = typename VecW<W>::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NTHREADS = NWAVES * 64;
+  constexpr int NTHREADS = NTT * 64;
+  constexpr int UPT = 16 / W;                             // >= 32 rows * (32 NTT / W) units / (64 NTT) threads
+  constexpr int KS = NTT <= 4 ? 8 : 4;                    // K steps whose operands are fetched ahead of their MFMAs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hi = lane >> 5;
-  const int d = p.d, NT = p.NT, ntile = NT * NT, ld = NT * 32, d4 = d / W;      // d4: W-wide units per row
+  const int d = p.d, ld = NTT * 32, d4 = d / W;           // d4: W-wide units per row
   float *Xs = reinterpret_cast<float *>(smem);          // [32][ld]
   float *Hs = Xs + GRAMC_ROWS * ld;                     // [32][ld]
   for (int i = tid; i < 2 * GRAMC_ROWS * ld; i += NTHREADS) Xs[i] = 0.0f;     // the padding columns stay zero
@@ -443,8 +449,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gram_codes_kernel(CodesParams p) 
   const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(p.n, r0 + rows_per);
   const int nstage = r1 > r0 ? (int)((r1 - r0 + GRAMC_ROWS - 1) / GRAMC_ROWS) : 0;
   const int units = GRAMC_ROWS * d4;
-  // this thread's units of a stage: (row, 4 dimensions); their sub-quantizer and gather base never change
-  int urow[UPT], ucol[UPT], uq[UPT], ubase[UPT];
+  // this thread's units of a stage: (row, W dimensions); their sub-quantizer and gather base never change
+  int urow[UPT], ucol[UPT], uq[UPT], ubase[UPT], usub[UPT];
 #pragma unroll
   for (int u = 0; u < UPT; ++u) {
     const int e = tid + u * NTHREADS;
@@ -452,10 +458,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gram_codes_kernel(CodesParams p) 
     ucol[u] = e < units ? W * (e % d4) : 0;
     uq[u] = codes_subq(p, ucol[u]);
     ubase[u] = p.h * p.off[uq[u]] + (ucol[u] - p.off[uq[u]]);      // + code * sub
+    usub[u] = p.off[uq[u] + 1] - p.off[uq[u]];
   }
-  int usub[UPT];
-#pragma unroll
-  for (int u = 0; u < UPT; ++u) usub[u] = p.off[uq[u] + 1] - p.off[uq[u]];
   int cd[UPT];
   V xv[UPT], hv[UPT];
   auto load_codes = [&](int s) {
@@ -474,22 +478,11 @@ __global__ __launch_bounds__(NWAVES * 64) void gram_codes_kernel(CodesParams p) 
       hv[u] = in ? *reinterpret_cast<const V *>(p.C + ubase[u] + cd[u] * usub[u]) : VecW<W>::zero();
     }
   };
-  f32x16 acc[TPW];
+  f32x16 acc[NTT];
 #pragma unroll
-  for (int i = 0; i < TPW; ++i)
+  for (int i = 0; i < NTT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-  // the wavefront's tiles (wave-uniform, in SGPRs).  A wavefront without a tile in slot i multiplies tile 0 there and drops the
-  // result: the K loop stays free of branches (exec-masked MFMAs made the compiler copy the accumulators around every one)
-  int ta[TPW], tb[TPW];
-  bool tv[TPW];
-#pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    const int t = __builtin_amdgcn_readfirstlane(wave + i * NWAVES);
-    tv[i] = t < ntile;
-    ta[i] = tv[i] ? t / NT : 0;
-    tb[i] = tv[i] ? t % NT : 0;
-  }
   if (nstage > 0) {
     load_codes(0);
     load_data(0);
@@ -509,54 +502,71 @@ __global__ __launch_bounds__(NWAVES * 64) void gram_codes_kernel(CodesParams p) 
       load_data(s + 1);                    // cd holds the codes of stage s + 1, loaded one trip ago
       if (s + 2 < nstage) load_codes(s + 2);
     }
-    // 8 K steps at a time: all operands first, then the MFMAs back to back
+    // KS K steps at a time: all operands first, then the MFMAs back to back
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float av[TPW][8], bv[TPW][8];
+    for (int part = 0; part < GRAMC_ROWS / 2 / KS; ++part) {
+      float av[KS], bv[NTT][KS];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int ro = (2 * (8 * half + u) + hi) * ld + j;
+      for (int u = 0; u < KS; ++u) {
+        const int ro = (2 * (KS * part + u) + hi) * ld + j;
+        av[u] = Xs[ro + 32 * wave];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) { av[i][u] = Xs[ro + 32 * ta[i]]; bv[i][u] = Hs[ro + 32 * tb[i]]; }
+        for (int i = 0; i < NTT; ++i) bv[i][u] = Hs[ro + 32 * i];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < KS; ++u)
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][u], bv[i][u], acc[i], 0, 0, 0);
+        for (int i = 0; i < NTT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[i][u], acc[i], 0, 0, 0);
     }
   }
   float *out = p.partial + (size_t)blockIdx.x * d * d;
 #pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    if (!tv[i]) continue;
+  for (int i = 0; i < NTT; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int ii = 32 * ta[i] + (r & 3) + 8 * (r >> 2) + 4 * hi, jj = 32 * tb[i] + j;
+      const int ii = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi, jj = 32 * i + j;
       if (ii < d && jj < d) out[(size_t)ii * d + jj] = acc[i][r];
     }
   }
 }
 
+// Per W-wide unit (row, block): sub-quantizer and gather base of the block come from a table built once per workgroup (walking
+// the offsets per unit -- up to m - 1 compares -- made this kernel VALU-bound: 0.45 ms at Deep1M shape, m = 16), and the
+// (row, block) pair advances by the grid stride without a division.
 template <int W>
 __global__ __launch_bounds__(256) void qerror_codes_kernel(CodesParams p) {
   using V = typename VecW<W>::T;
   __shared__ double red[256];
+  __shared__ int gbase[1024 / W];            // block -> h * off[q] - off[q] + column  (the gather address minus code * sub)
+  __shared__ unsigned short gq[1024 / W];    // block -> q | sub << 5
   const int d4 = p.d / W;
+  for (int c = threadIdx.x; c < d4; c += 256) {
+    const int col = W * c, q = codes_subq(p, col);
+    gbase[c] = p.h * p.off[q] + (col - p.off[q]);
+    gq[c] = (unsigned short)(q | ((p.off[q + 1] - p.off[q]) << 5));
+  }
+  __syncthreads();
   const int64_t total = p.n * d4;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t srow = stride / d4;
+  const int scol = (int)(stride - srow * d4);
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t row = e / d4;
+  int cb = (int)(e - row * d4);
   double s = 0.0;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int64_t row = e / d4;
-    const int col = W * (int)(e - row * d4);
-    const int q = codes_subq(p, col);
+  for (; e < total; e += stride) {
+    const int qs = gq[cb], q = qs & 31, sub = qs >> 5;
     const int code = p.codes[row * p.m + q];
-    const V x = *reinterpret_cast<const V *>(p.X + row * p.d + col);
-    const V c = *reinterpret_cast<const V *>(p.C + (size_t)p.h * p.off[q] + (size_t)code * (p.off[q + 1] - p.off[q]) + (col - p.off[q]));
+    const V x = *reinterpret_cast<const V *>(p.X + row * p.d + W * cb);
+    const V c = *reinterpret_cast<const V *>(p.C + gbase[cb] + code * sub);
     const double a0 = (double)x.x - (double)c.x, a1 = (double)x.y - (double)c.y;
     s += a0 * a0; s += a1 * a1;
     if constexpr (W == 4) {
       const double a2 = (double)x.z - (double)c.z, a3 = (double)x.w - (double)c.w;
       s += a2 * a2; s += a3 * a3;
     }
+    row += srow; cb += scol;
+    if (cb >= d4) { cb -= d4; ++row; }
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -879,7 +889,7 @@ int qerror_launch(double *acc_dev, const float *X, const float *CB, int64_t n, i
 int codes_forms_width(int d, int m, int h, bool for_gram) {
   if (!tuning("TRAIN_FUSED_CB", 1)) return 0;
   if (m < 1 || m > 32 || d < m || (d & 1) || h < 1 || h > 256) return 0;
-  if (for_gram && d > 256) return 0;
+  if (d > 1024 || (for_gram && d > 256)) return 0;
   int off[33];
   fill_offsets(off, d, m);
   int w = 4;
@@ -896,33 +906,28 @@ static void fill_codes_params(CodesParams &p, const float *X, const uint8_t *cod
   fill_offsets(p.off, d, m);
 }
 
-template <int NW, int TPW, int UPT, int W>
+template <int NTT, int W>
 static int gram_codes_run(CodesParams &p, int grid, size_t lds, hipStream_t stream) {
-  auto kern = gram_codes_kernel<NW, TPW, UPT, W>;
+  auto kern = gram_codes_kernel<NTT, W>;
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTT * 64), lds, stream, p);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
 }
 
 template <int W>
 static int gram_codes_pick(CodesParams &p, int grid, size_t lds, hipStream_t stream) {
-  const int ntile = p.NT * p.NT;
-  const int units = GRAMC_ROWS * (p.d / W);       // W-wide units of a 32-row stage; UPT >= units / threads
-  if (ntile <= 8) {                               // d <= 64: 8 wavefronts, one tile each
-    if (units <= 512) return gram_codes_run<8, 1, 1, W>(p, grid, lds, stream);
-    return gram_codes_run<8, 1, 2, W>(p, grid, lds, stream);
+  switch (p.NT) {
+    case 1: return gram_codes_run<1, W>(p, grid, lds, stream);
+    case 2: return gram_codes_run<2, W>(p, grid, lds, stream);
+    case 3: return gram_codes_run<3, W>(p, grid, lds, stream);
+    case 4: return gram_codes_run<4, W>(p, grid, lds, stream);
+    case 5: return gram_codes_run<5, W>(p, grid, lds, stream);
+    case 6: return gram_codes_run<6, W>(p, grid, lds, stream);
+    case 7: return gram_codes_run<7, W>(p, grid, lds, stream);
+    case 8: return gram_codes_run<8, W>(p, grid, lds, stream);
   }
-  if (ntile <= 16) {                              // d <= 128
-    if (units <= 1024) return gram_codes_run<8, 2, 2, W>(p, grid, lds, stream);
-    return gram_codes_run<8, 2, 4, W>(p, grid, lds, stream);
-  }
-  if (ntile <= 32) {                              // d <= 160
-    if (units <= 2048) return gram_codes_run<8, 4, 4, W>(p, grid, lds, stream);
-    return gram_codes_run<8, 4, 5, W>(p, grid, lds, stream);
-  }
-  if (units <= 2048) return gram_codes_run<16, 4, 2, W>(p, grid, lds, stream);      // d <= 256: 16 wavefronts
-  return gram_codes_run<16, 4, 4, W>(p, grid, lds, stream);
+  return fail(RQ_EUNSUPPORTED, "gram_codes: d=%d", p.d);
 }
 
 // G = X' CB with CB given as (codes, C); codes_forms_ok(d, m, h, true) must hold
@@ -932,7 +937,10 @@ int gram_codes_launch(float *G, const float *X, const uint8_t *codes, const floa
   if (!w) return fail(RQ_EUNSUPPORTED, "gram_codes: d=%d m=%d h=%d", d, m, h);
   CodesParams p;
   fill_codes_params(p, X, codes, C, n, d, m, h);
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(2 * (int64_t)num_cu, (n + 255) / 256));
+  // workgroups of NT wavefronts, 8 wavefronts per CU (measured 4 ... 32: 8 is best at d = 128 and d = 96 -- more workgroups mean more
+  // partial matrices to write and reduce, fewer leave the matrix pipe idle at the stage barriers)
+  const int per_cu = std::max(1, tuning("GRAM_WAVES_PER_CU", 8) / p.NT);
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * num_cu, (n + 255) / 256));
   void *part = nullptr;
   RQ_TRY(workspace(WS_TMP, (size_t)grid * d * d * sizeof(float), &part, stream));
   p.partial = (float *)part;
