@@ -290,16 +290,33 @@ __global__ void centers_finish_kernel(TrainParams p, int nparts) {
 }
 
 // ---- reconstruction ----------------------------------------------------------------------------------
-__global__ void reconstruct_kernel(TrainParams p) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= p.n * p.d) return;
-  const int64_t r = e / p.d;
-  const int dim = (int)(e - r * p.d);
-  int q = 0;
-  while (q + 1 < p.m && dim >= p.off[q + 1]) ++q;
-  const int sub = p.off[q + 1] - p.off[q];
-  const int code = p.codes[r * p.m + q];
-  p.CB[e] = p.C[(size_t)p.h * p.off[q] + (size_t)code * sub + (dim - p.off[q])];
+// a per-dimension table (sub-quantizer | width, gather base) in LDS replaces the walk over the offsets per element; a
+// persistent grid walks the elements with a 32-bit (row, dimension) pair instead of a 64-bit division each
+__global__ __launch_bounds__(256) void reconstruct_kernel(TrainParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
+  int *gbase = reinterpret_cast<int *>(rc_smem);                              // [d]  h * off[q] - off[q] + dim
+  unsigned short *gq = reinterpret_cast<unsigned short *>(gbase + p.d);       // [d]  q (m <= 32)
+  unsigned short *gsub = gq + p.d;                                            // [d]  width of the sub-space
+  for (int dim = threadIdx.x; dim < p.d; dim += 256) {
+    int q = 0;
+    while (q + 1 < p.m && dim >= p.off[q + 1]) ++q;
+    gbase[dim] = p.h * p.off[q] + (dim - p.off[q]);
+    gq[dim] = (unsigned short)q;
+    gsub[dim] = (unsigned short)(p.off[q + 1] - p.off[q]);
+  }
+  __syncthreads();
+  const int64_t total = p.n * p.d, stride = (int64_t)gridDim.x * 256;
+  const int64_t srow = stride / p.d;
+  const int sdim = (int)(stride - srow * p.d);
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t r = e / p.d;
+  int dim = (int)(e - r * p.d);
+  for (; e < total; e += stride) {
+    const int code = p.codes[r * p.m + gq[dim]];
+    p.CB[e] = p.C[gbase[dim] + code * (int)gsub[dim]];
+    r += srow; dim += sdim;
+    if (dim >= p.d) { dim -= p.d; ++r; }
+  }
 }
 
 // ---- quantisation error: sum (X - CB)^2 in double, fixed reduction tree (bit-reproducible) ---------------------
@@ -861,7 +878,9 @@ int reconstruct_launch(float *CB, const uint8_t *codes, const float *C, int64_t 
   p.codes = codes; p.C = const_cast<float *>(C); p.CB = CB; p.n = n; p.d = d; p.m = m; p.h = h;
   fill_offsets(p.off, d, m);
   const int64_t total = n * d;
-  hipLaunchKernelGGL(reconstruct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+  if (d > 8192) return fail(RQ_EUNSUPPORTED, "reconstruct: d=%d", d);
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(reconstruct_kernel, dim3(grid), dim3(256), (size_t)d * 8, stream, p);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
 }
