@@ -249,6 +249,10 @@ __global__ __launch_bounds__(512) void centers_mfma_kernel(TrainParams p, int nu
   }
 }
 
+// (Tried for narrow sub-spaces -- Deep1M's sub = 6 uses 6 of the 16 B columns: the three pieces and the counter PACKED side by
+// side into two B operands, half the MFMAs, pieces added across lanes at the end.  Correct, and no faster: 0.45 against 0.41 ms
+// at Deep1M shape -- with 16 sub-quantizers the kernel is bound by the VALU work per (step, sub-quantizer), the mask build and
+// the 8 instructions per tile, not by the matrix pipe.  The cost of this formulation is proportional to m, not to d.)
 // dst[i] = sum over the nparts slices of src[w * stride + i] in a FIXED order (16 interleaved groups of slices, then the 16
 // group sums in ascending order): the serial loop over 256-512 slices per element of round 3 took 70-140 us per call
 template <class T>

@@ -311,11 +311,13 @@ def test_train_opq_newton_schulz_and_jacobi_agree(rq):
 
 
 @pytest.mark.parametrize("n,d,m,h", [(50_000, 128, 8, 256), (20_001, 96, 16, 256), (7_000, 64, 8, 64), (3_003, 30, 5, 17),
-                                     (70_000, 200, 4, 256), (999, 8, 8, 256), (40_000, 130, 2, 100)])
+                                     (70_000, 200, 4, 256), (999, 8, 8, 256), (40_000, 130, 2, 100), (5_000, 40, 8, 64),
+                                     (6_000, 64, 8, 200), (9_001, 50, 8, 256)])
 def test_update_centers_kernels_agree(rq, n, d, m, h):
     """Two kernels for Clustering.update_centers! (call site src/OPQ.jl:121): the round-3 owner-thread scatter (sequential f32
     sums in row order) and the matrix-core kernel (one-hot x three exact bf16 pieces of x; the default), which adds the same
-    f32 values in the MFMA's order: identical counts, centres within 1e-5 of float64 for both."""
+    f32 values in the MFMA's order: identical counts, centres within 1e-5 of float64 for both.  Narrow and mixed sub-space
+    widths included (d / m = 96 / 16, 30 / 5, 8 / 8, 40 / 8, 64 / 8, 50 / 8)."""
     import torch
     from rayuela_jl_amd import device as rqd
     from oracle import train_oracle as to
