@@ -177,6 +177,25 @@ struct DevMem {
   template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
 
+// the device's persistent non-blocking compute stream (the caller holds the DeviceLock) with the two events that order it
+// against the default stream
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t ready = nullptr, done = nullptr;
+  int create() {
+    hipStream_t xs = nullptr;
+    RQ_TRY(aux_streams(&s, &xs));
+    RQ_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    RQ_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    return RQ_OK;
+  }
+  ~SideStream() {
+    if (s) (void)hipStreamSynchronize(s);
+    if (ready) (void)hipEventDestroy(ready);
+    if (done) (void)hipEventDestroy(done);
+  }
+};
+
 static void offsets(int *off, int d, int m) {
   const int per = d / m, extra = d % m;
   int pos = 0;
@@ -430,15 +449,22 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
   if (dev_ns) RQ_TRY(dns.alloc(polar_ns_scratch_bytes(d, di.num_cu)));
   bool dev_warm = false;
   prof.loop_begin();
+  // The objective of every iteration is computed on a SIDE STREAM while the main stream goes on with X'CB and the polar factor
+  // (the objective reads RX, the codes and C; the rotation that overwrites RX waits for it), and the niter + 1 values are
+  // read back once, after the loop -- not one blocking 8-byte copy per iteration.
+  SideStream side;
+  RQ_TRY(side.create());
+  DevMem dobj;
+  RQ_TRY(dobj.alloc((size_t)(niter + 1) * 8));
   for (int it = 0; it <= niter; ++it) {
     // objective |R CB - X|^2 / n == |CB - R'X|^2 / n (src/OPQ.jl:108)
     prof.start();
-    if (fused_cb) RQ_TRY(qerror_codes_launch(dacc.as<double>(), dRX.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
-    else RQ_TRY(qerror_launch(dacc.as<double>(), dRX.as<float>(), dCB.as<float>(), n, d, di.num_cu, nullptr));
-    double acc = 0;
-    RQ_HIP(hipMemcpy(&acc, dacc.p, 8, hipMemcpyDeviceToHost));
+    RQ_HIP(hipEventRecord(side.ready, nullptr));
+    RQ_HIP(hipStreamWaitEvent(side.s, side.ready, 0));
+    if (fused_cb) RQ_TRY(qerror_codes_launch(dobj.as<double>() + it, dRX.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, di.num_cu, side.s));
+    else RQ_TRY(qerror_launch(dobj.as<double>() + it, dRX.as<float>(), dCB.as<float>(), n, d, di.num_cu, side.s));
+    RQ_HIP(hipEventRecord(side.done, side.s));
     prof.stop(TP_QERROR);
-    if (obj) obj[it] = (float)(acc / (double)n);
     // update R (src/OPQ.jl:112-113): G = X CB' and its polar factor U V' on the device
     prof.start();
     if (fused_cb) RQ_TRY(gram_codes_launch(dG.as<float>(), dX.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, di.num_cu, nullptr));
@@ -472,6 +498,7 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
       g_train_prof[TP_HOST_POLAR] += 1;
     }
     prof.stop(TP_SVD);
+    RQ_HIP(hipStreamWaitEvent(nullptr, side.done, 0));      // the objective has read RX, C (and CB)
     RQ_PH(TP_ROTATE, RQ_TRY(rotate_launch(dRX.as<float>(), dR.as<float>(), dX.as<float>(), d, n, di.num_cu, nullptr)));
     RQ_PH(TP_CENTERS, RQ_TRY(update_centers_launch(dC.as<float>(), dcnt.as<unsigned int>(), dRX.as<float>(), dcodes.as<uint8_t>(), n, d,
                                  m, h, di.num_cu, nullptr)));
@@ -479,6 +506,12 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
     if (!fused_cb) RQ_PH(TP_RECONSTRUCT, RQ_TRY(reconstruct_launch(dCB.as<float>(), dcodes.as<uint8_t>(), dC.as<float>(), n, d, m, h, nullptr)));
   }
   prof.loop_end(niter + 1);
+  {
+    std::vector<double> accs((size_t)niter + 1);
+    RQ_HIP(hipStreamSynchronize(side.s));
+    RQ_HIP(hipMemcpy(accs.data(), dobj.p, accs.size() * 8, hipMemcpyDeviceToHost));
+    if (obj) for (int it = 0; it <= niter; ++it) obj[it] = (float)(accs[it] / (double)n);
+  }
   RQ_TRY(widen_codes_launch(d16.as<int16_t>(), dcodes.as<uint8_t>(), n * m, nullptr));
   RQ_HIP(hipDeviceSynchronize());
   prof.start();
