@@ -494,7 +494,9 @@ __device__ __forceinline__ uint32_t mask_leq16(const f32x16 &v, float thr) {
   return cm;
 }
 
-template <int SUB, int NT, int NWAVES>
+// DBG: the instantiation that stores the filter's W values (rq_dev_encode_pq_filter_w, tests only); the product kernel carries
+// none of that code (16 lane masks and a 64-bit address per tile)
+template <int SUB, int NT, int NWAVES, bool DBG = false>
 __global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams p) {
   using Shape = SplitShape<SUB>;
   constexpr bool PACK = Shape::PACK;
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_split_kernel(EncParams 
         return __builtin_fminf(mm, a[15]);
       };
       auto tile_filter = [&](const f32x16 &a, int t) {
-        if (p.dbg_w) {          // tests/test_gpu_encode_margin.py: the very values the filter decides on (wave-uniform branch)
+        if constexpr (DBG) {    // tests/test_gpu_encode_margin.py: the very values the filter decides on
           if (row0 + j < p.n) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1304,7 +1306,7 @@ static int launch_encode_split(EncParams p, int num_cu, hipStream_t stream) {
   const size_t budget = 160 * 1024 - 64;
   const int gmax = (int)std::min<size_t>(budget / per_sub, (size_t)p.m);
   if (gmax < 1) return fail(RQ_EUNSUPPORTED, "split encode: one sub-codebook needs %zu B of LDS", per_sub);
-  auto kern = encode_pq_split_kernel<SUB, NT, NWAVES>;
+  auto kern = p.dbg_w ? encode_pq_split_kernel<SUB, NT, NWAVES, true> : encode_pq_split_kernel<SUB, NT, NWAVES, false>;
   const int64_t ntiles = (p.n + 31) / 32;
   const int grid = (int)std::min<int64_t>(num_cu, (ntiles + NWAVES - 1) / NWAVES);
   for (int i0 = 0; i0 < p.m; i0 += gmax) {

@@ -144,7 +144,7 @@ def _mfma_asm_hazards(lines):
 
 
 def test_split_encode_asm_never_reads_unconsumed_mfma_results(encode_asm):
-    names = sorted(set(re.findall(r"\n(_ZN2rq22encode_pq_split_kernelILi\d+ELi\d+ELi\d+EEEvNS_9EncParamsE):", encode_asm)))
+    names = sorted(set(re.findall(r"\n(_ZN2rq22encode_pq_split_kernelILi\d+ELi\d+ELi\d+ELb[01]EEEvNS_9EncParamsE):", encode_asm)))
     assert len(names) >= 24, names        # 8 widths x 4 tile counts x 3 wave counts are instantiated
     checked = 0
     for name in names:
