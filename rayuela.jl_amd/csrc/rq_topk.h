@@ -504,7 +504,10 @@ __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_
 #pragma unroll 1
     for (uint32_t b0 = row; b0 <= bstar; b0 += NR * UB) {
       uint32_t lo[UB], hi[UB];
-      uint64_t first[UB];
+      // the first TWO 16-key chunks of every bucket in flight are loaded up front: with random splitters the bucket sizes are
+      // geometric (mean ~7.5), one bucket in ten has more than 16 keys, and a chunk fetched inside the loops below is a
+      // dependent global load -- with 16 buckets per wavefront and trip almost every trip waited for two of them
+      uint64_t first[UB], second[UB];
 #pragma unroll
       for (uint32_t u = 0; u < UB; ++u) {
         const uint32_t b = b0 + u * NR;
@@ -513,17 +516,21 @@ __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_
         hi[u] = on ? nxt[b] : 0u;
       }
 #pragma unroll
-      for (uint32_t u = 0; u < UB; ++u) first[u] = (lo[u] + l16 < hi[u]) ? dst[lo[u] + l16] : KEY_MAX;
+      for (uint32_t u = 0; u < UB; ++u) {
+        first[u] = (lo[u] + l16 < hi[u]) ? dst[lo[u] + l16] : KEY_MAX;
+        second[u] = (lo[u] + 16u + l16 < hi[u]) ? dst[lo[u] + 16u + l16] : KEY_MAX;
+      }
 #pragma unroll
       for (uint32_t u = 0; u < UB; ++u) {
 #pragma unroll 1
         for (uint32_t a = lo[u]; a < hi[u]; a += 16) {
           const bool have = a + l16 < hi[u];
-          const uint64_t mine = (a == lo[u]) ? first[u] : (have ? dst[a + l16] : KEY_MAX);
+          const uint64_t mine = (a == lo[u]) ? first[u] : (a == lo[u] + 16u) ? second[u] : (have ? dst[a + l16] : KEY_MAX);
           uint32_t r = lo[u];
 #pragma unroll 1
           for (uint32_t c = lo[u]; c < hi[u]; c += 16) {
-            const uint64_t other = (c == a) ? mine : (c == lo[u]) ? first[u] : ((c + l16 < hi[u]) ? dst[c + l16] : KEY_MAX);
+            const uint64_t other = (c == a) ? mine : (c == lo[u]) ? first[u] : (c == lo[u] + 16u) ? second[u]
+                                   : ((c + l16 < hi[u]) ? dst[c + l16] : KEY_MAX);
             r += (uint32_t)(other < mine);
             const uint32_t olo = (uint32_t)other, ohi = (uint32_t)(other >> 32);
             const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
