@@ -535,13 +535,22 @@ __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_
             const uint32_t olo = (uint32_t)other, ohi = (uint32_t)(other >> 32);
             const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
             uint32_t t;
+#if !defined(RQ_SS_ABL) || RQ_SS_ABL != 1
             asm volatile("s_nop 4\n" SS_ROTS(1) SS_ROTS(2) SS_ROTS(3) SS_ROTS(4) SS_ROTS(5) SS_ROTS(6) SS_ROTS(7)
                          SS_ROTS(8) SS_ROTS(9) SS_ROTS(10) SS_ROTS(11) SS_ROTS(12) SS_ROTS(13) SS_ROTS(14) SS_ROTS(15)
                          : "+v"(r), "=&v"(t)
                          : "v"(olo), "v"(ohi), "v"(mlo), "v"(mhi)
                          : "vcc");
+#endif
           }
+#if defined(RQ_SS_ABL) && RQ_SS_ABL == 1
+          r += l16;
+#endif
+#if !defined(RQ_SS_ABL) || RQ_SS_ABL != 2
           if (have && r < n_out) emit(r, mine);
+#else
+          if (have && r == 0xffffffffu) emit(r, mine);
+#endif
         }
       }
     }
