@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(NWAVES * 64) void rotate_kernel_v2(RotParams p) {
       swap32(z, w);   // z: dims (8q+2, 8q+3) = k-step 4q+1  w: dims (8q+6, 8q+7) = k-step 4q+3
       b[4 * q + 0] = x; b[4 * q + 1] = z; b[4 * q + 2] = y; b[4 * q + 3] = w;
     }
-#pragma unroll 1
+#pragma unroll 1      // (unrolled, so that a tile's stores overlap the next chain: spills, 0.31 -> 0.61 ms)
     for (int t = 0; t < NT; ++t) {
       // next tile's loads go out under the last chain of this one (keeps nx's live range short)
       if (t == NT - 1 && tile + total_waves < ntiles) gload(tile + total_waves);
@@ -1245,9 +1245,12 @@ __global__ __launch_bounds__(NWAVES * 64) void rotate_kernel_v2(RotParams p) {
   }
 }
 
+#ifndef RQ_ROT_NW
+#define RQ_ROT_NW 8
+#endif
 template <int KK>
 static int launch_rotate_v2(const RotParams &p, int num_cu, hipStream_t stream) {
-  constexpr int NW = 8;
+  constexpr int NW = RQ_ROT_NW;
   constexpr int NT = (2 * KK + 31) / 32;
   const size_t lds = (size_t)NT * KK * 64 * sizeof(float);
   auto kern = rotate_kernel_v2<KK, NW>;
