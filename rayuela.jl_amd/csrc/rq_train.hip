@@ -462,7 +462,11 @@ __global__ __launch_bounds__(NTT * 64) void gram_codes_kernel(CodesParams p) {
   constexpr int KS = NTT <= 4 ? 8 : 4;                    // K steps whose operands are fetched ahead of their MFMAs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hi = lane >> 5;
-  const int d = p.d, ld = NTT * 32, d4 = d / W;           // d4: W-wide units per row
+  const int d = p.d, ld = NTT * 32, d4 = ld / W;          // d4: W-wide units per row of the staged column blocks
+  // d > 32 NTT (d > 256 at NTT = 8): blockIdx.y = (A, B) picks the output block rows 32 NTT A .. and columns 32 NTT B ..;
+  // the stage then holds X's column block A and CB's column block B
+  const int nblk = (d + ld - 1) / ld;
+  const int acol0 = (int)(blockIdx.y / nblk) * ld, bcol0 = (int)(blockIdx.y % nblk) * ld;
   float *Xs = reinterpret_cast<float *>(smem);          // [32][ld]
   float *Hs = Xs + GRAMC_ROWS * ld;                     // [32][ld]
   for (int i = tid; i < 2 * GRAMC_ROWS * ld; i += NTHREADS) Xs[i] = 0.0f;     // the padding columns stay zero
@@ -472,13 +476,17 @@ __global__ __launch_bounds__(NTT * 64) void gram_codes_kernel(CodesParams p) {
   const int units = GRAMC_ROWS * d4;
   // this thread's units of a stage: (row, W dimensions); their sub-quantizer and gather base never change
   int urow[UPT], ucol[UPT], uq[UPT], ubase[UPT], usub[UPT];
+  bool xin[UPT], hin[UPT];
 #pragma unroll
   for (int u = 0; u < UPT; ++u) {
     const int e = tid + u * NTHREADS;
     urow[u] = e < units ? e / d4 : -1;
-    ucol[u] = e < units ? W * (e % d4) : 0;
-    uq[u] = codes_subq(p, ucol[u]);
-    ubase[u] = p.h * p.off[uq[u]] + (ucol[u] - p.off[uq[u]]);      // + code * sub
+    ucol[u] = e < units ? W * (e % d4) : 0;                       // column inside the staged blocks
+    xin[u] = urow[u] >= 0 && acol0 + ucol[u] < d;
+    hin[u] = urow[u] >= 0 && bcol0 + ucol[u] < d;
+    const int hcol = hin[u] ? bcol0 + ucol[u] : 0;
+    uq[u] = codes_subq(p, hcol);
+    ubase[u] = p.h * p.off[uq[u]] + (hcol - p.off[uq[u]]);         // + code * sub
     usub[u] = p.off[uq[u] + 1] - p.off[uq[u]];
   }
   int cd[UPT];
@@ -487,16 +495,16 @@ __global__ __launch_bounds__(NTT * 64) void gram_codes_kernel(CodesParams p) {
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
       const int64_t row = r0 + (int64_t)s * GRAMC_ROWS + urow[u];
-      cd[u] = (urow[u] >= 0 && row < r1) ? (int)p.codes[row * p.m + uq[u]] : 0;
+      cd[u] = (hin[u] && row < r1) ? (int)p.codes[row * p.m + uq[u]] : 0;
     }
   };
   auto load_data = [&](int s) {
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
       const int64_t row = r0 + (int64_t)s * GRAMC_ROWS + urow[u];
-      const bool in = urow[u] >= 0 && row < r1;
-      xv[u] = in ? *reinterpret_cast<const V *>(p.X + row * d + ucol[u]) : VecW<W>::zero();
-      hv[u] = in ? *reinterpret_cast<const V *>(p.C + ubase[u] + cd[u] * usub[u]) : VecW<W>::zero();
+      const bool in = row < r1;
+      xv[u] = (in && xin[u]) ? *reinterpret_cast<const V *>(p.X + row * d + acol0 + ucol[u]) : VecW<W>::zero();
+      hv[u] = (in && hin[u]) ? *reinterpret_cast<const V *>(p.C + ubase[u] + cd[u] * usub[u]) : VecW<W>::zero();
     }
   };
   f32x16 acc[NTT];
@@ -545,7 +553,7 @@ __global__ __launch_bounds__(NTT * 64) void gram_codes_kernel(CodesParams p) {
   for (int i = 0; i < NTT; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int ii = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi, jj = 32 * i + j;
+      const int ii = acol0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi, jj = bcol0 + 32 * i + j;
       if (ii < d && jj < d) out[(size_t)ii * d + jj] = acc[i][r];
     }
   }
@@ -912,7 +920,7 @@ int qerror_launch(double *acc_dev, const float *X, const float *CB, int64_t n, i
 int codes_forms_width(int d, int m, int h, bool for_gram) {
   if (!tuning("TRAIN_FUSED_CB", 1)) return 0;
   if (m < 1 || m > 32 || d < m || (d & 1) || h < 1 || h > 256) return 0;
-  if (d > 1024 || (for_gram && d > 256)) return 0;
+  if (d > 1024) return 0;
   int off[33];
   fill_offsets(off, d, m);
   int w = 4;
@@ -933,13 +941,15 @@ template <int NTT, int W>
 static int gram_codes_run(CodesParams &p, int grid, size_t lds, hipStream_t stream) {
   auto kern = gram_codes_kernel<NTT, W>;
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTT * 64), lds, stream, p);
+  const int nblk = (p.d + 32 * NTT - 1) / (32 * NTT);
+  hipLaunchKernelGGL(kern, dim3(grid, nblk * nblk), dim3(NTT * 64), lds, stream, p);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
 }
 
 template <int W>
 static int gram_codes_pick(CodesParams &p, int grid, size_t lds, hipStream_t stream) {
+  if (p.NT > 8) return gram_codes_run<8, W>(p, grid, lds, stream);        // d > 256: 256-wide output blocks, blockIdx.y
   switch (p.NT) {
     case 1: return gram_codes_run<1, W>(p, grid, lds, stream);
     case 2: return gram_codes_run<2, W>(p, grid, lds, stream);
@@ -961,13 +971,16 @@ int gram_codes_launch(float *G, const float *X, const uint8_t *codes, const floa
   CodesParams p;
   fill_codes_params(p, X, codes, C, n, d, m, h);
   // workgroups of NT wavefronts, 8 wavefronts per CU (measured 4 ... 32: 8 is best at d = 128 and d = 96 -- more workgroups mean more
-  // partial matrices to write and reduce, fewer leave the matrix pipe idle at the stage barriers)
-  const int per_cu = std::max(1, tuning("GRAM_WAVES_PER_CU", 8) / p.NT);
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * num_cu, (n + 255) / 256));
+  // partial matrices to write and reduce, fewer leave the matrix pipe idle at the stage barriers); d > 256: nblk^2 output
+  // blocks of 256 x 256 per row slice
+  const int ntt = std::min(p.NT, 8);
+  const int nblk = (p.NT + ntt - 1) / ntt;
+  const int per_cu = std::max(1, tuning("GRAM_WAVES_PER_CU", 8) / ntt);
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, (int64_t)per_cu * num_cu / (nblk * nblk)), (n + 255) / 256));
   void *part = nullptr;
   RQ_TRY(workspace(WS_TMP, (size_t)grid * d * d * sizeof(float), &part, stream));
   p.partial = (float *)part;
-  const size_t lds = (size_t)2 * GRAMC_ROWS * p.NT * 32 * sizeof(float);
+  const size_t lds = (size_t)2 * GRAMC_ROWS * ntt * 32 * sizeof(float);
   if (w == 4) RQ_TRY(gram_codes_pick<4>(p, grid, lds, stream));
   else RQ_TRY(gram_codes_pick<2>(p, grid, lds, stream));
   return partials_reduce<float>(G, p.partial, (size_t)d * d, grid, d * d, stream);

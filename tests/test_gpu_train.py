@@ -357,7 +357,8 @@ def test_update_centers_kernels_agree(rq, n, d, m, h):
 
 
 @pytest.mark.parametrize("n,d,m,h", [(30_000, 128, 8, 256), (20_001, 96, 16, 256), (20_001, 96, 8, 256), (5_000, 64, 8, 64), (12_345, 160, 4, 100),
-                                     (8_000, 128, 32, 256), (6_000, 256, 32, 64), (4_000, 30, 5, 17),
+                                     (8_000, 128, 32, 256), (6_000, 256, 32, 64), (4_000, 30, 5, 17), (3_000, 320, 8, 64),
+                                     (2_500, 960, 8, 256), (2_000, 520, 4, 16),
                                      (9_000, 256, 8, 256), (7_777, 32, 2, 16), (100, 8, 2, 4), (31, 128, 8, 256)])
 def test_gram_and_qerror_from_codes_match_the_reconstructed_forms(rq, n, d, m, h):
     """gram_codes / qerror_codes gather CB[j] = C[codes[j]] inside the kernel (src/OPQ.jl:101,108,112 without the n x d
