@@ -1330,13 +1330,82 @@ __device__ __forceinline__ double ns_tile(const double *__restrict__ X, const do
   return (acc0 + acc1) + (acc2 + acc3);
 }
 
+// The same product on 64 x 64 output tiles, 4 x 4 outputs per thread (d >= 384: at d = 960 the 16 x 16 tiles above -- two LDS
+// reads per FMA, 3600 tiles over 256 workgroups -- ran at 3 TF: 39 ms per polar factor): per k step a thread reads 4 + 4
+// doubles (four ds_read_b128) for 16 FMAs.  K in chunks of 32 through LDS (the same 34 KiB).
+constexpr int NSB_T = 64, NSB_KC = 32, NSB_LDA = 66;
+template <int MODE>
+__device__ __forceinline__ void ns_tile_big(const double *__restrict__ X, const double *__restrict__ Y, int d, int I, int J, double a,
+                                            double b, double *As, double *Bs, double (&acc)[4][4]) {
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  constexpr int PER = NSB_KC * NSB_T / NS_THREADS;        // 8 elements of each operand per thread and chunk
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+  // the chunk after the one being multiplied is already on its way from memory (registers), so that a chunk costs
+  // max(load latency, its 32 k steps) and not their sum
+  double pa[PER], pb[PER];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + u * NS_THREADS;
+      if (MODE == 0) {
+        const int k = e >> 6, c = e & 63, kk = k0 + k;
+        pa[u] = (kk < d && NSB_T * I + c < d) ? X[(size_t)kk * d + NSB_T * I + c] : 0.0;
+        pb[u] = (kk < d && NSB_T * J + c < d) ? X[(size_t)kk * d + NSB_T * J + c] : 0.0;
+      } else {
+        const int ka = e & (NSB_KC - 1), ca = e >> 5;                    // k fastest: rows of X are read along k
+        pa[u] = (k0 + ka < d && NSB_T * I + ca < d) ? X[(size_t)(NSB_T * I + ca) * d + k0 + ka] : 0.0;
+        const int k = e >> 6, c = e & 63, kk = k0 + k, col = NSB_T * J + c;
+        pb[u] = (kk < d && col < d) ? __builtin_fma(b, Y[(size_t)kk * d + col], kk == col ? a : 0.0) : 0.0;
+      }
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + u * NS_THREADS;
+      if (MODE == 0) {
+        As[(e >> 6) * NSB_LDA + (e & 63)] = pa[u];
+      } else {
+        As[(e & (NSB_KC - 1)) * NSB_LDA + (e >> 5)] = pa[u];
+      }
+      Bs[(e >> 6) * NSB_T + (e & 63)] = pb[u];
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < d; k0 += NSB_KC) {
+    __syncthreads();
+    stash();
+    __syncthreads();
+    if (k0 + NSB_KC < d) fetch(k0 + NSB_KC);
+#pragma unroll 4
+    for (int k = 0; k < NSB_KC; ++k) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) av[r] = As[k * NSB_LDA + 4 * ti + r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bv[c] = Bs[k * NSB_T + 4 * tj + c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_fma(av[r], bv[c], acc[r][c]);
+    }
+  }
+}
+
+// TS = 16: one output per thread (ns_tile); TS = 64: 4 x 4 outputs per thread (ns_tile_big)
+template <int TS>
 __global__ __launch_bounds__(NS_THREADS) void polar_ns_kernel(NsParams p) {
-  __shared__ double As[NS_KC * NS_LDA];
-  __shared__ double Bs[NS_KC * NS_T];
+  constexpr int R = TS / 16;
+  constexpr int AS_SZ = TS == 16 ? NS_KC * NS_LDA : NSB_KC * NSB_LDA, BS_SZ = TS == 16 ? NS_KC * NS_T : NSB_KC * NSB_T;
+  __shared__ double As[AS_SZ];
+  __shared__ double Bs[BS_SZ];
   __shared__ double red[NS_THREADS];
   __shared__ int s_ok;
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-  const int d = p.d, T = (d + NS_T - 1) / NS_T, ntile = T * T;
+  const int d = p.d, T = (d + TS - 1) / TS, ntile = T * T;
   const unsigned int nwg = gridDim.x, wg = blockIdx.x;
   unsigned int target = 0;
   // |G|_F^2, by every workgroup in the same order
@@ -1348,25 +1417,37 @@ __global__ __launch_bounds__(NS_THREADS) void polar_ns_kernel(NsParams p) {
     return;
   }
   const double inv = 1.0 / sqrt(fro2);
-  for (int t = wg; t < ntile; t += nwg) {
-    const int i = NS_T * (t / T) + ti, j = NS_T * (t % T) + tj;
-    if (i < d && j < d) p.X0[(size_t)i * d + j] = (double)p.G[(size_t)i * d + j] * inv;
-  }
+  for (int e = (int)wg * NS_THREADS + tid; e < d * d; e += (int)nwg * NS_THREADS) p.X0[e] = (double)p.G[e] * inv;
   if (!ns_grid_barrier(p.bar, target, nwg, &s_ok)) { if (tid == 0) p.status[0] = 1; return; }
   double *cur = p.X0, *nxt = p.X1;
   double l = p.l0;
   int it = 0, ok = 0;
+  // the thread's outputs of tile (I, J): rows TS I + R ti + r, columns TS J + R tj + c
+  auto tile = [&](int mode, const double *Xc, int I, int J, double a, double b, double (&o)[R][R]) {
+    if constexpr (TS == 16) {
+      o[0][0] = mode == 0 ? ns_tile<0>(Xc, nullptr, d, I, J, 0.0, 0.0, As, Bs) : ns_tile<1>(Xc, p.Y, d, I, J, a, b, As, Bs);
+    } else {
+      if (mode == 0) ns_tile_big<0>(Xc, nullptr, d, I, J, 0.0, 0.0, As, Bs, o);
+      else ns_tile_big<1>(Xc, p.Y, d, I, J, a, b, As, Bs, o);
+    }
+  };
   for (;; ++it) {
     double perr = 0.0;
     for (int t = wg; t < ntile; t += nwg) {
       const int I = t / T, J = t % T;
-      const double y = ns_tile<0>(cur, nullptr, d, I, J, 0.0, 0.0, As, Bs);
-      const int i = NS_T * I + ti, j = NS_T * J + tj;
-      if (i < d && j < d) {
-        p.Y[(size_t)i * d + j] = y;
-        const double dv = y - (i == j ? 1.0 : 0.0);
-        perr = __builtin_fma(dv, dv, perr);
-      }
+      double o[R][R];
+      tile(0, cur, I, J, 0.0, 0.0, o);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+          const int i = TS * I + R * ti + r, j = TS * J + R * tj + c;
+          if (i < d && j < d) {
+            p.Y[(size_t)i * d + j] = o[r][c];
+            const double dv = o[r][c] - (i == j ? 1.0 : 0.0);
+            perr = __builtin_fma(dv, dv, perr);
+          }
+        }
     }
     const double mine = ns_block_sum(perr, red);
     if (tid == 0) p.part[(size_t)it * nwg + wg] = mine;
@@ -1385,18 +1466,25 @@ __global__ __launch_bounds__(NS_THREADS) void polar_ns_kernel(NsParams p) {
     }
     for (int t = wg; t < ntile; t += nwg) {
       const int I = t / T, J = t % T;
-      const double x = ns_tile<1>(cur, p.Y, d, I, J, a, b, As, Bs);
-      const int i = NS_T * I + ti, j = NS_T * J + tj;
-      if (i < d && j < d) nxt[(size_t)i * d + j] = x;
+      double o[R][R];
+      tile(1, cur, I, J, a, b, o);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+          const int i = TS * I + R * ti + r, j = TS * J + R * tj + c;
+          if (i < d && j < d) nxt[(size_t)i * d + j] = o[r][c];
+        }
     }
     if (!ns_grid_barrier(p.bar, target, nwg, &s_ok)) { if (tid == 0) p.status[0] = 1; return; }
     double *tmp = cur; cur = nxt; nxt = tmp;
   }
   if (wg == 0 && tid == 0) { p.status[0] = ok ? 0 : 1; p.status[1] = it; }
   if (!ok) return;
-  for (int t = wg; t < ntile; t += nwg) {
-    const int i = NS_T * (t / T) + ti, j = NS_T * (t % T) + tj;          // X[i][j] = R[i][j]  ->  Rimg[j * d + i]
-    if (i < d && j < d) p.Rimg[(size_t)j * d + i] = (float)cur[(size_t)i * d + j];
+  // X[i][j] = R[i][j]  ->  Rimg[j * d + i]
+  for (int e = (int)wg * NS_THREADS + tid; e < d * d; e += (int)nwg * NS_THREADS) {
+    const int i = e / d, j = e - i * d;
+    p.Rimg[(size_t)j * d + i] = (float)cur[e];
   }
 }
 
@@ -1409,7 +1497,9 @@ size_t polar_ns_scratch_bytes(int d, int num_cu) {
 int polar_ns_launch(float *Rimg, const float *G, int d, int *status, void *scratch, int num_cu, hipStream_t stream) {
   if (d < 1 || d > 1024) return fail(RQ_EUNSUPPORTED, "device polar factor: d <= 1024; got %d", d);
   NsParams p;
-  const int T = (d + NS_T - 1) / NS_T;
+  // 16 x 16 output tiles, one per thread-block of 256 outputs; from d = 384 on 64 x 64 tiles with 4 x 4 outputs per thread
+  const bool big = d >= tuning("TRAIN_NS_BIG_D", 384);
+  const int T = big ? (d + NSB_T - 1) / NSB_T : (d + NS_T - 1) / NS_T;
   const int nwg = std::max(1, std::min(T * T, num_cu));
   p.G = G; p.Rimg = Rimg; p.status = status; p.d = d;
   p.maxit = 96;
@@ -1421,7 +1511,8 @@ int polar_ns_launch(float *Rimg, const float *G, int d, int *status, void *scrat
   p.part = s + (size_t)3 * d * d;
   p.bar = reinterpret_cast<unsigned int *>(p.part + (size_t)(p.maxit + 2) * nwg);
   RQ_HIP(hipMemsetAsync(p.bar, 0, 8, stream));
-  hipLaunchKernelGGL(polar_ns_kernel, dim3(nwg), dim3(NS_THREADS), 0, stream, p);
+  if (big) hipLaunchKernelGGL(polar_ns_kernel<64>, dim3(nwg), dim3(NS_THREADS), 0, stream, p);
+  else hipLaunchKernelGGL(polar_ns_kernel<16>, dim3(nwg), dim3(NS_THREADS), 0, stream, p);
   RQ_HIP(hipGetLastError());
   return RQ_OK;
 }

@@ -246,7 +246,7 @@ def _polar_cases(d, rng):
     yield "orthogonal_already", Q2
 
 
-@pytest.mark.parametrize("d", [2, 6, 30, 96, 128, 130, 200])
+@pytest.mark.parametrize("d", [2, 6, 30, 96, 128, 130, 200, 384, 500, 960])
 def test_device_polar_factor_matches_the_svd(rq, d):
     """src/OPQ.jl:112-113: U, S, VV = svd(X * CB'); R = U * VV'.  The Newton-Schulz kernel (what rq_train_opq runs) and the
     Jacobi kernel against LAPACK's SVD in float64: |R - U V'| <= 1e-6 (f32 storage of R and of G; the factor's condition
@@ -255,6 +255,8 @@ def test_device_polar_factor_matches_the_svd(rq, d):
     from rayuela_jl_amd import device as rqd
     rng = np.random.default_rng(d)
     for name, G in _polar_cases(d, rng):
+        if d > 256 and name not in ("gaussian", "pca_like"):      # (the 64 x 64-tile kernel; float64 SVDs of this size take a second each)
+            continue
         G32 = np.ascontiguousarray(G, dtype=np.float32)
         P, s = _polar_ref(G32)
         tol = max(2e-6, 4e-7 * s[0] / s[-1] * 0.01) if name != "kappa1e6" else 5e-2
