@@ -1179,6 +1179,98 @@ __global__ __launch_bounds__(NWAVES * 64) void rotate_wide_kernel(RotParams p) {
   }
 }
 
+// The same chunked rotation with COALESCED, PREFETCHED staging (d % 4 == 0, 16-byte aligned X and R; round 4).  The kernel
+// above fills its LDS panels with 48 scalar loads per thread and chunk (R read across its rows: one cache line per lane) and
+// multiplies only after they have landed: 36 TF at d = 960.  Here a thread fetches the next chunk as twelve 16-byte loads
+// along k (8 of the R panel, 4 of its wavefront's X slice) into registers BEFORE the 128 MFMAs of the current chunk and
+// writes them into the A-fragment / transposed layouts afterwards; the panel rows are padded to 65 floats so that those
+// writes spread over the banks.  Same k-ordered chain per output, same bits.
+constexpr int RW_RA_STRIDE = 65;
+template <int NWAVES, int TG>
+__global__ __launch_bounds__(NWAVES * 64) void rotate_wide2_kernel(RotParams p) {
+  static_assert(NWAVES == 4 && TG == 8, "thread mapping of the staging loads");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int KC = 32, KS = KC / 2;
+  float *RA = reinterpret_cast<float *>(smem);                       // [TG][KS] rows of RW_RA_STRIDE (64 used)
+  float *xs_all = RA + (size_t)TG * KS * RW_RA_STRIDE;               // NWAVES * KC * XS_STRIDE
+  const int d = p.d, NT = p.NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  float *xs = xs_all + (size_t)wave * (KC * XS_STRIDE);
+  const int64_t ntiles = (p.n + 31) / 32;
+  const int64_t nbatches = (ntiles + NWAVES - 1) / NWAVES;
+  // staging roles: R panel -- thread -> (panel row tid / 8 of every tile t, k quad tid % 8); X slice -- lane -> (row lane / 8 + 8 v, k quad lane % 8)
+  const int rrow = tid >> 3, rq4 = tid & 7;
+  const int xrow = lane >> 3, xq4 = lane & 7;
+  for (int64_t batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
+    const int64_t tile = batch * NWAVES + wave;
+    const int64_t row0 = tile * 32;
+    for (int g0 = 0; g0 < NT; g0 += TG) {
+      f32x16 acc[TG];
+#pragma unroll
+      for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+      float4 ra4[TG], x4[4];
+      auto fetch = [&](int k0) {
+        const int kr = k0 + 4 * rq4;
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+          const int i = (g0 + t) * 32 + rrow;
+          ra4[t] = (i < d && kr < d) ? *reinterpret_cast<const float4 *>(p.R + (size_t)i * d + kr) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int kx = k0 + 4 * xq4;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          int64_t gr = row0 + xrow + 8 * v;
+          if (gr >= p.n) gr = p.n - 1;
+          x4[v] = kx < d ? *reinterpret_cast<const float4 *>(p.X + gr * d + kx) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      };
+      auto stash = [&]() {
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+          // k = 4 rq4 + e  ->  k step 2 rq4 + e / 2, half e & 1
+          float *dst = RA + (size_t)(t * KS + 2 * rq4) * RW_RA_STRIDE + rrow;
+          dst[0] = ra4[t].x; dst[32] = ra4[t].y; dst[RW_RA_STRIDE] = ra4[t].z; dst[RW_RA_STRIDE + 32] = ra4[t].w;
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          float *dst = xs + (4 * xq4) * XS_STRIDE + xrow + 8 * v;
+          dst[0] = x4[v].x; dst[XS_STRIDE] = x4[v].y; dst[2 * XS_STRIDE] = x4[v].z; dst[3 * XS_STRIDE] = x4[v].w;
+        }
+      };
+      fetch(0);
+      for (int k0 = 0; k0 < d; k0 += KC) {
+        __syncthreads();
+        stash();
+        __syncthreads();
+        if (k0 + KC < d) fetch(k0 + KC);
+        const float *xb = xs + hi * XS_STRIDE + j;
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+          const float *ra = RA + (size_t)t * KS * RW_RA_STRIDE + lane;
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk * RW_RA_STRIDE], xb[2 * kk * XS_STRIDE], acc[t], 0, 0, 0);
+        }
+      }
+      if (row0 + j < p.n) {
+        float *o = p.RX + (size_t)(row0 + j) * d;
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int i0 = (g0 + t) * 32 + 4 * hi + 8 * g4;
+            if (i0 < d)
+              *reinterpret_cast<float4 *>(o + i0) = make_float4(acc[t][g4 * 4 + 0], acc[t][g4 * 4 + 1], acc[t][g4 * 4 + 2], acc[t][g4 * 4 + 3]);
+          }
+        }
+      }
+    }
+  }
+}
+
 // Rotation, fast path for d % 8 == 0 (KK = d/2 compile time): the 32 x d tile of X never touches
 // LDS.  Lane (j, hi) loads the 16-byte pieces X[j][8q + 4hi .. +3]; two v_permlane32_swap per piece
 // pair turn them into the B fragments of k-steps 4q..4q+3 (lanes 0-31 the even, 32-63 the odd
@@ -1448,6 +1540,15 @@ int rotate_launch(float *RX, const float *R, const float *X, int d, int64_t n, i
   if (lds > 160 * 1024) {
     // R does not fit the LDS: chunked kernel (any d)
     constexpr int TG = 8, KC = 32;
+    if (tuning("ROT_WIDE2", 1) && (d & 3) == 0 && (((uintptr_t)X | (uintptr_t)R | (uintptr_t)RX) & 15) == 0) {
+      const size_t lds2 = ((size_t)TG * (KC / 2) * RW_RA_STRIDE + (size_t)NW * KC * XS_STRIDE) * sizeof(float);
+      auto wk2 = rotate_wide2_kernel<NW, TG>;
+      RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wk2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      const int64_t nb2 = ((n + 31) / 32 + NW - 1) / NW;
+      hipLaunchKernelGGL(wk2, dim3((int)std::min<int64_t>(2 * (int64_t)num_cu, nb2)), dim3(NW * 64), lds2, stream, p);
+      RQ_HIP(hipGetLastError());
+      return RQ_OK;
+    }
     const size_t wlds = ((size_t)TG * (KC / 2) * 64 + (size_t)NW * KC * XS_STRIDE) * sizeof(float);
     auto wk = rotate_wide_kernel<NW, TG, KC>;
     RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));

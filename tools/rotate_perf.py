@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rayuela_jl_amd as rq
 import rayuela_jl_amd.synth as synth
 from rayuela_jl_amd import device as rqd
-for d in (128, 96):
-    n = 1_000_000
+for d in (128, 96, 960, 320):
+    n = 1_000_000 if d <= 128 else 200_000
     X = torch.randn((n, d), device="cuda")
     R = torch.from_numpy(synth.rotation(d)).cuda()
     out = torch.empty_like(X)
