@@ -18,10 +18,12 @@
 // Two details the kernel's row tiling dictates (rq_scan.hip):
 //  * lane j of half-wave h handles rows  tile*T + h*32*RPT + j*RPT + r  (T = 64*RPT, r < RPT), so the 32 consecutive rows
 //    of the sort order that should meet in one gather are DEALT to those positions;
-//  * the second threshold estimate (retune_tau) treats the first eighth of a slice as a random sample of it, and the
-//    XCD windows / row slices treat any row range alike.  A sorted base breaks that (measured: 487 of 1250 items fell
-//    back to the exact redo, 2.4 -> 9.5 ms).  So whole granules of `gran` rows (one coalesced sub-step of a workgroup) are
-//    spread by a Weyl permutation g -> g*A mod G: any range of positions is a stratified sample of the sort order.
+//  * the threshold estimates of a work item are statistics of ROWS, and the XCD windows / row slices treat any row range
+//    alike.  A sorted base correlates position with content (measured: 487 of 1250 items fell back to the exact redo, 2.4 ->
+//    9.5 ms; on clustered data even a shuffle of 1024-row granules was not enough).  So (a) one block in every
+//    ORDER_SAMPLE_STRIDE (16) holds every 16th row of the base in ARRIVAL order -- the kernel visits a slice's sample blocks
+//    first and takes both estimates from them --, and (b) the sorted rows are spread tile by tile (64 * RPT rows) by a Weyl
+//    permutation g -> g * A mod G, so that any range of positions is a stratified sample of the sort order.
 #include "rq_internal.h"
 
 #include <cmath>
