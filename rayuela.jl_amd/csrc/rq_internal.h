@@ -45,7 +45,7 @@ void host_pool_free(void *p);
 void host_pool_trim();
 void sharded_cache_release();
 int aux_streams(hipStream_t *compute, hipStream_t *transfer);
-enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_PAD = 4, WS_MERGE = 5, WS_NORMB = 6, WS_ORDER = 7, WS_ORDER_TMP = 8, WS_SLOTS = 9 };
+enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_PAD = 4, WS_MERGE = 5, WS_NORMB = 6, WS_ORDER = 7, WS_ORDER_TMP = 8, WS_ENCFLAG = 9, WS_SLOTS = 10 };
 
 // Per-device launch lock (recursive): held while a call looks up scratch, resets the work counter and
 // launches, so two host threads cannot interleave those sequences on one device.

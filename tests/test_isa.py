@@ -159,6 +159,48 @@ def test_split_encode_asm_never_reads_unconsumed_mfma_results(encode_asm):
     assert checked >= 24
 
 
+@pytest.fixture(scope="module")
+def filter_asm(tmp_path_factory):
+    if not os.path.isfile(HIPCC):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa_filt") / "rq_encode_filter.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
+                           "--cuda-device-only", os.path.join(ROOT, "rayuela.jl_amd", "csrc", "rq_encode_filter.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def test_filter_encode_asm_never_reads_unconsumed_mfma_results(filter_asm):
+    """the shipped two-launch encode (rq_encode_filter.hip): the exec-masked copy of the winning tile and the v_cmp / v_addc
+    mask builder are the asm statements; neither may touch a register of an MFMA no compiler-visible VALU instruction has read"""
+    names = sorted(set(re.findall(r"\n(_ZN2rq23encode_pq_filter_kernelILi\d+ELi\d+ELi\d+ELb[01]EEEvNS_9EncParamsE):", filter_asm)))
+    assert len(names) >= 24, names
+    checked = 0
+    for name in names:
+        start = filter_asm.index("\n" + name + ":")
+        lines = filter_asm[start:filter_asm.index("s_endpgm", start)].splitlines()
+        assert any("v_mfma" in ln for ln in lines)
+        bad = _mfma_asm_hazards(lines)
+        assert not bad, "%s: inline asm reads MFMA results before any compiler-visible VALU read:\n%s" % (
+            name, "\n".join("%d: %s" % b for b in bad[:6]))
+        checked += 1
+    assert checked >= 24
+
+
+def test_filter_tile_loop_is_one_basic_block(filter_asm):
+    """the point of the round-5 rewrite: between the first and the last MFMA of a sub-quantizer there is no branch and no
+    label (SIFT and Deep bench shapes), so the LDS reads of tile t + 1 can be in flight under the MFMAs of tile t"""
+    for sub, nw in ((16, 12), (6, 16)):
+        name = "_ZN2rq23encode_pq_filter_kernelILi%dELi8ELi%dELb0EEEvNS_9EncParamsE" % (sub, nw)
+        start = filter_asm.index("\n" + name + ":")
+        lines = [ln.strip() for ln in filter_asm[start:filter_asm.index("s_endpgm", start)].splitlines()]
+        mf = [i for i, ln in enumerate(lines) if ln.startswith("v_mfma")]
+        assert len(mf) == (24 if sub > 8 else 16), len(mf)
+        body = lines[mf[0]:mf[-1]]
+        assert not any(ln.startswith("s_cbranch") or ln.startswith(".LBB") for ln in body), \
+            [ln for ln in body if ln.startswith("s_cbranch") or ln.startswith(".LBB")][:4]
+
+
 def test_mfma_hazard_walker_detects_a_planted_hazard():
     """the walker itself: an asm read straight behind the MFMA is flagged, one behind a v_min3 of the same tile is not"""
     unsafe = ["v_mfma_f32_32x32x16_bf16 v[0:15], v[86:89], v[58:61], v[0:15]", ";;#ASMSTART", "v_mov_b64 v[90:91], v[2:3]", ";;#ASMEND"]
