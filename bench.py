@@ -107,21 +107,45 @@ def timed(fn, steps, warmup, barrier):
     return e0.elapsed_time(e1), wall_ms
 
 
+def lib_build():
+    """the 12-hex-digit id of the kernel sources the loaded library was built from (rq_version())"""
+    from rayuela_jl_amd import _lib
+    v = (_lib.lib().rq_version() or b"").decode()
+    return v.split("build ")[-1] if "build " in v else "?"
+
+
 def load_traffic(kernel_key):
-    """HBM/fabric bytes per launch of `kernel_key` from the NEWEST committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE, separate runs; FETCH doubled per MI355X_MICROARCH.md section HBM).  Only the newest round's file counts:
-    a shape that was not re-measured after the kernels changed reports null, never an older round's bytes
-    (tools/profile_round4.sh + tools/collect_profiles.py rewrite the file)."""
-    for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-        except Exception:
-            continue
-        if kernel_key in tj:
-            e = tj[kernel_key]
-            return 2.0 * e["FETCH_SIZE_KiB"] * 1024 + e["WRITE_SIZE_KiB"] * 1024, "profiles/%s (%s)" % (name, e.get("source", ""))
-        return None, None
-    return None, None
+    """HBM/fabric bytes per launch of `kernel_key` from THIS round's committed PMC passes (profiles/r5_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE, separate runs; FETCH doubled per MI355X_MICROARCH.md section HBM).  The figure is a REPLAY
+    of a profiled run, so it is bound to what it was measured on: the entry names the kernel instantiation (as rocprofv3 and
+    rq_last_scan_kernel() spell it) and the library build id (rq_version()); if either differs from what just ran, traffic
+    is null and the reason is reported instead."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r5_traffic.json")))
+    except Exception:
+        return None, "no profiles/r5_traffic.json"
+    e = tj.get(kernel_key)
+    if e is None:
+        return None, "profiles/r5_traffic.json has no entry for this shape"
+    from rayuela_jl_amd import _lib
+    ran = (_lib.lib().rq_last_scan_kernel() or b"").decode()
+    build = lib_build()
+    if e.get("build") != build or e.get("kernel") != ran:
+        return None, ("not replayed: profiles/r5_traffic.json was measured on %s of build %s, this run launched %s of build %s"
+                      % (e.get("kernel"), e.get("build"), ran, build))
+    return (2.0 * e["FETCH_SIZE_KiB"] * 1024 + e["WRITE_SIZE_KiB"] * 1024,
+            "profiles/r5_traffic.json (%s; kernel %s, build %s: the ones this run used)" % (e.get("source", ""), ran, build))
+
+
+def load_encode_counters(kernel, sub):
+    """per-launch instruction counters of the encode kernels from this round's PMC passes (profiles/r5_encode_counters.json), bound
+    to the library build like the traffic figures; None when they do not describe the library that just ran"""
+    try:
+        ej = json.load(open(os.path.join(ROOT, "profiles", "r5_encode_counters.json")))
+    except Exception:
+        return None
+    e = ej.get("%s sub=%d" % (kernel, sub))
+    return e if e is not None and e.get("build") == lib_build() else None
 
 
 def scan_roofline(m, n_local, nq, K, kernel_ms):
@@ -329,6 +353,9 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+        # the ranks > 0 wait for rank 0's post-processing (checks, CPU baseline, the in-library leg over ALL devices) on the host:
+        # an RCCL barrier would park a spinning kernel on every GPU that leg is about to time
+        host_group = dist.new_group(backend="gloo")
 
     def barrier():
         if world > 1:
@@ -481,7 +508,11 @@ def main():
     qps = nq / (ms_step * 1e-3)                       # true queries/s against the whole n-row base
 
     if rank != 0:
-        barrier()
+        # release this rank's shard before rank 0 drives every device of the node from ONE process (inproc leg below)
+        res.clear()
+        ix = codes = X = None      # noqa: F841
+        torch.cuda.empty_cache()
+        dist.barrier(group=host_group)
         dist.destroy_process_group()
         return
 
@@ -495,22 +526,48 @@ def main():
         sub_w = d // m
         from rayuela_jl_amd import _lib as _l
         enc_kernel = (_l.lib().rq_last_encode_kernel() or b"").decode() or "?"      # what the library actually launched
-        split = enc_kernel == "encode_pq_split_kernel"
+        split = enc_kernel in ("encode_pq_split_kernel", "encode_pq_filter_kernel")
+        t_enc = enc_ms_step * 1e-3
         enc_roof = {"bound": "mfma", "kernel": enc_kernel,
                     "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
-                    "hbm_GBps": round((4.0 * d + m) * n_local / (enc_ms_step * 1e-3) / 1e9, 1),
+                    "hbm_GBps": round((4.0 * d + m) * n_local / t_enc / 1e9, 1),
                     "definition": "algorithmic 2*d*h flop per vector / time vs the f32 matrix peak (SURVEY.md 8d)"}
         if split:
-            # the distance products run as an exact FILTER on the bf16 matrix cores (3, or 2 for sub <= 8, K = 16 MFMAs per 32
-            # centroids x 32 vectors), only the candidates (~1.02 per vector and sub-quantizer) get the canonical f32
-            # evaluation -- so the f32 matrix peak is a yardstick here, not a ceiling; what binds is the VALU epilogue
+            # The distance products run as an exact FILTER on the bf16 matrix cores (3, or 2 for sub <= 8, K = 16 MFMAs per 32
+            # centroids x 32 vectors); pairs the filter cannot settle (2-3 %) get the canonical f32 evaluation in a second
+            # launch.  What binds is instruction ISSUE on the SIMDs: a 32 x 32 x 16 bf16 MFMA holds the matrix pipe 32 cycles,
+            # a wave64 VALU instruction its SIMD ~4, and in this kernel the two do not overlap (PMC: VALU-busy + MFMA-busy =
+            # the kernel's cycles, profiles/r5_pmc_counters.md).  frac = those issue cycles / (SIMDs x clock x time) -- a
+            # fraction of a real roof, never above 1; the SURVEY 8(d) yardsticks ride along.
             nmf = 2 if sub_w <= 8 else 3
-            bf_flops = 2.0 * 16 * 256 * nmf * m * n_local
-            enc_roof["note"] = ("exact argmin through a bf16 matrix-core filter + canonical f32 re-evaluation of the candidates: "
-                                "frac > 1 is possible because the products do not run at the f32 rate; bound = VALU epilogue")
-            enc_roof["bf16_mfma"] = {"issued_TFLOPs": round(bf_flops / (enc_ms_step * 1e-3) / 1e12, 1), "peak": 2500.0,
-                                     "frac": round(bf_flops / (enc_ms_step * 1e-3) / 1e12 / 2500.0, 4)}
+            n_mfma = nmf * ((h + 31) // 32) * m * ((n_local + 31) // 32)        # wave-level MFMA instructions per launch
+            bf_flops = 2.0 * 32 * 32 * 16 * n_mfma
+            cnt = load_encode_counters(enc_kernel, sub_w)
+            f32eq = {"achieved_TFLOPs": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "frac": round(tf / FP32_PEAK_TFLOPS, 4),
+                     "note": "SURVEY 8(d)'s yardstick (2*d*h flop per vector vs the f32 matrix peak); the products do not run at the "
+                             "f32 rate, so this may pass 1 and is not a fraction of a roof"}
+            enc_roof = {"bound": "simd-issue", "kernel": enc_kernel, "unit": "issue cycles/s", "traffic": None,
+                        "peak": NUM_CU * 4 * CLK_GHZ * 1e9,
+                        "definition": "(VALU wave-instructions x 4 + MFMA instructions x 32 cycles) per second vs 4 SIMDs x %d CUs x "
+                                      "%.1f GHz; instruction counts per launch from profiles/r5_encode_counters.json (PMC "
+                                      "SQ_INSTS_VALU / SQ_INSTS_MFMA of the same library build), scaled to this run's rows" % (NUM_CU, CLK_GHZ),
+                        "bf16_mfma": {"issued_TFLOPs": round(bf_flops / t_enc / 1e12, 1), "peak": 2500.0,
+                                      "frac": round(bf_flops / t_enc / 1e12 / 2500.0, 4)},
+                        "hbm": {"algorithmic_GBps": round((4.0 * d + m) * n_local / t_enc / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
+                                "frac": round((4.0 * d + m) * n_local / t_enc / 1e9 / HBM_PEAK_GBS, 4)},
+                        "f32_equivalent": f32eq}
+            if cnt is not None:
+                scale = float(n_local) / cnt["rows"]
+                valu = (cnt["SQ_INSTS_VALU"] - cnt["SQ_INSTS_MFMA"]) * scale
+                issue = (valu * 4.0 + cnt["SQ_INSTS_MFMA"] * scale * 32.0) / t_enc
+                enc_roof.update({"achieved": round(issue, 1), "frac": round(issue / enc_roof["peak"], 4),
+                                 "valu_insts_per_launch": round(valu), "mfma_insts_per_launch": round(cnt["SQ_INSTS_MFMA"] * scale),
+                                 "launches": cnt.get("launches", "tables + filter + exact pass")})
+            else:
+                enc_roof.update({"achieved": None, "frac": round(bf_flops / t_enc / 1e12 / 2500.0, 4),
+                                 "note": "no instruction counters for this library build in profiles/: frac falls back to the bf16 "
+                                         "matrix-core fraction"})
         if use_R:
             enc_roof["note"] = (enc_roof.get("note", "") + "; time includes the R'X rotation kernel (2*d*d f32-MFMA flop per vector more, "
                                 "not counted in achieved)").lstrip("; ")
@@ -727,6 +784,46 @@ def main():
         except Exception as e:   # noqa: BLE001 -- an anchor, not the measurement
             anchor = {"error": repr(e)[:200]}
 
+    # ---- N > 1: the SAME workload through the library's own multi-device index (rq_index_create_sharded: one process, one
+    # shard per device, per-shard top-k gathered with grouped ncclSend/ncclRecv on an ncclCommInitAll clique, merged on device
+    # 0) -- the path a Julia session takes (host code stays Julia: julia/RayuelaHIP.jl holds one handle), timed on the wall
+    # clock after the torch.distributed ranks are done with the GPUs.  `value` above is the one-process-per-GPU harness.
+    inproc_leg = None
+    if world > 1:
+        try:
+            ndev = torch.cuda.device_count()
+            devs = [i % ndev for i in range(world)] if debug_gloo else list(range(world))
+            ixl = rq.Index(C, d, devices=devs)
+            if big:
+                ixl.set_codes_synth(n, synth.SEED_BASE)
+            else:
+                Xw = torch.cat([gen(min(250_000, n - o), o) for o in range(0, n, 250_000)], 0)
+                cw = rqd.encode_opq(Xw, R, Ccat, m, h) if use_R else rqd.encode_pq(Xw, Ccat, m, h)
+                ixl.set_codes(cw.cpu().numpy())
+                del Xw, cw
+            Qh = Q.cpu().numpy()
+            Rh = None if R is None else R.cpu().numpy()
+            out_l = {}
+
+            def scan_lib():
+                out_l["r"] = ixl.search(Qh, K, R=Rh, id_base=0)
+            _, lib_wall = timed(scan_lib, a.steps, a.warmup, lambda: None)
+            info = ixl.info()
+            ld, li = out_l["r"]
+            same = bool(np.array_equal(np.asarray(ld).view(np.uint32), res["r"][0].cpu().numpy().view(np.uint32)) and
+                        np.array_equal(np.asarray(li).view(np.uint32), res["r"][1].cpu().numpy().view(np.uint32)))
+            inproc_leg = {"what": "rq_index_create_sharded over devices %s from this one process (rank 0), same base / queries / k" % devs,
+                          "ms_per_step": round(lib_wall / a.steps, 4), "value": round(nq / (lib_wall / a.steps * 1e-3), 1),
+                          "unit": "queries/s", "clock": "host wall clock around K searches (host queries in, host results out)",
+                          "exchange": info["exchange"], "shards": info["shards"], "devices": info["devices"],
+                          "rccl_ranks": info["shards"] if info["exchange"] == "rccl" else 0,
+                          "answer_identical": same}
+            if not debug_gloo and inproc_leg["rccl_ranks"] != world:
+                inproc_leg["error"] = "the library's exchange is %r over %d ranks, expected RCCL over %d" % (info["exchange"], inproc_leg["rccl_ranks"], world)
+            ixl.close()
+        except Exception as e:   # noqa: BLE001 -- a second measurement, never the headline
+            inproc_leg = {"error": repr(e)[:300]}
+
     if a.inproc:
         par = "one process, rq_index_create_sharded over %d shard(s) on device list %s: exchange=%s" % (
             ngpu, dev_list or list(range(ngpu)), ix_info["exchange"] if ix_info else "?")
@@ -755,13 +852,14 @@ def main():
         "row_order": order_info if (world == 1 and not big) else
                      ({"index_prepare_ms_once": round(ix.order_ms, 3)} if (not a.inproc and ix.order_ms is not None) else None),
         "same_workload_1gpu": ref1,
+        "inproc": inproc_leg,
         "scale_anchor_1gpu": anchor,
         "wall_ms_per_step": round(scan_wall / a.steps, 4),
     }
     print(json.dumps(line))
     sys.stdout.flush()
     if world > 1:
-        barrier()
+        dist.barrier(group=host_group)
         dist.destroy_process_group()
 
 

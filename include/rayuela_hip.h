@@ -48,7 +48,7 @@ extern "C" {
 
 #define RQ_MAX_K 65536      /* largest k the scan returns */
 
-const char *rq_version(void);
+const char *rq_version(void);              /* "rayuela-hip <ver> (gfx950) build <sha1 of the kernel sources, 12 hex digits>" */
 const char *rq_last_error(void);
 int rq_device_count(void);
 /* Select the device used by the calling thread's subsequent calls (hipSetDevice). */
@@ -159,6 +159,10 @@ int rq_dev_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n,
 /* Name of the kernel the calling thread's last encode call ran ("encode_pq_split_kernel", "encode_pq_direct_kernel", ...):
  * bench.py labels its encode roofline with it instead of guessing from the tuning. */
 const char *rq_last_encode_kernel(void);
+/* The scan kernel instantiation the calling thread's last linscan launched, spelled as rocprofv3 prints it
+ * ("adc_scan_kernel<8, false, true, false>"); "" before the first scan.  bench.py replays committed PMC traffic figures
+ * only for the very instantiation (and library build) they were measured on. */
+const char *rq_last_scan_kernel(void);
 /* Test aid (no reference counterpart): rq_dev_encode_pq through the split kernel (even sub-space widths <= 16), which also
  * stores the values its bf16 matrix-core FILTER decides on: W [n][m][h], W_k = |c_k|^2 - 2 <c_k, x> as the MFMAs produced it.
  * tests/test_gpu_encode_margin.py measures |(W_k + |x|^2) - v_k| against the bound the kernel's exactness rests on. */
@@ -237,7 +241,17 @@ int rq_dev_qerror_codes(double *acc, const float *X, const uint8_t *codes, const
  * when given they replace the random initialisation.  Every training entry point is bit-reproducible for a
  * given seed / start (segment sums in the matrix cores' fixed order, fixed reduction trees, a reproducible step count of the
  * polar iteration).  `seed` feeds the library's own
- * splitmix64 stream -- the reference uses Julia's global RNG, so equal seeds do not mean equal draws. */
+ * splitmix64 stream -- the reference uses Julia's global RNG, so equal seeds do not mean equal draws.
+ * The k-means of train_pq / train_rvq against Clustering.kmeans (v0.12.2, what src/PQ.jl:86 and src/RVQ.jl:104 call):
+ *   seeding      kmeans++ (init=:kmpp), the same law, other draws;
+ *   empty centre re-drawn with probability proportional to the points' current cost, costs lowered to the distance to each
+ *                new centre before the next draw (Clustering.repick_unused_centers), other draws;
+ *   stopping     Clustering: |objv - prev_objv| < 1e-6 absolute on a Float32 sum of costs, or maxiter; here: no assignment
+ *                changed, or niter -- the same iteration whenever the objective exceeds ~10 (float32 resolution above 1e-6:
+ *                an unchanged rounded objective then means unchanged assignments); data of tiny magnitude (objective below
+ *                ~10) stops EARLIER in Clustering than here;
+ *   all sub-spaces iterate together and stop together (a sub-space that is stationary early is recomputed to the same bits).
+ * tests/test_gpu_train.py holds the final error against oracle/train_oracle.py::train_pq_clustering (those rules) on 3 seeds. */
 int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n, int d, int m, int h,
                 int niter, uint64_t seed);
 /* kmeans++ seeding as train_pq / train_rvq use it (Clustering.jl init=:kmpp, call sites src/PQ.jl:86 and

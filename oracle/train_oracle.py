@@ -69,3 +69,79 @@ def train_opq(X, m, h, niter, R0, C0, fast=False):
         codes = oracle.encode_pq(RX, cat(C), m, h)
         CB = reconstruct(C, codes, off, d)
     return C, codes, R, obj
+
+
+def kmeans_clustering(Xs, h, maxiter, rng, tol=1e-6):
+    """Clustering.kmeans(Xs, h, init=:kmpp, maxiter=...) as Clustering.jl v0.12.2 runs it (`_kmeans!`; call sites src/PQ.jl:86,
+    src/RVQ.jl:104), restated from the published algorithm (the package is not in /root/reference: PARITY UNPINNED, like the
+    encode): kmeans++ seeding; then per iteration  update_centers! (means; an emptied cluster keeps its value) ->
+    repick_unused_centers (a centre without points is re-drawn with probability proportional to the points' current cost, the
+    costs lowered to the distance to every new centre before the next draw) -> distances + update_assignments! (first-index
+    argmin, strict '<') -> objv = sum(costs); stop when |objv - prev_objv| < tol (tol = 1e-6 ABSOLUTE, Float32 sums) or at
+    maxiter.  Draws come from `rng` (numpy Generator), not Julia's stream.  Xs (n, sub) float32.  Returns (C (h, sub) f32,
+    assignments (n,), objv, iterations)."""
+    Xs = np.ascontiguousarray(Xs, dtype=np.float32)
+    n, sub = Xs.shape
+    X64 = Xs.astype(np.float64)
+
+    def dist_to(c):
+        e = X64 - c.astype(np.float64)[None, :]
+        return (e * e).sum(1)
+    # kmeans++ (Clustering.kmpp): first centre uniform, the others with probability proportional to the min cost so far
+    C = np.empty((h, sub), dtype=np.float32)
+    j = int(rng.integers(n))
+    C[0] = Xs[j]
+    mincost = dist_to(C[0])
+    for k in range(1, h):
+        tot = mincost.sum()
+        j = int(np.searchsorted(np.cumsum(mincost), rng.random() * tot, side="right")) if tot > 0 else int(rng.integers(n))
+        j = min(j, n - 1)
+        C[k] = Xs[j]
+        mincost = np.minimum(mincost, dist_to(C[k]))
+
+    def assign(C):
+        codes = oracle.encode_pq(Xs, np.ascontiguousarray(C).reshape(-1), 1, h)[:, 0].astype(np.int64)
+        e = X64 - C.astype(np.float64)[codes]
+        costs = (e * e).sum(1).astype(np.float32)
+        return codes, costs
+    codes, costs = assign(C)
+    objv = float(costs.sum(dtype=np.float32))
+    it = 0
+    while it < maxiter:
+        it += 1
+        cnt = np.bincount(codes, minlength=h)
+        for s in range(sub):
+            sums = np.bincount(codes, weights=X64[:, s], minlength=h)
+            C[cnt > 0, s] = (sums[cnt > 0] / cnt[cnt > 0]).astype(np.float32)
+        unused = np.flatnonzero(cnt == 0)
+        if unused.size:
+            tc = costs.astype(np.float64).copy()
+            for k in unused:
+                tot = tc.sum()
+                j = int(np.searchsorted(np.cumsum(tc), rng.random() * tot, side="right")) if tot > 0 else int(rng.integers(n))
+                j = min(j, n - 1)
+                tc[j] = 0.0
+                C[k] = Xs[j]
+                tc = np.minimum(tc, dist_to(C[k]))
+        codes, costs = assign(C)
+        prev, objv = objv, float(costs.sum(dtype=np.float32))
+        if abs(objv - prev) < tol:
+            break
+    return C, codes, objv, it
+
+
+def train_pq_clustering(X, m, h, niter, seed):
+    """train_pq (src/PQ.jl:68-99): one Clustering.kmeans per sub-space (kmeans_clustering above), then the quantisation error of
+    the final assignment (qerror_pq, src/qerrors.jl:93-100).  Returns (C list, codes (n, m) uint8, error)."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    n, d = X.shape
+    off = offsets(d, m)
+    rng = np.random.default_rng(seed)
+    C, codes = [], np.empty((n, m), dtype=np.uint8)
+    for i in range(m):
+        Ci, _, _, _ = kmeans_clustering(X[:, off[i]:off[i + 1]], h, niter, rng)
+        C.append(Ci)
+    codes = oracle.encode_pq(X, np.concatenate([c.reshape(-1) for c in C]), m, h)
+    CB = reconstruct(C, codes, off, d)
+    err = float(((X.astype(np.float64) - CB) ** 2).sum() / n)
+    return C, codes, err

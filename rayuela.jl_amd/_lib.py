@@ -25,6 +25,7 @@ _vp, _i32, _i64, _u32, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_ui
 # name -> (restype, argtypes); kept in sync with include/rayuela_hip.h (tests/test_cabi.py checks it)
 SIGNATURES = {
     "rq_version": (C.c_char_p, []),
+    "rq_last_scan_kernel": (C.c_char_p, []),
     "rq_last_error": (C.c_char_p, []),
     "rq_device_count": (_i32, []),
     "rq_set_device": (_i32, [_i32]),

@@ -413,10 +413,22 @@ int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *code
   // (order_base: index handles, rq_dev_order_rows, the host-pointer calls).  Otherwise the call orders a copy itself when
   // that pays: the four small kernels cost ~40 us at 1e6 rows, a scan of nq queries gains ~15 % of its time -- from
   // ORDER_MIN_NQ (2048) queries on.  LSQ scans index row_bias / norm bytes by position and keep the arrival order.
-  if (!perm && !row_bias && order_pays(n, nq, k)) {
+  // The in-call order is an optimisation on hidden scratch (n * (mp + 8) bytes per device and stream, kept until
+  // rq_release_workspaces): it is skipped above ORDER_MAX_SCRATCH_MB (default 2048 MiB = a 1.25e8-row m = 8 shard; bigger
+  // bases belong in an index handle or rq_dev_order_rows, which order ONCE), and a scratch or launch failure means "scan
+  // in arrival order" -- the round-3 path, which needs no extra memory -- never a failed search.
+  if (!perm && !row_bias && order_pays(n, nq, k) &&
+      order_base_bytes(n, mp) + (size_t)n * 4 <= (size_t)std::max(0, tuning("ORDER_MAX_SCRATCH_MB", 2048)) * 1048576ull) {
     void *ord = nullptr;
-    RQ_TRY(workspace(WS_ORDER, order_base_bytes(n, mp), &ord, stream));
-    RQ_TRY(order_base(&codes, &perm, ord, codes, n, mp, stream));
+    const uint8_t *ocodes = codes;
+    const uint32_t *operm = nullptr;
+    if (workspace(WS_ORDER, order_base_bytes(n, mp), &ord, stream) == RQ_OK &&
+        order_base(&ocodes, &operm, ord, codes, n, mp, stream) == RQ_OK) {
+      codes = ocodes;
+      perm = operm;
+    } else {
+      (void)hipGetLastError();      // out of memory for the scratch: not an error of the search
+    }
   }
   ScanPlan pl;
   RQ_TRY(scan_plan(pl, n, nq, m, d, k, di.num_cu, tuning("SCAN_SLICES", 0)));
@@ -762,7 +774,11 @@ using namespace rq;
 
 extern "C" {
 
-const char *rq_version(void) { return "rayuela-hip 0.1 (gfx950)"; }
+#ifndef RQ_BUILD_ID
+#define RQ_BUILD_ID "unknown"
+#endif
+const char *rq_version(void) { return "rayuela-hip 0.1 (gfx950) build " RQ_BUILD_ID; }
+const char *rq_last_scan_kernel(void) { return last_scan_kernel_name(); }
 const char *rq_last_error(void) { return g_err; }
 
 int rq_device_count(void) {
@@ -894,6 +910,12 @@ rq_lsq_index *rq_lsq_prepare(const uint8_t *codes, const float *codebooks, const
   if (n < 1 || n >= (1LL << 31) || m < 1 || d < 1) { fail(RQ_EINVAL, "rq_lsq_prepare: bad shape n=%lld m=%d d=%d", (long long)n, m, d); return nullptr; }
   const int mp = scan_padded_m(m);
   if (mp < 0) { fail(RQ_EUNSUPPORTED, "the ADC scan kernels cover 1 <= m <= 64 sub-quantizers; got m=%d", m); return nullptr; }
+  // device placement as in the one-shot call (rq_linscan_lsq / host_linscan_aq): the first device of RAYUELA_HIP_DEVICES when the
+  // list is set, else the calling thread's current device; the thread's device is restored on every exit path
+  SavedDevice saved;
+  int devs[64];
+  const int nd = env_devices(devs, 64);
+  if (nd > 0 && hipSetDevice(devs[0]) != hipSuccess) { (void)hipGetLastError(); fail(RQ_EINVAL, "rq_lsq_prepare: cannot select device %d", devs[0]); return nullptr; }
   DeviceInfo di;
   if (device_info(&di) != RQ_OK) return nullptr;
   DeviceLock lock;
@@ -916,9 +938,13 @@ rq_lsq_index *rq_lsq_prepare(const uint8_t *codes, const float *codebooks, const
     }
     // the base is resident: bank-aware row order once (rq_order.hip), norms permuted alike -- row_bias and the filter's
     // norm bytes are indexed by POSITION in the kernel, ids come from perm
-    if (tuning("INDEX_ORDER", 1) && order_pays(n, 0, 0)) {
-      RQ_HIP(hipMalloc(&ix->ordered, order_base_bytes(n, mp)));
-      RQ_TRY(order_base(&ix->ocodes, &ix->perm, ix->ordered, ix->codes, n, mp, nullptr));
+    // (an ordered copy that cannot be allocated or built leaves the base in arrival order: slower gathers, same answer)
+    if (tuning("INDEX_ORDER", 1) && order_pays(n, 0, 0) && hipMalloc(&ix->ordered, order_base_bytes(n, mp)) != hipSuccess) {
+      (void)hipGetLastError();
+      ix->ordered = nullptr;
+    }
+    if (ix->ordered) {
+      if (order_base(&ix->ocodes, &ix->perm, ix->ordered, ix->codes, n, mp, nullptr) != RQ_OK) { (void)hipGetLastError(); ix->perm = nullptr; }
       if (ix->perm) {
         float *pn = nullptr;
         RQ_HIP(hipMalloc((void **)&pn, (size_t)n * 4));
@@ -1290,9 +1316,11 @@ int rq_dev_linscan_ordered(float *dists, uint32_t *ids, uint64_t *keys, const ui
                            uint32_t id_offset, int id_base, void *stream) {
   if (!perm) {
     // identity order (rq_dev_order_rows on a tiny base): rows are padded already, scan them as they are
-    const int mp = scan_padded_m(m);
-    if (mp != m) return fail(RQ_EUNSUPPORTED, "ordered scan without perm needs a tiled row width (m=%d)", m);
-    return dev_linscan(dists, ids, keys, codes_ordered, centers, queries, n, nq, m, d, k, id_offset, id_base, (hipStream_t)stream);
+    // (m = 12 rows arrive 16 bytes wide from rq_dev_order_rows: `padded` tells the scan so)
+    ScanBase sb0;
+    sb0.padded = scan_padded_m(m) != m;
+    return dev_linscan(dists, ids, keys, codes_ordered, centers, queries, n, nq, m, d, k, id_offset, id_base, (hipStream_t)stream,
+                       LUT_PQ, nullptr, &sb0);
   }
   ScanBase sb;
   sb.perm = perm;

@@ -77,23 +77,34 @@ __device__ __forceinline__ float min16(const f32x16 &a) {
   return __builtin_fminf(mm, a[15]);
 }
 
-// LDS image of the sub-codebooks (same layout as encode_pq_split_kernel's):
+// LDS image of the sub-codebooks of one launch (same layout as encode_pq_split_kernel's), built ONCE per launch in global
+// scratch by encode_tables_kernel and copied by every workgroup of the filter with straight 16-byte loads.  (Built inside
+// each workgroup -- 8 strided scalar loads per fragment, a dozen dependent round trips to L2 -- the prologue took 50 us of
+// the 280 a 1e6-row SIFT-shape launch lasts, and nearly all of a short one.)
 //   cbA [mg][NT][NPIECE][64] uint4  bf16 pieces of -2c in the A-fragment order of v_mfma_f32_32x32x16_bf16 (lane l: centroid
 //                                   l & 31, K elements 8 (l >> 5) .. + 7; PACK: K 0-7 = hi pieces, 8-15 = lo pieces)
-//   saL [mg][NT][2][16] float       |c_k|^2 (canonical chain) in C/D-fragment order, +inf for centroids >= h
-//   saMax [mg] float                max_k |c_k|^2 over the real centroids (NaN if any norm is NaN)
-template <int SUB, int NT, int NTHREADS>
-__device__ __forceinline__ void filter_prologue(const EncParams &p, uint4 *cbA, float *saL, float *saMax) {
+//   saL [mg][NT][2][16] float       |c_k|^2 (canonical chain s = 0..sub-1 from +0) in C/D-fragment order, +inf for k >= h
+//   saMax [mg] float                max_k |c_k|^2 over the real centroids (NaN if any norm is NaN), padded to 16 bytes
+template <int SUB>
+__host__ __device__ constexpr size_t filter_image_bytes(int mg, int NT) {
+  return (size_t)mg * NT * SplitShape<SUB>::NPIECE * 64 * 16 + (size_t)mg * NT * 32 * 4 + (((size_t)mg * 4 + 15) & ~(size_t)15);
+}
+
+// grid = mg workgroups (one per sub-quantizer of the launch) x 256 threads
+template <int SUB, int NT>
+__global__ __launch_bounds__(256) void encode_tables_kernel(EncParams p) {
   constexpr bool PACK = SplitShape<SUB>::PACK;
   constexpr int NPIECE = SplitShape<SUB>::NPIECE;
-  const int h = p.h, i0 = p.i0, mg = p.i1 - p.i0;
+  const int h = p.h, i0 = p.i0, mg = p.i1 - p.i0, il = blockIdx.x;
+  uint4 *cbA = reinterpret_cast<uint4 *>(p.image);
+  float *saL = reinterpret_cast<float *>(cbA + (size_t)mg * NT * NPIECE * 64);
+  float *saMax = saL + (size_t)mg * NT * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int idx = tid; idx < mg * NT * NPIECE * 64; idx += NTHREADS) {
+  __shared__ float wmax[4];
+  for (int idx = tid; idx < NT * NPIECE * 64; idx += 256) {
     const int l = idx & 63;
-    int rest = idx >> 6;
-    const int piece = rest % NPIECE; rest /= NPIECE;
-    const int t = rest % NT;
-    const int il = rest / NT;
+    const int piece = (idx >> 6) % NPIECE;
+    const int t = (idx >> 6) / NPIECE;
     const int cen = t * 32 + (l & 31);
     uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -108,12 +119,11 @@ __device__ __forceinline__ void filter_prologue(const EncParams &p, uint4 *cbA, 
       }
       w[e >> 1] |= bits << (16 * (e & 1));
     }
-    cbA[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+    cbA[(size_t)il * NT * NPIECE * 64 + idx] = make_uint4(w[0], w[1], w[2], w[3]);
   }
-  for (int idx = tid; idx < mg * NT * 32; idx += NTHREADS) {
-    const int c32 = idx & 31;
-    const int t = (idx >> 5) % NT;
-    const int il = (idx >> 5) / NT;
+  float mx = 0.0f;
+  for (int idx = tid; idx < NT * 32; idx += 256) {
+    const int c32 = idx & 31, t = idx >> 5;
     const int cen = t * 32 + c32;
     float sa = __uint_as_float(0x7f800000u);
     if (cen < h) {
@@ -121,28 +131,22 @@ __device__ __forceinline__ void filter_prologue(const EncParams &p, uint4 *cbA, 
       sa = 0.0f;
 #pragma unroll
       for (int sx = 0; sx < SUB; ++sx) sa = __builtin_fmaf(c[sx], c[sx], sa);
+      mx = __builtin_fmaxf(mx, sa) + (sa != sa ? sa : 0.0f);    // a NaN norm poisons the bound -> exact pass
     }
-    const int hh = (c32 >> 2) & 1;
-    const int r = (c32 & 3) + 4 * (c32 >> 3);
-    saL[((size_t)(il * NT + t) * 2 + hh) * 16 + r] = sa;
+    saL[((size_t)(il * NT + t) * 2 + ((c32 >> 2) & 1)) * 16 + (c32 & 3) + 4 * (c32 >> 3)] = sa;
   }
-  __syncthreads();
-  for (int il = wave; il < mg; il += NTHREADS / 64) {
-    float mx = 0.0f;
-    for (int e = lane; e < NT * 32; e += 64) {
-      const float v = saL[(size_t)il * NT * 32 + e];
-      const int t = e >> 5, hh = (e >> 4) & 1, r = e & 15;
-      const int cen = t * 32 + 4 * hh + 8 * (r >> 2) + (r & 3);
-      if (cen < h) mx = __builtin_fmaxf(mx, v) + (v != v ? v : 0.0f);    // a NaN norm poisons the bound -> exact pass
-    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const float o = __shfl_xor(mx, off);
-      mx = (o != o || mx != mx) ? __uint_as_float(0x7fc00000u) : __builtin_fmaxf(mx, o);
-    }
-    if (lane == 0) saMax[il] = mx;
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(mx, off);
+    mx = (o != o || mx != mx) ? __uint_as_float(0x7fc00000u) : __builtin_fmaxf(mx, o);
   }
+  if (lane == 0) wmax[wave] = mx;
   __syncthreads();
+  if (tid == 0) {
+    float r = wmax[0];
+    for (int w = 1; w < 4; ++w) r = (r != r || wmax[w] != wmax[w]) ? __uint_as_float(0x7fc00000u) : __builtin_fmaxf(r, wmax[w]);
+    saMax[il] = r;
+  }
 }
 
 template <int SUB, int NT, int NWAVES, bool DBG = false>
@@ -158,9 +162,13 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_filter_kernel(EncParams
   float *saMax = saL + (size_t)mg * NT * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hi = lane >> 5;
-  filter_prologue<SUB, NT, NWAVES * 64>(p, cbA, saL, saMax);
-  if (blockIdx.x == 0)      // the exact pass reads the norm table instead of rebuilding it in every workgroup
-    for (int idx = tid; idx < mg * NT * 32; idx += NWAVES * 64) p.sa_tab[idx] = saL[idx];
+  {   // the launch's table image, as encode_tables_kernel left it
+    const uint4 *src = reinterpret_cast<const uint4 *>(p.image);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    const int n16 = (int)(filter_image_bytes<SUB>(mg, NT) / 16);
+    for (int idx = tid; idx < n16; idx += NWAVES * 64) dst[idx] = src[idx];
+    __syncthreads();
+  }
 
   const int64_t ntiles = (p.n + 31) / 32;
   const int64_t total_waves = (int64_t)gridDim.x * NWAVES;
@@ -371,7 +379,7 @@ constexpr int FIX_ROWS = 2048;
 constexpr int FIX_THREADS = 512;
 
 template <int SUB, int NT>
-__global__ __launch_bounds__(FIX_THREADS) void encode_pq_fix_kernel(EncParams p) {
+__global__ __launch_bounds__(FIX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_pq_fix_kernel(EncParams p) {
   constexpr int KS = SUB / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int mg = p.i1 - p.i0, h = p.h, d = p.d, m = p.m;
@@ -394,8 +402,9 @@ __global__ __launch_bounds__(FIX_THREADS) void encode_pq_fix_kernel(EncParams p)
     }
   }
   if (!__syncthreads_or(any != 0u)) return;
-  // the norm table (canonical chain s = 0..sub-1 from +0; +inf for centroids >= h), as the filter's workgroup 0 left it
-  for (int idx = tid; idx < mg * NT * 32; idx += FIX_THREADS) saL[idx] = p.sa_tab[idx];
+  // the norm table (canonical chain s = 0..sub-1 from +0; +inf for centroids >= h) of the launch's table image
+  const float *sa_img = reinterpret_cast<const float *>(reinterpret_cast<const uint4 *>(p.image) + (size_t)mg * NT * SplitShape<SUB>::NPIECE * 64);
+  for (int idx = tid; idx < mg * NT * 32; idx += FIX_THREADS) saL[idx] = sa_img[idx];
   __syncthreads();
 
   int item = 0;       // items are numbered sub-quantizer by sub-quantizer; wavefront w takes items w, w + 8, ...
@@ -434,44 +443,63 @@ __global__ __launch_bounds__(FIX_THREADS) void encode_pq_fix_kernel(EncParams p)
 #pragma unroll
       for (int r = 0; r < 8; ++r) st.ub[r] = f32x2{0.0f, 0.0f};
       const float4 *sa_i = reinterpret_cast<const float4 *>(saL + ((size_t)il * NT * 2 + hi) * 16);
-      // A fragments: lane = centroid 32 t + j, k = 2 kk + hi; the next tile's centroid rows travel under this tile's MFMAs
+      // A fragments: lane (j, hi) wants C_i[32 t + j][2 kk + hi].  For 8-wide halves (sub = 16) the lane loads floats
+      // 8 hi .. 8 hi + 7 of its centroid (two 16-byte loads) and one v_permlane32_swap per register PAIR turns
+      // (c[2q] | c[8 + 2q]), (c[2q + 1] | c[9 + 2q]) into the fragments of k-steps q and 4 + q; other widths load the whole
+      // row and select.  Four tiles are requested at a time, so an item waits for L2 twice, not once per tile.
       auto cload = [&](int t, float (&a)[KS]) {
         const int cen = t * 32 + j;
-        float c[SUB];
+        if constexpr (SUB == 16) {
+          float4 v0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), v1 = v0;
+          if (cen < h) {
+            const float4 *src = reinterpret_cast<const float4 *>(p.C + ((size_t)i * h + cen) * SUB + 8 * hi);
+            v0 = src[0]; v1 = src[1];
+          }
+          float r[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-        for (int s = 0; s < SUB; ++s) c[s] = 0.0f;
-        if (cen < h) {
-          const float *src = p.C + ((size_t)i * h + cen) * SUB;
-          if constexpr (SUB % 4 == 0) {
+          for (int q = 0; q < 4; ++q) {
+            swap32(r[2 * q], r[2 * q + 1]);
+            a[q] = r[2 * q]; a[4 + q] = r[2 * q + 1];
+          }
+        } else {
+          float c[SUB];
 #pragma unroll
-            for (int s4 = 0; s4 < SUB / 4; ++s4) {
-              const float4 v = reinterpret_cast<const float4 *>(src)[s4];
-              c[4 * s4] = v.x; c[4 * s4 + 1] = v.y; c[4 * s4 + 2] = v.z; c[4 * s4 + 3] = v.w;
-            }
-          } else {
+          for (int s = 0; s < SUB; ++s) c[s] = 0.0f;
+          if (cen < h) {
+            const float *src = p.C + ((size_t)i * h + cen) * SUB;
+            if constexpr (SUB % 4 == 0) {
 #pragma unroll
-            for (int s2 = 0; s2 < SUB / 2; ++s2) {
-              const f32x2 v = reinterpret_cast<const f32x2 *>(src)[s2];
-              c[2 * s2] = v.x; c[2 * s2 + 1] = v.y;
+              for (int s4 = 0; s4 < SUB / 4; ++s4) {
+                const float4 v = reinterpret_cast<const float4 *>(src)[s4];
+                c[4 * s4] = v.x; c[4 * s4 + 1] = v.y; c[4 * s4 + 2] = v.z; c[4 * s4 + 3] = v.w;
+              }
+            } else {
+#pragma unroll
+              for (int s2 = 0; s2 < SUB / 2; ++s2) {
+                const f32x2 v = reinterpret_cast<const f32x2 *>(src)[s2];
+                c[2 * s2] = v.x; c[2 * s2 + 1] = v.y;
+              }
             }
           }
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk) a[kk] = hi ? c[2 * kk + 1] : c[2 * kk];
         }
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) a[kk] = hi ? c[2 * kk + 1] : c[2 * kk];
       };
-      float a0[KS], a1[KS];
-      cload(0, a0);
+      constexpr int TB = NT < 4 ? NT : (KS >= 8 ? 2 : 4);        // tiles per batch (registers: 128 per lane at 4 wavefronts per SIMD)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        if (t + 1 < NT) cload(t + 1, a1);
-        f32x16 acc;
+      for (int t0 = 0; t0 < NT; t0 += TB) {
+        float a[TB][KS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int u = 0; u < TB; ++u) cload(t0 + u, a[u]);
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b[kk], acc, 0, 0, 0);
-        tile_argmin(acc, sa_i + (size_t)t * 8, sb, t, st);
+        for (int u = 0; u < TB; ++u) {
+          f32x16 acc;
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) a0[kk] = a1[kk];
+          for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][kk], b[kk], acc, 0, 0, 0);
+          tile_argmin(acc, sa_i + (size_t)(t0 + u) * 8, sb, t0 + u, st);
+        }
       }
       float best_v = st.best_v;
       int best_i = argmin_finish(st, hi);
@@ -493,10 +521,10 @@ static int launch_encode_filter(EncParams p, int num_cu, hipStream_t stream) {
   const int gmax = (int)std::min<size_t>(std::min<size_t>(budget / per_sub, (size_t)p.m), 32);
   if (gmax < 1) return fail(RQ_EUNSUPPORTED, "split encode: one sub-codebook needs %zu B of LDS", per_sub);
   void *fl = nullptr;
-  const size_t sa_bytes = (size_t)32 * NT * 32 * sizeof(float);
-  RQ_TRY(workspace(WS_ENCFLAG, sa_bytes + (size_t)p.n * sizeof(uint32_t), &fl, stream));
-  p.sa_tab = static_cast<float *>(fl);
-  p.flags = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(fl) + sa_bytes);
+  const size_t img_bytes = (filter_image_bytes<SUB>(gmax, NT) + 255) & ~(size_t)255;
+  RQ_TRY(workspace(WS_ENCFLAG, img_bytes + (size_t)p.n * sizeof(uint32_t), &fl, stream));
+  p.image = static_cast<unsigned char *>(fl);
+  p.flags = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(fl) + img_bytes);
   auto kern = p.dbg_w ? encode_pq_filter_kernel<SUB, NT, NWAVES, true> : encode_pq_filter_kernel<SUB, NT, NWAVES, false>;
   const int64_t ntiles = (p.n + 31) / 32;
   const int grid = (int)std::min<int64_t>(num_cu, (ntiles + NWAVES - 1) / NWAVES);
@@ -505,7 +533,9 @@ static int launch_encode_filter(EncParams p, int num_cu, hipStream_t stream) {
   for (int i0 = 0; i0 < p.m; i0 += gmax) {
     p.i0 = i0;
     p.i1 = std::min(p.m, i0 + gmax);
-    const size_t lds = per_sub * (size_t)(p.i1 - p.i0) + 64;
+    const size_t lds = filter_image_bytes<SUB>(p.i1 - p.i0, NT);
+    hipLaunchKernelGGL((encode_tables_kernel<SUB, NT>), dim3(p.i1 - p.i0), dim3(256), 0, stream, p);
+    RQ_HIP(hipGetLastError());
     RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, p);
     RQ_HIP(hipGetLastError());

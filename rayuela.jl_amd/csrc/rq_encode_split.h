@@ -19,7 +19,7 @@ struct EncParams {
   float delta_rel;  // split kernel: candidate margin relative to max|c|^2 + |x|^2 (SplitCfg::DELTA_REL unless tuned, tests)
   float *dbg_w;     // split kernel, tests only: [n][m][h] receives the filter's W values (nullptr in every product call)
   uint32_t *flags;  // filter + exact pass: [n] words, bit (i - i0) set = (row, sub-quantizer i) goes to the exact pass
-  float *sa_tab;    // filter + exact pass: [i1 - i0][NT][2][16] |c|^2 in C/D-fragment order, written by the filter's workgroup 0
+  unsigned char *image;  // filter + exact pass: the launch's LDS table image (encode_tables_kernel, rq_encode_filter.hip)
 };
 
 // lanes 32-63 of a  <->  lanes 0-31 of b   (v_permlane32_swap_b32)

@@ -319,15 +319,17 @@ static int index_set(rq_index *ix, int64_t n, uint32_t id_offset, Fill fill) {
     // other widths are padded and ordered per search.  Costs 4 bytes per row for perm; the arrival-order copy is freed.
     if (tuning("INDEX_ORDER", 1) && scan_padded_m(ix->m) == ix->m && order_pays(s.n, 0, 0)) {
       DeviceLock order_lock;      // scratch lookup + launches of this device, like a scan
+      // (an ordered copy that cannot be allocated or built -- memory -- leaves the shard in arrival order: slower gathers,
+      // the same answer; set_codes does not fail for the sake of an optimisation)
       void *ord = nullptr;
-      RQ_HIP(hipMalloc(&ord, order_base_bytes(s.n, ix->m)));
       const uint8_t *oc = nullptr;
       const uint32_t *op = nullptr;
-      int rc = order_base(&oc, &op, ord, s.codes, s.n, ix->m, dv.stream);
+      int rc = hipMalloc(&ord, order_base_bytes(s.n, ix->m)) == hipSuccess ? RQ_OK : RQ_EUNSUPPORTED;
+      if (rc == RQ_OK) rc = order_base(&oc, &op, ord, s.codes, s.n, ix->m, dv.stream);
       if (rc == RQ_OK) { hipError_t e = hipStreamSynchronize(dv.stream); if (e != hipSuccess) rc = fail_hip(e, "order sync", __FILE__, __LINE__); }
       if (rc != RQ_OK || !op) {
-        (void)hipFree(ord);
-        if (rc != RQ_OK) return rc;
+        if (ord) (void)hipFree(ord);
+        (void)hipGetLastError();
       } else {
         RQ_HIP(hipFree(s.codes));
         s.codes = (uint8_t *)ord;

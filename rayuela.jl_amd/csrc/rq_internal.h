@@ -86,6 +86,7 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
                 uint32_t id_offset, int id_base, uint32_t *work_counter, uint64_t *cand,
                 hipStream_t stream, int lut_mode = 0, const float *row_bias = nullptr, uint8_t *norm_buf = nullptr,
                 const uint32_t *perm = nullptr, bool norm_ready = false);
+const char *last_scan_kernel_name();      // which instantiation the calling thread's last scan_launch chose
 size_t lsq_norm_bytes(int64_t n);      // LSQ pre-filter: bytes of a base's prepared norm buffer
 int lsq_norm_prepare(uint8_t *norm_buf, const uint8_t *codes, const float *centers, const float *row_bias, int64_t n,
                      int mp, int m_real, int d, hipStream_t stream);

@@ -494,7 +494,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
           __builtin_amdgcn_sched_barrier(0);
           }  // gather batches
         }
-        asm volatile("; RQ_FILTER_LOOP_END" ::: "memory");
+        asm volatile("; RQ_FILTER_GATHERS_END" ::: "memory");    // end of the streaming part (gathers + byte sums + alive bits)
         if (!full_blk) {          // rows behind the slice's end (only a slice's last block is ragged)
 #pragma unroll
           for (int u = 0; u < UCH; ++u) {
@@ -791,6 +791,9 @@ __global__ void synth_codes_kernel(uint8_t *codes, size_t nbytes, uint64_t seed,
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+static thread_local char g_last_scan_kernel[64] = "";      // the calling thread's last scan launch (template arguments as rocprofv3 prints them)
+const char *last_scan_kernel_name() { return g_last_scan_kernel; }
+
 template <int M>
 static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) {
   using Cfg = ScanCfg<M>;
@@ -809,21 +812,24 @@ static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) 
   if (plan.spread) lds = std::max<size_t>(lds, 84 * 1024);
   // the pre-filter is tiled for M = 8 and 16 and needs non-negative table entries (PQ and CQ tables are sums of squares)
   void (*kern)(ScanParams) = p.row_bias ? adc_scan_kernel<M, true, false> : adc_scan_kernel<M, false, false>;
+  bool t_bias = p.row_bias != nullptr, t_filt = false, t_fine = false;       // the instantiation, for rq_last_scan_kernel()
   if constexpr (Cfg::HAS_FILT) {
-    if (p.filter) kern = adc_scan_kernel<M, false, true>;
+    if (p.filter) { kern = adc_scan_kernel<M, false, true>; t_filt = true; }
     // LSQ (signed tables + row norms): the two-set byte sums (m = 8: 4 and 4 + 1 entries, m = 16: 8 and 8 + 1)
-    if (p.filter && p.row_bias) kern = adc_scan_kernel<M, true, true, (M == 8)>;
+    if (p.filter && p.row_bias) { kern = adc_scan_kernel<M, true, true, (M == 8)>; t_fine = (M == 8); }
     // m = 8, large k: the finer byte tables (6-bit entries, two sum sets) -- more VALU work per row, fewer rows for
     // the exact evaluation.  Measured at SIFT1M shape, coarse vs fine: k = 1 2.23 / 2.34 ms, k = 100 2.36 / 2.39,
     // k = 1000 2.91 / 2.91, k = 10000 6.62 / 6.26.
     if constexpr (M == 8) {
       int fine_k = tuning("SCAN_FINE_MIN_K", 0);
       if (fine_k <= 0) fine_k = 8192;            // crossover measured between k = 4096 (level) and 10000
-      if (p.filter && !p.row_bias && p.K >= fine_k) kern = adc_scan_kernel<M, false, true, true>;
+      if (p.filter && !p.row_bias && p.K >= fine_k) { kern = adc_scan_kernel<M, false, true, true>; t_fine = true; }
     }
   } else {
     p.filter = 0;
   }
+  snprintf(g_last_scan_kernel, sizeof(g_last_scan_kernel), "adc_scan_kernel<%d, %s, %s, %s>", M, t_bias ? "true" : "false",
+           t_filt ? "true" : "false", t_fine ? "true" : "false");
   RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(Cfg::THREADS), lds, stream, p);
@@ -1043,7 +1049,7 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
                 bool norm_ready) {
   ScanParams p;
   p.perm = perm;
-  p.samp_end = 0;           // set per row width below (launch_scan): positions below it hold a sample block in every 8
+  p.samp_end = 0;           // set per row width below (launch_scan): positions below it hold a sample block in every 16 (order_sample_stride())
   p.codes = codes; p.centers = centers; p.queries = queries;
   p.n = (uint32_t)n; p.nq = (uint32_t)nq; p.sub = d / m; p.d = d; p.K = K;
   p.m_real = m;

@@ -241,6 +241,50 @@ static int check_train(int64_t n, int d, int m, int h, int niter) {
   return RQ_OK;
 }
 
+// Clustering.repick_unused_centers (Clustering.jl v0.12.2, called by kmeans' loop right after update_centers! -- the k-means of
+// src/PQ.jl:86 and src/RVQ.jl:104): every centre that lost all its points is re-drawn from the data with probability
+// proportional to the points' CURRENT cost (distance to their assigned centre), kmeans++ style: the drawn point's cost drops to
+// zero and all costs are lowered to the distance to the new centre before the next draw.  Empty clusters are rare (none in the
+// bench runs), so this runs on the host: the sub-space columns and the stage's codes come down once per affected sub-space.
+// dCsub: device [h][sub] block of the sub-codebook; dX: device rows of `d` floats, the sub-space starts at column col0;
+// codes: device bytes, the row's code at codes[row * cstride + ci].  The draws use the library's seeded stream (not Julia's).
+static int repick_unused(float *dCsub, const float *dX, int64_t n, int d, int col0, int sub, const uint8_t *codes, int cstride,
+                         int ci, int h, const std::vector<int> &unused, Rng &rng) {
+  std::vector<float> xs((size_t)n * sub), cs((size_t)h * sub);
+  std::vector<uint8_t> cb((size_t)n);
+  RQ_HIP(hipMemcpy2D(xs.data(), (size_t)sub * 4, dX + col0, (size_t)d * 4, (size_t)sub * 4, (size_t)n, hipMemcpyDeviceToHost));
+  RQ_HIP(hipMemcpy2D(cb.data(), 1, codes + ci, (size_t)cstride, 1, (size_t)n, hipMemcpyDeviceToHost));
+  RQ_HIP(hipMemcpy(cs.data(), dCsub, (size_t)h * sub * 4, hipMemcpyDeviceToHost));
+  std::vector<double> tc((size_t)n);
+  for (int64_t j = 0; j < n; ++j) {
+    const float *x = &xs[(size_t)j * sub], *c = &cs[(size_t)cb[j] * sub];
+    double a = 0;
+    for (int t = 0; t < sub; ++t) { const double e = (double)x[t] - (double)c[t]; a += e * e; }
+    tc[j] = a;
+  }
+  for (int k : unused) {
+    double total = 0;
+    for (int64_t j = 0; j < n; ++j) total += tc[j];
+    int64_t pick = (int64_t)(rng.next() % (uint64_t)n);          // all costs zero (fewer distinct points than centres): uniform
+    if (total > 0) {
+      const double u = rng.uniform() * total;
+      double run = 0;
+      pick = n - 1;
+      for (int64_t j = 0; j < n; ++j) { run += tc[j]; if (run > u) { pick = j; break; } }
+    }
+    const float *v = &xs[(size_t)pick * sub];
+    RQ_HIP(hipMemcpy(dCsub + (size_t)k * sub, v, (size_t)sub * 4, hipMemcpyHostToDevice));
+    tc[pick] = 0;
+    for (int64_t j = 0; j < n; ++j) {
+      const float *x = &xs[(size_t)j * sub];
+      double a = 0;
+      for (int t = 0; t < sub; ++t) { const double e = (double)x[t] - (double)v[t]; a += e * e; }
+      if (a < tc[j]) tc[j] = a;
+    }
+  }
+  return RQ_OK;
+}
+
 }  // namespace rq
 
 using namespace rq;
@@ -283,7 +327,12 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
   RQ_PH(TP_H2D, RQ_HIP(hipMemcpy(dX.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice)));
   RQ_PH(TP_INIT, RQ_TRY(seed_centers(dC.as<float>(), dX.as<float>(), n, d, m, h, off, rng)));
   std::vector<unsigned int> counts((size_t)m * h);
-  // convergence = "no assignment changed" (Clustering.kmeans' tol on these magnitudes): the codes of two consecutive
+  // Convergence.  Clustering.kmeans (v0.12.2 `_kmeans!`) stops when |objv - prev_objv| < tol, tol = 1e-6 ABSOLUTE on
+  // objv = sum(costs), a Float32 sum: for any data whose objective exceeds ~10 (float32 resolution 1e-6) that is "the rounded
+  // objective did not move", which an iteration without a changed assignment produces exactly (same assignments -> same centres
+  // -> same costs) and one WITH changed assignments practically never does.  So the loop stops on "no assignment changed" --
+  // the same stopping point on the bench shapes (tests/test_gpu_train.py compares the final error with the oracle loop that
+  // applies Clustering's own rule) -- and does not pay a pass over X per iteration for the objective.  The codes of two consecutive
   // iterations are compared ON THE DEVICE (a D2H of n*m bytes + a host compare per iteration cost more than the encode)
   // The change counter sits right behind the cluster counts: ONE small read-back per iteration serves the convergence test
   // and the empty-cluster check (the centres are recomputed before the test is known; with unchanged assignments that
@@ -311,14 +360,14 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
     if (!changed) break;   // assignments stable: Lloyd has converged
     ++iters_done;
     memcpy(counts.data(), back.data(), cnt_bytes);
-    for (int i = 0; i < m; ++i)               // re-seed empty clusters from sampled rows
+    for (int i = 0; i < m; ++i) {             // centres that lost all their points: re-drawn like Clustering.kmeans does
+      std::vector<int> unused;
       for (int k = 0; k < h; ++k)
-        if (counts[(size_t)i * h + k] == 0) {
-          const int sub = off[i + 1] - off[i];
-          const int64_t row = (int64_t)(rng.next() % (uint64_t)n);
-          RQ_HIP(hipMemcpy(dC.as<float>() + (size_t)h * off[i] + (size_t)k * sub, dX.as<float>() + row * d + off[i],
-                           sizeof(float) * sub, hipMemcpyDeviceToDevice));
-        }
+        if (counts[(size_t)i * h + k] == 0) unused.push_back(k);
+      if (!unused.empty())
+        RQ_TRY(repick_unused(dC.as<float>() + (size_t)h * off[i], dX.as<float>(), n, d, off[i], off[i + 1] - off[i], cur, m, i, h,
+                             unused, rng));
+    }
     std::swap(cur, prev);
   }
   if (cur != dcodes.as<uint8_t>()) std::swap(dcodes.p, dprev.p);      // the final encode below writes (and the download reads) dcodes
@@ -373,12 +422,11 @@ int rq_train_rvq(float *C, int16_t *B1, double *error, const float *X, int64_t n
       RQ_TRY(update_centers_launch(dCi.as<float>(), dcnt.as<unsigned int>(), dXr.as<float>(), dstage.as<uint8_t>(), n,
                                    d, 1, h, di.num_cu, nullptr));
       RQ_HIP(hipMemcpy(counts.data(), dcnt.p, (size_t)h * 4, hipMemcpyDeviceToHost));
-      for (int k = 0; k < h; ++k)                // re-seed empty clusters from sampled residual rows
-        if (counts[k] == 0) {
-          const int64_t row = (int64_t)(rng.next() % (uint64_t)n);
-          RQ_HIP(hipMemcpy(dCi.as<float>() + (size_t)k * d, dXr.as<float>() + row * d, sizeof(float) * d,
-                           hipMemcpyDeviceToDevice));
-        }
+      std::vector<int> unused;                   // centres that lost all their points: re-drawn like Clustering.kmeans does
+      for (int k = 0; k < h; ++k)
+        if (counts[k] == 0) unused.push_back(k);
+      if (!unused.empty())
+        RQ_TRY(repick_unused(dCi.as<float>(), dXr.as<float>(), n, d, 0, d, dstage.as<uint8_t>(), 1, 0, h, unused, rng));
     }
     // the assignments of the final centres (what quantize_rvq would return for this stage), then the residual
     RQ_TRY(encode_launch(dstage.as<uint8_t>(), dXr.as<float>(), dCi.as<float>(), n, d, 1, h, di.num_cu, nullptr));
@@ -473,6 +521,13 @@ int rq_train_opq(float *C, int16_t *B1, float *R, float *obj, const float *X, in
     prof.start();
     int pstat = 1;
     if (dev_ns) {
+      // The Newton-Schulz kernel synchronises its <= num_cu workgroups with a grid barrier and needs them all resident.  The
+      // objective kernel on the side stream (num_cu * 8 workgroups) would compete for the CUs, and a barrier that times out
+      // falls back to the Jacobi / host factor -- other bits, i.e. the iteration's result would depend on timing.  With
+      // TRAIN_DETERMINISTIC = 1 (default) the main stream waits for the objective first (measured: +0.03 ms per iteration
+      // of 1.5); 0 keeps the overlap and reports the fallbacks in rq_train_profile()[15].
+      if (tuning("TRAIN_DETERMINISTIC", 1)) RQ_HIP(hipStreamWaitEvent(nullptr, side.done, 0));
+      RQ_HIP(hipMemsetAsync(dstat.p, 0, 8, nullptr));           // status[1] (steps) is only written on completed paths
       RQ_TRY(polar_ns_launch(dR.as<float>(), dG.as<float>(), d, dstat.as<int>(), dns.p, di.num_cu, nullptr));
       int st2[2] = {1, 0};
       RQ_HIP(hipMemcpy(st2, dstat.p, 8, hipMemcpyDeviceToHost));

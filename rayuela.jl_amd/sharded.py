@@ -46,7 +46,7 @@ def shard_bounds(n_total, world):
 
 class ShardedIndex:
     def __init__(self, codes_local, centers, id_offset, group=None, scan_fn=None, merge_fn=None, host_staging=False,
-                 always_exchange=False, order=True):
+                 always_exchange=False, order=True, keep_arrival_copy=False):
         # always_exchange: take the all_to_all / gather path even at world size 1 (exercises the RCCL collectives
         # on a one-GPU box; the product never sets it)
         self.always_exchange = always_exchange
@@ -62,6 +62,7 @@ class ShardedIndex:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # total rows of the base: k beyond it has no answer (the reference requires K <= N, linscan_aqd.cpp:91)
         self.n_total = int(codes_local.shape[0])
+        self.n_local = int(codes_local.shape[0])
         # The shard is resident for many searches: put its rows in bank-aware order once (csrc/rq_order.hip: the scan's
         # table gathers then hit distinct LDS bank columns; ids stay original row numbers, the answer is unchanged).
         # HIP path only -- an injected scan_fn (CPU tests) sees the codes as given.
@@ -75,6 +76,10 @@ class ShardedIndex:
             t0[1].record()
             torch.cuda.synchronize()
             self.order_ms = t0[0].elapsed_time(t0[1])
+            # the ordered copy serves every search: the arrival-order rows are only kept on request (like the C index, which
+            # frees them -- 1 GB of a 1.25e8 x 8 shard otherwise held twice; the caller's own reference is the caller's)
+            if not keep_arrival_copy:
+                self.codes = None
         if self.world > 1:
             t = torch.tensor([self.n_total], dtype=torch.int64, device="cpu" if host_staging else codes_local.device)
             dist.all_reduce(t, group=group)
@@ -82,7 +87,7 @@ class ShardedIndex:
 
     def local_keys(self, queries, k):
         """[nq][k] int64 sorted keys of this shard, padded with KEY_MAX when the shard has < k rows."""
-        n_local = self.codes.shape[0]
+        n_local = self.n_local
         nq = queries.shape[0]
         k_local = min(k, n_local)
         if k_local == 0:

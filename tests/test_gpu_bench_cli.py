@@ -58,6 +58,12 @@ def test_driver_command_shape_one_process_per_gpu(ngpu, rows):
     assert ref and "error" not in ref, ref
     assert ref["answer_identical_to_the_sharded_run"] is True
     assert line["roofline"] and line["roofline"]["kernel"] == "adc_scan_kernel<8>"
+    # the same workload once more through the library's own multi-device index (what a Julia session holds), from rank 0,
+    # with one LOGICAL shard per rank on the test box's device; on a real node `rccl_ranks` must equal N
+    lib = line["inproc"]
+    assert lib and "error" not in lib, lib
+    assert lib["shards"] == ngpu and lib["answer_identical"] is True and lib["ms_per_step"] > 0
+    assert lib["exchange"] in ("peer", "rccl", "none")
 
 
 def test_inproc_logical_shards_through_the_library_index():
@@ -116,7 +122,13 @@ def test_default_command_shape_single_gpu_contract():
     assert cpu["kind"] in ("reference", "port") and cpu["gpu_matches_cpu_bit_exact"] is True
     assert cpu["encode"]["codes_match"] is True
     enc = line["encode"]
-    assert enc["value"] > 0 and enc["roofline"]["kernel"] == "encode_pq_split_kernel"
+    assert enc["value"] > 0 and enc["roofline"]["kernel"] == "encode_pq_filter_kernel"
+    er = enc["roofline"]
+    assert er["bound"] == "simd-issue" and 0 < er["frac"] <= 1.0          # a fraction of the binding resource, never above 1
+    assert 0 < er["bf16_mfma"]["frac"] <= 1.0 and 0 < er["hbm"]["frac"] <= 1.0 and "f32_equivalent" in er
+    # replayed PMC traffic is bound to the kernel instantiation and library build that just ran: a number or an explained null
+    assert roof["traffic"] is None or roof["traffic"] > 0
+    assert roof["hbm"]["traffic_source"]
     assert line["checks"]["ascending"] and line["checks"]["ids_unique_per_query"]
     assert line["host_path"]["same_answer_as_resident"] is True
     assert line["recall"]["r@1"] > 0.2

@@ -1,4 +1,4 @@
-"""GPU, full BASELINE sizes: how often does the f32 encode (GEMM-trick distance, first-index argmin -- the
+"""GPU, BASELINE shapes (5e5 rows): how often does the f32 encode (GEMM-trick distance, first-index argmin -- the
 arithmetic of Distances.pairwise + Clustering.update_assignments!, src/PQ.jl:40-41) pick a different centroid
 than exact arithmetic would?  SURVEY.md 8c predicted "O(<= 10) near-tie flips per 8e6 assignments"; this test
 MEASURES it on the HIP output: every code that differs from the float64 argmin must be a near-tie -- its float64
@@ -43,13 +43,14 @@ def _flips(X, Ccat_list, codes, off):
 
 
 @pytest.mark.parametrize("kind", ["sift", "deep"])
-def test_f32_vs_f64_argmin_flips_at_full_size(kind):
+def test_f32_vs_f64_argmin_flips_at_bench_shape(kind):
     import torch
     import rayuela_jl_amd.synth as synth
     import rayuela_jl_amd.synth_torch as st
     from rayuela_jl_amd import device as rqd
     dev = torch.device("cuda", 0)
-    n, h = 1_000_000, 256
+    n, h = 500_000, 256        # (1e6 in round 4: same rates; every assignment of the full base is compared with the oracle in
+                               #  test_gpu_encode_margin.py, this test counts near-tie flips against float64)
     if kind == "sift":
         d, m = 128, 8
         gen = lambda rows, row0: st.sift_like(rows, d, seed=synth.SEED_BASE, ncentres=65536, row0=row0, device=dev)   # noqa: E731
@@ -71,10 +72,10 @@ def test_f32_vs_f64_argmin_flips_at_full_size(kind):
     print("\n%s-like %d x %d, m=%d: %d of %d assignments differ from the float64 argmin (%.2e), %d outside the "
           "near-tie bound, worst gap/bound = %.3f" % (kind, n, d, m, flips, n * m, flips / (n * m), outside, worst))
     assert outside == 0
-    assert flips <= 2000        # 2.5e-4 of the assignments; measured: see DESIGN.md section 2
-    # the same published algorithm with a real OpenBLAS sgemm / sdot underneath (oracle/blas_order.py), 2e5 rows
+    assert flips <= 1000        # 2.5e-4 of the assignments; measured: see DESIGN.md section 2
+    # the same published algorithm with a real OpenBLAS sgemm / sdot underneath (oracle/blas_order.py), 1e5 rows
     from oracle import blas_order
-    ns = 200_000
+    ns = 100_000
     Xh = X[:ns].cpu().numpy()
     blas = blas_order.encode_pq(Xh, C, off)
     mine = codes[:ns].cpu().numpy()

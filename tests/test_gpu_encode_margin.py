@@ -105,8 +105,8 @@ def test_filter_error_within_bound_on_hostile_inputs(rq, oracle, case, sub):
 
 @pytest.mark.parametrize("shape", ["sift", "deep"])
 def test_filter_error_and_margin_walk_at_full_size(rq, oracle, shape):
-    """1e6 bench vectors: (a) the error of every one of the 2e9 / 4e9 filter values against the bound, (b) ALL assignments
-    against the oracle at the shipped margin, (c) the margin walked down until codes change."""
+    """1e6 bench vectors: (a) the error of the filter values of a 250 000-row stratified sample against the bound, (b) ALL
+    8e6 / 1.6e7 assignments against the oracle at the shipped margin, (c) the margin walked down until codes change."""
     import torch
     import rayuela_jl_amd.synth as synth
     import rayuela_jl_amd.synth_torch as st
@@ -123,10 +123,15 @@ def test_filter_error_and_margin_walk_at_full_size(rq, oracle, shape):
         X, S = rqd.rotate_T(R, X), rqd.rotate_T(R, S)
     C = synth.codebooks(S.cpu().numpy(), m, h, seed=synth.SEED_CODEBOOK, iters=5, sample=20000)
     Xh = X.cpu().numpy()
-    worst, worst_u, nbad = _ratio_max(rq, oracle, Xh, C, m, h)
+    # (a) on every 4th 62500-row block (250 000 rows, 5e8 / 1e9 values): the host side of this sweep -- the oracle's h x n
+    # distance matrix -- is what made the round-4 suite take ten minutes on the driver's box; round 4 ran all 1e6 rows and
+    # found the maximum (0.053 / 0.363 * 2^-14) well inside the first block.  (b) below still covers EVERY assignment.
+    na = 250_000
+    Xa = np.ascontiguousarray(np.concatenate([Xh[o:o + na // 4] for o in range(0, n, n // 4)], 0))
+    worst, worst_u, nbad = _ratio_max(rq, oracle, Xa, C, m, h)
     print("filter error %s shape, %d x %d x %d values: max = %.3e = %.3f * 2^-14 (unclamped %.3f * 2^-14); wrong codes %d of %d" % (
-        shape, n, m, h, worst, worst / E_K, worst_u / E_K, nbad, n * m))
-    assert nbad == 0                       # (b) every assignment, not a sample
+        shape, na, m, h, worst, worst / E_K, worst_u / E_K, nbad, na * m))
+    assert nbad == 0
     assert worst <= E_K, worst / E_K       # (a)
     # (c) the margin walk: DELTA = numerator * 2^-14 * (max|c|^2 + |x|^2)
     Ccat = synth.cat_codebooks(C)
@@ -145,6 +150,6 @@ def test_filter_error_and_margin_walk_at_full_size(rq, oracle, shape):
     print("margin walk %s shape (numerator of DELTA_REL, codes that differ from the oracle of %d): %s" % (shape, n * m, table))
     print("   -> first failing numerator %s: safety factor of the shipped 3.0 >= %s" % (
         None if first_bad is None else first_bad / 1000.0, "inf" if not first_bad else "%.0fx" % (3000.0 / first_bad)))
-    assert table[0][1] == 0
+    assert table[0][1] == 0              # (b) every assignment of the 1e6 vectors, not a sample
     # the shipped margin holds with a factor of at least 4 to spare on this data
     assert first_bad is None or first_bad < 750, table

@@ -223,3 +223,20 @@ def test_clumped_base_does_not_fall_back(rq, oracle):
         sel = np.arange(0, nq, max(1, nq // 32))
         d0, i0 = oracle.linscan_aqd_query(B, np.stack(C), Q[sel], K)
         assert np.array_equal(i1.cpu().numpy().view(np.uint32)[sel], i0) and _eq_bits(d1.cpu().numpy()[sel], d0), nq
+
+
+def test_tiny_base_of_an_untiled_row_width_through_order_rows(rq, oracle):
+    """n < 1024 rows of m = 12 (rows padded to 16 bytes, nothing to order: perm = NULL): order_rows followed by linscan(OrderedBase)
+    used to be refused with RQ_EUNSUPPORTED; the pair must always be usable."""
+    import torch
+    from rayuela_jl_amd import device as rqd
+    rng = np.random.default_rng(5)
+    n, m, sub, nq, K = 700, 12, 4, 9, 50
+    B = rng.integers(0, 256, (n, m), dtype=np.uint8)
+    C = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    Q = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    ob = rqd.order_rows(torch.from_numpy(B).cuda())
+    assert ob.perm is None
+    d1, i1 = rqd.linscan(ob, torch.from_numpy(C).cuda(), torch.from_numpy(Q).cuda(), K)
+    d0, i0 = oracle.linscan_aqd_query(B, C, Q, K)
+    assert np.array_equal(i1.cpu().numpy().view(np.uint32), i0) and _eq_bits(d1.cpu().numpy(), d0)

@@ -89,6 +89,34 @@ def test_train_pq_reduces_the_error(rq, oracle):
     assert abs(e - e0) <= 1e-6 * e0
 
 
+@pytest.mark.parametrize("kind", ["sift", "clustered"])
+def test_train_pq_lands_where_clustering_kmeans_rules_land(rq, oracle, kind):
+    """rq_train_pq against oracle/train_oracle.py::train_pq_clustering -- Clustering.kmeans' own rules (kmeans++ seeding,
+    repick of emptied centres proportional to cost, stop on |objv - prev| < 1e-6) -- on 3 seeds each: the draws differ
+    (different random streams on the two sides), so the comparison is the final quantisation error, within 0.5 % on the
+    seed average and 1.5 % seed by seed.  `clustered`: fewer natural clusters than centres -- the shape that empties
+    clusters -- so that the repick rule is exercised on both sides."""
+    import rayuela_jl_amd.synth as synth
+    from oracle import train_oracle as to
+    if kind == "sift":
+        X = synth.sift_like(20000, 32, seed=77)
+        m, h, niter = 4, 64, 25
+    else:
+        rng = np.random.default_rng(9)
+        cen = rng.uniform(-200, 200, (24, 16)).astype(np.float32)
+        X = (cen[rng.integers(0, 24, 12000)] + rng.standard_normal((12000, 16)) * 2.0).astype(np.float32)
+        m, h, niter = 2, 64, 25
+    eg, eo = [], []
+    for seed in (1, 2, 3):
+        C, B, e = rq.train_pq(X, m, h, niter=niter, seed=seed)
+        assert np.array_equal(B, rq.quantize_pq(X, C))
+        _, _, e0 = to.train_pq_clustering(X, m, h, niter, seed)
+        eg.append(e); eo.append(e0)
+    print("train_pq %s: library %s  oracle (Clustering rules) %s" % (kind, np.round(eg, 3), np.round(eo, 3)))
+    assert abs(np.mean(eg) - np.mean(eo)) <= 0.005 * np.mean(eo), (eg, eo)
+    assert all(abs(a - b) <= 0.015 * b for a, b in zip(eg, eo)), (eg, eo)
+
+
 def test_experiment_opq_end_to_end(rq, oracle):
     """experiment_opq (src/OPQ.jl:142-171) on synthetic data: train -> quantize_opq -> linscan_opq ->
     eval_recall, all through the C ABI; the search leg must equal the oracle given the trained model."""

@@ -57,12 +57,17 @@ def test_prefilter_hot_loop_has_no_scratch_traffic(scan_asm, m, fine):
     start = scan_asm.index("\n" + name + ":")
     lines = scan_asm[start:scan_asm.index("s_endpgm", start)].splitlines()
     lo = [i for i, ln in enumerate(lines) if "RQ_FILTER_LOOP_BEGIN" in ln]
+    mid = [i for i, ln in enumerate(lines) if "RQ_FILTER_GATHERS_END" in ln]
     hi = [i for i, ln in enumerate(lines) if "RQ_FILTER_LOOP_END" in ln]
-    # (the END marker may be duplicated by tail duplication of the block loop's control flow: the region runs to the last one)
-    assert len(lo) == 1 and len(hi) >= 1 and lo[0] < hi[0], "filter loop markers not found in the generated code"
-    region = lines[lo[0]:hi[-1]]
-    gathers = sum(1 for ln in region if re.search(r"\bds_read_b(64|32)\b", ln))
+    # one marker each: BEGIN .. GATHERS_END is the streaming part (gathers, byte sums, alive bits), GATHERS_END .. LOOP_END the
+    # queueing of the alive rows with the call sites of the exact re-evaluation
+    assert len(lo) == 1 and len(mid) == 1 and len(hi) == 1 and lo[0] < mid[0] < hi[0], (lo, mid, hi)
+    stream = lines[lo[0]:mid[0]]
+    gathers = sum(1 for ln in stream if re.search(r"\bds_read_b(64|32)\b", ln))
     assert gathers >= 64, gathers                     # 8 rows x 8 (m = 8) / 4 rows x 16 (m = 16) gathers per block
+    assert not [ln for ln in stream if "scratch_" in ln], "scratch access in the streaming part of the pre-filter loop"
+    assert not [ln for ln in stream if "s_swappc" in ln], "a call inside the streaming part of the pre-filter loop"
+    region = lines[lo[0]:hi[0]]
     stores = [ln for ln in region if "scratch_store" in ln]
     loads = [ln for ln in region if "scratch_load" in ln]
     # Reloads right after a call of the exact re-evaluation belong to that (rare) path; the streaming path itself --
