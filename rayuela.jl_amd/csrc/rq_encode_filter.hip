@@ -224,7 +224,11 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_filter_kernel(EncParams
       const bf16x8_t Bh = __builtin_bit_cast(bf16x8_t, make_uint4(bh[0], bh[1], bh[2], bh[3]));
       const bf16x8_t Bl = __builtin_bit_cast(bf16x8_t, make_uint4(bl[0], bl[1], bl[2], bl[3]));
       float sb = sq.x + sq.y;
-      if constexpr (!PACK) sb += __shfl_xor(sb, 32);       // the other half-wave holds dimensions 8..15
+      if constexpr (!PACK) {                               // the other half-wave holds dimensions 8..15
+        float sa_ = sb, sb_ = sb;                          // (v_permlane32_swap: no trip through the LDS crossbar)
+        swap32(sa_, sb_);
+        sb += hi ? sa_ : sb_;
+      }
       // the next sub-vector travels while this one is filtered
       if (il + 1 < mg) gload(tile, il + 1);
       else if (tile + total_waves < ntiles) gload(tile + total_waves, 0);
@@ -347,10 +351,13 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_filter_kernel(EncParams
       const bool single = (mine_w >> 16) + (other_w >> 16) == 1u;
       const uint32_t kk = min(mine_w & 0xffffu, other_w & 0xffffu);       // the candidate (single) or any stand-in
       fl |= single ? 0u : (1u << il);
-      const uint32_t bk = kk & 0xffu;
-#pragma unroll
-      for (int w = 0; w < 4; ++w)
-        if ((i >> 3) == w) cw[w] |= (uint64_t)bk << (8 * (i & 7));
+      const uint64_t bk = (uint64_t)(kk & 0xffu) << (8 * (i & 7));
+      switch (i >> 3) {          // (uniform: one 64-bit shift and OR instead of four selected ones)
+        case 0: cw[0] |= bk; break;
+        case 1: cw[1] |= bk; break;
+        case 2: cw[2] |= bk; break;
+        default: cw[3] |= bk; break;
+      }
     }
     if (hi == 0 && row0 + j < p.n) {
       uint8_t *o = p.codes + (size_t)(row0 + j) * m;

@@ -27,7 +27,8 @@ int main(int argc, char **argv) {
   const uint32_t K = argc > 1 ? atoi(argv[1]) : 10000;
   const uint32_t cnt = argc > 2 ? atoi(argv[2]) : 19000;
   const int reps = 20;
-  for (int blocks : {256, 512}) {
+  const int lds_kb = argc > 3 ? atoi(argv[3]) : 72;      // 72: two workgroups per CU like inside the scan kernel; 41: three (a finish kernel of its own)
+  for (int blocks : {256, 512, 768, 1024}) {
     const size_t nkeys = (size_t)blocks * cnt;
     uint64_t *in, *scr, *out;
     uint16_t *bkt;
@@ -42,14 +43,14 @@ int main(int argc, char **argv) {
       h[i] = ((uint64_t)d << 32) | (uint32_t)i;
     }
     hipMemcpy(in, h.data(), nkeys * 8, hipMemcpyHostToDevice);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_ss), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_ss), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int it = 0; it < 2; ++it) {
       hipMemset(stats, 0, 16 * 8);
       hipEventRecord(e0);
       // 72 KiB of LDS per workgroup, like the scan kernel: two workgroups per CU at 512 blocks
-      hipLaunchKernelGGL(k_ss, dim3(blocks), dim3(512), 72 * 1024, 0, in, scr, bkt, out, cnt, K, reps, stats);
+      hipLaunchKernelGGL(k_ss, dim3(blocks), dim3(512), lds_kb * 1024, 0, in, scr, bkt, out, cnt, K, reps, stats);
       hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     }
     std::vector<uint64_t> ho((size_t)blocks * K);
@@ -63,8 +64,8 @@ int main(int argc, char **argv) {
       for (uint32_t i = 0; i < K; ++i) if (ref[i] != ho[(size_t)b * K + i]) { ok = false; break; }
     }
     const double tot = (double)st[0];
-    printf("blocks=%d K=%u cnt=%u: %.1f us per select+sort (wall per WG)  %s | sample-sort %.0f%% search %.0f%% scan+scatter %.0f%% rank %.0f%%\n",
-           blocks, K, cnt, ms * 1e3 / reps, ok ? "ok" : "MISMATCH", 100 * st[9] / tot, 100 * st[10] / tot,
+    printf("lds=%dKiB blocks=%d K=%u cnt=%u: %.1f us per select+sort (wall per WG) = %.0f sorts/ms  %s | sample-sort %.0f%% search %.0f%% scan+scatter %.0f%% rank %.0f%%\n",
+           lds_kb, blocks, K, cnt, ms * 1e3 / reps, blocks * reps / ms, ok ? "ok" : "MISMATCH", 100 * st[9] / tot, 100 * st[10] / tot,
            100 * st[11] / tot, 100 * (tot - st[9] - st[10] - st[11]) / tot);
     hipFree(in); hipFree(scr); hipFree(bkt); hipFree(out); hipFree(stats);
   }

@@ -1,11 +1,12 @@
-# Round-4 evidence: bench lines, rocprofv3 kernel stats and PMC passes of the same commands.  Run on the GPU box:
-#   bash tools/profile_round4.sh [quick]      (outputs under gpurun_out/r4; tools/collect_profiles.py copies the summaries
-#                                              to profiles/ and REWRITES profiles/r4_traffic.json from the PMC passes, so
+# Round-5 evidence: bench lines, rocprofv3 kernel stats and PMC passes of the same commands.  Run on the GPU box:
+#   bash tools/profile_round5.sh [quick]      (outputs under gpurun_out/r5; tools/collect_profiles.py copies the summaries
+#                                              to profiles/ and REWRITES profiles/r5_traffic.json from the PMC passes, so
 #                                              the bytes bench.py replays cannot go stale after a kernel change)
 set -x
 R=$PWD
-O=$R/gpurun_out/r4
+O=$R/gpurun_out/r5
 mkdir -p $O
+python -c "import rayuela_jl_amd as rq; from rayuela_jl_amd import _lib; print(_lib.lib().rq_version().decode().split('build ')[-1])" > $O/build_id.txt 2>/dev/null
 python bench.py > $O/bench_pq.json 2> $O/bench_pq.err
 python bench.py --workload opq > $O/bench_opq.json 2> $O/bench_opq.err
 python bench.py --workload deep > $O/bench_deep.json 2> $O/bench_deep.err
@@ -14,6 +15,7 @@ python bench.py --workload sift1b --steps 3 --warmup 1 > $O/bench_sift1b_1gpu.js
 # the exact per-GPU work of BASELINE config 5 on 8 GPUs: a 1.25e8-row shard, 1024 queries, k = 100
 python bench.py --workload sift1b --rows 125000000 --steps 5 --warmup 1 --no-cpu > $O/bench_sift1b_shard.json 2> $O/bench_sift1b_shard.err
 python bench.py --workload sift1b --inproc --gpus 1 --steps 3 --warmup 1 --no-cpu > $O/bench_sift1b_inproc.json 2> $O/bench_sift1b_inproc.err
+RQ_BENCH_BACKEND=gloo python bench.py --gpus 2 --rows 250000000 --steps 2 --warmup 1 --no-cpu > $O/bench_sift1b_2ranks_gloo.json 2> $O/bench_sift1b_2ranks_gloo.err
 python tools/index_overhead.py > $O/index_overhead.md 2> $O/index_overhead.err
 python bench.py --workload train_opq --steps 25 --warmup 2 > $O/bench_train_opq.json 2> $O/bench_train_opq.err
 python bench.py --workload train_pq --steps 25 --warmup 2 > $O/bench_train_pq.json 2> $O/bench_train_pq.err
