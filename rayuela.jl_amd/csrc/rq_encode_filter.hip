@@ -20,6 +20,8 @@
 // fragments of tile t + 1 are requested before the MFMAs of tile t issue, and the exact pass runs at full occupancy.
 #include "rq_encode_split.h"
 
+#include <type_traits>
+
 namespace rq {
 
 // ---- filter --------------------------------------------------------------------------------------------------------
@@ -202,8 +204,49 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_filter_kernel(EncParams
     const int64_t row0 = tile * 32;
     uint64_t cw[4] = {0, 0, 0, 0};
     uint32_t fl = 0;                 // bit il: (this row, sub-quantizer i0 + il) goes to the exact pass
-#pragma unroll 1
-    for (int il = 0; il < mg; ++il) {
+    // the tile loop's result for one sub-quantizer, consumed by `settle` (one candidate, or the exact pass)
+    struct Pend { f32x16 ub; float b1, delta; int t1, il; uint64_t amb; bool slow; };
+    auto settle = [&](const Pend &q) {
+      const int i = i0 + q.il;
+      float bo_a = q.b1, bo_b = q.b1;                              // the other half of this vector's centroids
+      swap32(bo_a, bo_b);
+      const float bo = hi ? bo_a : bo_b;
+      const float thr = __builtin_fminf(q.b1, bo) + q.delta;
+      const bool contend = (q.b1 <= thr) && !q.slow;
+#if defined(RQ_FILT_ABL) && RQ_FILT_ABL == 5
+      uint32_t cm = __float_as_uint(q.ub[3]) & 0xffffu;
+#else
+      uint32_t cm = mask_leq16_4(q.ub, thr);
+#endif
+      if (!contend) cm = 0;
+      const bool todo = contend && __builtin_amdgcn_inverse_ballot_w64(q.amb);
+      const int r1 = __builtin_ctz(cm | 0x10000u);
+      const uint32_t kmine = cm != 0u ? (uint32_t)(q.t1 * 32 + cbase + 8 * (r1 >> 2) + (r1 & 3)) : 0xffffu;
+      // candidate counts of the two halves add; a flagged tile or an unusable bound in either half shows
+      const uint32_t mine_w = ((uint32_t)__builtin_popcount(cm) | (todo ? 0x100u : 0u) | (q.slow ? 0x200u : 0u)) << 16 | kmine;
+      float ow_a = __uint_as_float(mine_w), ow_b = __uint_as_float(mine_w);
+      swap32(ow_a, ow_b);
+      const uint32_t other_w = __float_as_uint(hi ? ow_a : ow_b);
+      const bool single = (mine_w >> 16) + (other_w >> 16) == 1u;
+      const uint32_t kk = min(mine_w & 0xffffu, other_w & 0xffffu);       // the candidate (single) or any stand-in
+      fl |= single ? 0u : (1u << q.il);
+      const uint64_t bk = (uint64_t)(kk & 0xffu) << (8 * (i & 7));
+      switch (i >> 3) {          // (uniform: one 64-bit shift and OR instead of four selected ones)
+        case 0: cw[0] |= bk; break;
+        case 1: cw[1] |= bk; break;
+        case 2: cw[2] |= bk; break;
+        default: cw[3] |= bk; break;
+      }
+    };
+    Pend pend;
+    // One sub-quantizer: B fragments, tile loop.  EPI: the PREVIOUS sub-quantizer's `settle` -- ~80 VALU instructions in
+    // dependent chains with two half-wave exchanges, no matrix work of its own -- is placed inside this one's straight-line
+    // tile loop, where the scheduler can slide it under the MFMAs (build knob RQ_FILT_PIPE = 1; default: it runs right after its
+    // own loop).  MEASURED, round 5: the carried state (16 W values + 6 scalars) costs more than the overlap returns -- 252
+    // registers at 8 wavefronts per CU: 0.356 ms per 1e6 SIFT-shape vectors against 0.342 unpipelined at 8 and 0.334 at 12
+    // wavefronts (where the pipelined build spills 88 registers: 0.390); Deep shape 0.572 / 0.581 / 0.501.  Not shipped.
+    auto unit = [&](int il, auto epi_tag) {
+      constexpr bool EPI = decltype(epi_tag)::value;
       const int i = i0 + il;
       // |x|^2 (any order: it only scales the margin) and the B fragments: this lane's 8 K elements of x as bf16 pieces
       f32x2 sel[4];
@@ -322,43 +365,27 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_filter_kernel(EncParams
 #endif
           const f32x16 acc = products(cur);
           if (t > 0) filter(done, t - 1);
+          if constexpr (EPI) { if (t == (NT > 2 ? 2 : NT - 1)) settle(pend); }
           done = acc;
           if (t + 1 < NT) cur = nxt;
         }
         filter(done, NT - 1);
       }
+      pend.ub = ub; pend.b1 = b1; pend.delta = delta; pend.t1 = t1; pend.il = il; pend.amb = amb; pend.slow = slow;
+    };
 
-      // ---- one candidate, or the exact pass -------------------------------------------------------------------------
-      float bo_a = b1, bo_b = b1;                                  // the other half of this vector's centroids
-      swap32(bo_a, bo_b);
-      const float bo = hi ? bo_a : bo_b;
-      const float thr = __builtin_fminf(b1, bo) + delta;
-      const bool contend = (b1 <= thr) && !slow;
-#if defined(RQ_FILT_ABL) && RQ_FILT_ABL == 5
-      uint32_t cm = __float_as_uint(ub[3]) & 0xffffu;
+#if defined(RQ_FILT_PIPE) && RQ_FILT_PIPE
+    unit(0, std::false_type{});
+#pragma unroll 1
+    for (int il = 1; il < mg; ++il) unit(il, std::true_type{});
+    settle(pend);
 #else
-      uint32_t cm = mask_leq16_4(ub, thr);
-#endif
-      if (!contend) cm = 0;
-      const bool todo = contend && __builtin_amdgcn_inverse_ballot_w64(amb);
-      const int r1 = __builtin_ctz(cm | 0x10000u);
-      const uint32_t kmine = cm != 0u ? (uint32_t)(t1 * 32 + cbase + 8 * (r1 >> 2) + (r1 & 3)) : 0xffffu;
-      // candidate counts of the two halves add; a flagged tile or an unusable bound in either half shows
-      const uint32_t mine_w = ((uint32_t)__builtin_popcount(cm) | (todo ? 0x100u : 0u) | (slow ? 0x200u : 0u)) << 16 | kmine;
-      float ow_a = __uint_as_float(mine_w), ow_b = __uint_as_float(mine_w);
-      swap32(ow_a, ow_b);
-      const uint32_t other_w = __float_as_uint(hi ? ow_a : ow_b);
-      const bool single = (mine_w >> 16) + (other_w >> 16) == 1u;
-      const uint32_t kk = min(mine_w & 0xffffu, other_w & 0xffffu);       // the candidate (single) or any stand-in
-      fl |= single ? 0u : (1u << il);
-      const uint64_t bk = (uint64_t)(kk & 0xffu) << (8 * (i & 7));
-      switch (i >> 3) {          // (uniform: one 64-bit shift and OR instead of four selected ones)
-        case 0: cw[0] |= bk; break;
-        case 1: cw[1] |= bk; break;
-        case 2: cw[2] |= bk; break;
-        default: cw[3] |= bk; break;
-      }
+#pragma unroll 1
+    for (int il = 0; il < mg; ++il) {
+      unit(il, std::false_type{});
+      settle(pend);
     }
+#endif
     if (hi == 0 && row0 + j < p.n) {
       uint8_t *o = p.codes + (size_t)(row0 + j) * m;
       if ((m & 7) == 0 && mg == m) {
