@@ -159,6 +159,10 @@ int rq_dev_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n,
 /* Name of the kernel the calling thread's last encode call ran ("encode_pq_split_kernel", "encode_pq_direct_kernel", ...):
  * bench.py labels its encode roofline with it instead of guessing from the tuning. */
 const char *rq_last_encode_kernel(void);
+/* With tuning ENC_STATS = 1 (measurement aid; adds a synchronisation per encode): out2[0] = (vector, sub-quantizer) pairs of the
+ * calling thread's last encode through the filter kernels, out2[1] = how many of them the filter could not settle and the exact
+ * pass re-evaluated (1.5 % on SIFT-like, 0.5 % on Deep-like bench data).  Zeros when ENC_STATS was off. */
+int rq_last_encode_stats(uint64_t *out2);
 /* The scan kernel instantiation the calling thread's last linscan launched, spelled as rocprofv3 prints it
  * ("adc_scan_kernel<8, false, true, false>"); "" before the first scan.  bench.py replays committed PMC traffic figures
  * only for the very instantiation (and library build) they were measured on. */

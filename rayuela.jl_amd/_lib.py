@@ -55,6 +55,7 @@ SIGNATURES = {
     "rq_dev_encode_pq": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rq_dev_encode_pq_filter_w": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rq_last_encode_kernel": (C.c_char_p, []),
+    "rq_last_encode_stats": (C.c_int, [C.c_void_p]),
     "rq_dev_rotate_T": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp]),
     "rq_dev_encode_opq": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rq_dev_adc_lut": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),

@@ -1166,6 +1166,13 @@ int rq_dev_encode_pq_filter_w(uint8_t *codes, float *W, const float *X, const fl
 }
 
 const char *rq_last_encode_kernel(void) { return last_encode_kernel_name(); }
+int rq_last_encode_stats(uint64_t *out2) {
+  if (!out2) return fail(RQ_EINVAL, "rq_last_encode_stats: NULL");
+  unsigned long long t[2];
+  last_encode_stats(t);
+  out2[0] = t[0]; out2[1] = t[1];
+  return RQ_OK;
+}
 
 int rq_dev_rotate_T(float *RX, const float *R, const float *X, int d, int64_t n, void *stream) {
   DeviceInfo di;

@@ -436,6 +436,7 @@ __global__ __launch_bounds__(FIX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     }
   }
   if (!__syncthreads_or(any != 0u)) return;
+  if (p.stat && tid < 32 && tid < mg && cnt[tid]) atomicAdd(p.stat, (unsigned long long)cnt[tid]);
   // the norm table (canonical chain s = 0..sub-1 from +0; +inf for centroids >= h) of the launch's table image
   const float *sa_img = reinterpret_cast<const float *>(reinterpret_cast<const uint4 *>(p.image) + (size_t)mg * NT * SplitShape<SUB>::NPIECE * 64);
   for (int idx = tid; idx < mg * NT * 32; idx += FIX_THREADS) saL[idx] = sa_img[idx];
@@ -545,6 +546,9 @@ __global__ __launch_bounds__(FIX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   }
 }
 
+static thread_local unsigned long long g_enc_stats[2] = {0, 0};
+void last_encode_stats(unsigned long long out[2]) { out[0] = g_enc_stats[0]; out[1] = g_enc_stats[1]; }
+
 template <int SUB, int NT, int NWAVES>
 static int launch_encode_filter(EncParams p, int num_cu, hipStream_t stream) {
   p.NT = NT;
@@ -559,6 +563,15 @@ static int launch_encode_filter(EncParams p, int num_cu, hipStream_t stream) {
   RQ_TRY(workspace(WS_ENCFLAG, img_bytes + (size_t)p.n * sizeof(uint32_t), &fl, stream));
   p.image = static_cast<unsigned char *>(fl);
   p.flags = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(fl) + img_bytes);
+  // ENC_STATS = 1 (tests, DESIGN's figures): count the pairs that take the exact pass; costs a synchronous read-back
+  p.stat = nullptr;
+  const bool want_stats = tuning("ENC_STATS", 0) != 0;
+  void *stat_dev = nullptr;
+  if (want_stats) {
+    RQ_TRY(workspace(WS_COUNTER, 256, &stat_dev, stream));
+    p.stat = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(stat_dev) + 128);
+    RQ_HIP(hipMemsetAsync(p.stat, 0, 8, stream));
+  }
   auto kern = p.dbg_w ? encode_pq_filter_kernel<SUB, NT, NWAVES, true> : encode_pq_filter_kernel<SUB, NT, NWAVES, false>;
   const int64_t ntiles = (p.n + 31) / 32;
   const int grid = (int)std::min<int64_t>(num_cu, (ntiles + NWAVES - 1) / NWAVES);
@@ -577,6 +590,13 @@ static int launch_encode_filter(EncParams p, int num_cu, hipStream_t stream) {
     RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encode_pq_fix_kernel<SUB, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fix_lds));
     hipLaunchKernelGGL((encode_pq_fix_kernel<SUB, NT>), dim3((unsigned)nchunks), dim3(FIX_THREADS), fix_lds, stream, p);
     RQ_HIP(hipGetLastError());
+  }
+  if (want_stats) {
+    unsigned long long fl_pairs = 0;
+    RQ_HIP(hipMemcpyAsync(&fl_pairs, p.stat, 8, hipMemcpyDeviceToHost, stream));
+    RQ_HIP(hipStreamSynchronize(stream));
+    g_enc_stats[0] = (unsigned long long)p.n * (unsigned long long)p.m;
+    g_enc_stats[1] = fl_pairs;
   }
   return RQ_OK;
 }

@@ -136,6 +136,7 @@ int host_linscan_sharded(float *dists, uint32_t *ids, const uint8_t *codes, cons
 int encode_launch(uint8_t *codes, const float *X, const float *C, int64_t n, int d, int m, int h,
                   int num_cu, hipStream_t stream, float *dbg_w = nullptr);
 const char *last_encode_kernel_name();   // which kernel the calling thread's last encode_launch chose
+void last_encode_stats(unsigned long long out[2]);   // tuning ENC_STATS = 1: {pairs, pairs that took the exact pass} of that encode
 int rvq_residual_launch(float *Xr, const float *Ci, const uint8_t *stage_codes, uint8_t *codes, unsigned int *cnt,
                         int64_t n, int d, int m, int stage, hipStream_t stream);
 int rvq_encode_launch(uint8_t *codes, float *Xr, uint8_t *stage_codes, unsigned int *counts, const float *C,

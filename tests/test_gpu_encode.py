@@ -250,3 +250,34 @@ def test_split_encode_deep_shape_hostile(rq, oracle):
             C = [(rng.standard_normal((h, sub)) * scale).astype(np.float32) for _ in range(m)]
         got, old, ref = _enc_both(rq, oracle, X, C, m, h)
         assert np.array_equal(old, ref) and np.array_equal(got, ref), (scale, integer, int((got != ref).sum()))
+
+
+def test_share_of_pairs_that_take_the_exact_pass(rq):
+    """tuning ENC_STATS: how many (vector, sub-quantizer) pairs the bf16 filter leaves to the exact pass -- the figure the encode's
+    speed rests on (2-3 % on SIFT-like, under 1 % on Deep-like data); everything on degenerate input."""
+    import ctypes as C
+    import torch
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import device as rqd, _lib
+
+    def share(X, Cl, m):
+        rq.set_tuning("ENC_STATS", 1)
+        try:
+            rqd.encode_pq(torch.from_numpy(X).cuda(), torch.from_numpy(synth.cat_codebooks(Cl)).cuda(), m, 256)
+            torch.cuda.synchronize()
+            out = (C.c_uint64 * 2)()
+            _lib.check(_lib.lib().rq_last_encode_stats(C.cast(out, C.c_void_p)))
+        finally:
+            rq.set_tuning("ENC_STATS", 0)
+        assert out[0] == X.shape[0] * m
+        return out[1] / out[0]
+    Xs = synth.sift_like(200_000, 128, seed=3)
+    Cs = synth.codebooks(Xs[:20000], 8, 256, seed=4, iters=3, sample=20000)
+    Xd = synth.deep_like(200_000, 96, seed=5)
+    Cd = synth.codebooks(Xd[:20000], 16, 256, seed=6, iters=3, sample=20000)
+    fs, fd = share(Xs, Cs, 8), share(Xd, Cd, 16)
+    print("pairs left to the exact pass: sift-like %.3f %%, deep-like %.3f %%" % (100 * fs, 100 * fd))
+    assert 0 < fs < 0.06 and 0 <= fd < 0.03
+    Xz = np.zeros((5000, 128), dtype=np.float32)          # |x|^2 + max|c|^2 may be fine, but all-equal data ties everywhere
+    Cz = [np.zeros((256, 16), dtype=np.float32) for _ in range(8)]
+    assert share(Xz, Cz, 8) == 1.0

@@ -38,7 +38,14 @@ for kind in sys.argv[1:] or ["sift", "deep"]:
     C = synth.codebooks(X[:20000].cpu().numpy(), m, h, seed=synth.SEED_CODEBOOK, iters=3, sample=20000)
     Ccat = torch.from_numpy(synth.cat_codebooks(C)).to(dev)
     out = torch.empty((n, m), dtype=torch.uint8, device=dev)
+    rq.set_tuning("ENC_STATS", 1)        # share of (vector, sub-quantizer) pairs the filter leaves to the exact pass
     got = rqd.encode_pq(X, Ccat, m, h).cpu().numpy()
+    import ctypes as C
+    from rayuela_jl_amd import _lib
+    stt = (C.c_uint64 * 2)()
+    _lib.lib().rq_last_encode_stats(C.cast(stt, C.c_void_p))
+    rq.set_tuning("ENC_STATS", 0)
+    print("%s: %d of %d pairs to the exact pass (%.3f %%)" % (kind, stt[1], stt[0], 100.0 * stt[1] / max(1, stt[0])), flush=True)
     t1 = bench(lambda: rqd.encode_pq(X, Ccat, m, h, out=out))
     msg = ""
     if save:
