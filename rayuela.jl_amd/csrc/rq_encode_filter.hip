@@ -400,6 +400,107 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_filter_kernel(EncParams
   }
 }
 
+// The canonical evaluation of one work item -- sub-quantizer i, the rows the 32 lane pairs hold (lane (j, hi): row of lane j) --
+// against ALL h centroids on v_mfma_f32_32x32x2_f32; returns the first index of the minimum for the lane's row.  sa_i: this
+// sub-quantizer's |c|^2 table in C/D-fragment order, already offset by the lane's half (LDS).
+template <int SUB, int NT>
+__device__ __forceinline__ int exact_item(const EncParams &p, int i, int64_t row, const float4 *sa_i) {
+  constexpr int KS = SUB / 2;
+  const int lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
+  const int h = p.h, d = p.d;
+  // the row's sub-vector: |x|^2 (canonical chain) and the B fragments (lane: k = 2 kk + hi of vector j)
+  float x[SUB];
+  const float *xs = p.X + (size_t)row * d + (size_t)i * SUB;
+  if ((SUB % 4 == 0) && (d % 4 == 0) && (((uintptr_t)p.X & 15) == 0)) {
+#pragma unroll
+    for (int s4 = 0; s4 < SUB / 4; ++s4) {
+      const float4 v = reinterpret_cast<const float4 *>(xs)[s4];
+      x[4 * s4] = v.x; x[4 * s4 + 1] = v.y; x[4 * s4 + 2] = v.z; x[4 * s4 + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int s2 = 0; s2 < SUB / 2; ++s2) {
+      const f32x2 v = reinterpret_cast<const f32x2 *>(xs)[s2];
+      x[2 * s2] = v.x; x[2 * s2 + 1] = v.y;
+    }
+  }
+  float sb = 0.0f;
+#pragma unroll
+  for (int s = 0; s < SUB; ++s) sb = __builtin_fmaf(x[s], x[s], sb);
+  float b[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) b[kk] = hi ? x[2 * kk + 1] : x[2 * kk];
+  ArgminState st;
+  st.best_v = __uint_as_float(0x7f800000u);
+  st.best_t = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) st.ub[r] = f32x2{0.0f, 0.0f};
+  // A fragments: lane (j, hi) wants C_i[32 t + j][2 kk + hi].  For 8-wide halves (sub = 16) the lane loads floats
+  // 8 hi .. 8 hi + 7 of its centroid (two 16-byte loads) and one v_permlane32_swap per register PAIR turns
+  // (c[2q] | c[8 + 2q]), (c[2q + 1] | c[9 + 2q]) into the fragments of k-steps q and 4 + q; other widths load the whole
+  // row and select.  Four tiles are requested at a time, so an item waits for L2 twice, not once per tile.
+  auto cload = [&](int t, float (&a)[KS]) {
+    const int cen = t * 32 + j;
+    if constexpr (SUB == 16) {
+      float4 v0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), v1 = v0;
+      if (cen < h) {
+        const float4 *src = reinterpret_cast<const float4 *>(p.C + ((size_t)i * h + cen) * SUB + 8 * hi);
+        v0 = src[0]; v1 = src[1];
+      }
+      float r[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        swap32(r[2 * q], r[2 * q + 1]);
+        a[q] = r[2 * q]; a[4 + q] = r[2 * q + 1];
+      }
+    } else {
+      float c[SUB];
+#pragma unroll
+      for (int s = 0; s < SUB; ++s) c[s] = 0.0f;
+      if (cen < h) {
+        const float *src = p.C + ((size_t)i * h + cen) * SUB;
+        if constexpr (SUB % 4 == 0) {
+#pragma unroll
+          for (int s4 = 0; s4 < SUB / 4; ++s4) {
+            const float4 v = reinterpret_cast<const float4 *>(src)[s4];
+            c[4 * s4] = v.x; c[4 * s4 + 1] = v.y; c[4 * s4 + 2] = v.z; c[4 * s4 + 3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int s2 = 0; s2 < SUB / 2; ++s2) {
+            const f32x2 v = reinterpret_cast<const f32x2 *>(src)[s2];
+            c[2 * s2] = v.x; c[2 * s2 + 1] = v.y;
+          }
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) a[kk] = hi ? c[2 * kk + 1] : c[2 * kk];
+    }
+  };
+  constexpr int TB = NT < 4 ? NT : (KS >= 8 ? 2 : 4);        // tiles per batch (registers: 128 per lane at 4 wavefronts per SIMD)
+#pragma unroll
+  for (int t0 = 0; t0 < NT; t0 += TB) {
+    float a[TB][KS];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) cload(t0 + u, a[u]);
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][kk], b[kk], acc, 0, 0, 0);
+      tile_argmin(acc, sa_i + (size_t)(t0 + u) * 8, sb, t0 + u, st);
+    }
+  }
+  float best_v = st.best_v;
+  int best_i = argmin_finish(st, hi);
+  const float ov = __shfl_xor(best_v, 32);
+  const int oi = __shfl_xor(best_i, 32);
+  if (ov < best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+  return best_i;
+}
+
 // ---- exact pass ----------------------------------------------------------------------------------------------------
 // One 256-thread workgroup per chunk of FIX_ROWS rows.  The flagged rows of the chunk are collected per sub-quantizer in LDS;
 // a work item is (sub-quantizer, 32 flagged rows), taken by the wavefronts in turn.  The canonical evaluation is the one of
@@ -409,6 +510,11 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_filter_kernel(EncParams
 // the minimum of v = max(fl(fl(sa + sb) - 2g), 0), whatever the filter thought of the pair.  (Round 5's first version
 // evaluated the centroids on the VALU, four per lane and one row per wavefront at a time: 0.34 ns per pair, 0.1 ms for the
 // 2.4 % of the pairs of 1e6 SIFT-like vectors; on the matrix cores it is ~0.1 ns.)
+// (Round 5, measured and not kept: the same pass at the END of the filter kernel -- per-workgroup lists of the open pairs, the
+// |c|^2 table already in LDS, no flags array, one launch less.  Same speed at 1e6 rows (0.348 / 0.350 vs 0.345 / 0.344 ms at SIFT
+// shape, 0.513 / 0.520 vs 0.522 / 0.532 at Deep shape; 41 vs 46 us at 8192 rows): a workgroup's 16 items over 12 wavefronts are two
+// rounds of the same dependent chain -- row -> sub-vector from HBM -> centroid rows from L2 -> 64 MFMAs -- behind a barrier all
+// its wavefronts reach at different times, and it needs 4 m bytes of list scratch per row instead of 4.)
 constexpr int FIX_ROWS = 2048;
 constexpr int FIX_THREADS = 512;
 
@@ -450,97 +556,7 @@ __global__ __launch_bounds__(FIX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
       if ((item & (FIX_THREADS / 64 - 1)) != wave) continue;
       const int e = min(e0 + j, ne - 1);                  // (lanes past the end repeat the last row; nothing is stored for them)
       const int64_t row = row_base + list[(size_t)il * FIX_ROWS + e];
-      // the row's sub-vector: |x|^2 (canonical chain) and the B fragments (lane: k = 2 kk + hi of vector j)
-      float x[SUB];
-      const float *xs = p.X + (size_t)row * d + (size_t)i * SUB;
-      if ((SUB % 4 == 0) && (d % 4 == 0) && (((uintptr_t)p.X & 15) == 0)) {
-#pragma unroll
-        for (int s4 = 0; s4 < SUB / 4; ++s4) {
-          const float4 v = reinterpret_cast<const float4 *>(xs)[s4];
-          x[4 * s4] = v.x; x[4 * s4 + 1] = v.y; x[4 * s4 + 2] = v.z; x[4 * s4 + 3] = v.w;
-        }
-      } else {
-#pragma unroll
-        for (int s2 = 0; s2 < SUB / 2; ++s2) {
-          const f32x2 v = reinterpret_cast<const f32x2 *>(xs)[s2];
-          x[2 * s2] = v.x; x[2 * s2 + 1] = v.y;
-        }
-      }
-      float sb = 0.0f;
-#pragma unroll
-      for (int s = 0; s < SUB; ++s) sb = __builtin_fmaf(x[s], x[s], sb);
-      float b[KS];
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) b[kk] = hi ? x[2 * kk + 1] : x[2 * kk];
-      ArgminState st;
-      st.best_v = __uint_as_float(0x7f800000u);
-      st.best_t = 0;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) st.ub[r] = f32x2{0.0f, 0.0f};
-      const float4 *sa_i = reinterpret_cast<const float4 *>(saL + ((size_t)il * NT * 2 + hi) * 16);
-      // A fragments: lane (j, hi) wants C_i[32 t + j][2 kk + hi].  For 8-wide halves (sub = 16) the lane loads floats
-      // 8 hi .. 8 hi + 7 of its centroid (two 16-byte loads) and one v_permlane32_swap per register PAIR turns
-      // (c[2q] | c[8 + 2q]), (c[2q + 1] | c[9 + 2q]) into the fragments of k-steps q and 4 + q; other widths load the whole
-      // row and select.  Four tiles are requested at a time, so an item waits for L2 twice, not once per tile.
-      auto cload = [&](int t, float (&a)[KS]) {
-        const int cen = t * 32 + j;
-        if constexpr (SUB == 16) {
-          float4 v0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), v1 = v0;
-          if (cen < h) {
-            const float4 *src = reinterpret_cast<const float4 *>(p.C + ((size_t)i * h + cen) * SUB + 8 * hi);
-            v0 = src[0]; v1 = src[1];
-          }
-          float r[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            swap32(r[2 * q], r[2 * q + 1]);
-            a[q] = r[2 * q]; a[4 + q] = r[2 * q + 1];
-          }
-        } else {
-          float c[SUB];
-#pragma unroll
-          for (int s = 0; s < SUB; ++s) c[s] = 0.0f;
-          if (cen < h) {
-            const float *src = p.C + ((size_t)i * h + cen) * SUB;
-            if constexpr (SUB % 4 == 0) {
-#pragma unroll
-              for (int s4 = 0; s4 < SUB / 4; ++s4) {
-                const float4 v = reinterpret_cast<const float4 *>(src)[s4];
-                c[4 * s4] = v.x; c[4 * s4 + 1] = v.y; c[4 * s4 + 2] = v.z; c[4 * s4 + 3] = v.w;
-              }
-            } else {
-#pragma unroll
-              for (int s2 = 0; s2 < SUB / 2; ++s2) {
-                const f32x2 v = reinterpret_cast<const f32x2 *>(src)[s2];
-                c[2 * s2] = v.x; c[2 * s2 + 1] = v.y;
-              }
-            }
-          }
-#pragma unroll
-          for (int kk = 0; kk < KS; ++kk) a[kk] = hi ? c[2 * kk + 1] : c[2 * kk];
-        }
-      };
-      constexpr int TB = NT < 4 ? NT : (KS >= 8 ? 2 : 4);        // tiles per batch (registers: 128 per lane at 4 wavefronts per SIMD)
-#pragma unroll
-      for (int t0 = 0; t0 < NT; t0 += TB) {
-        float a[TB][KS];
-#pragma unroll
-        for (int u = 0; u < TB; ++u) cload(t0 + u, a[u]);
-#pragma unroll
-        for (int u = 0; u < TB; ++u) {
-          f32x16 acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-          for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][kk], b[kk], acc, 0, 0, 0);
-          tile_argmin(acc, sa_i + (size_t)(t0 + u) * 8, sb, t0 + u, st);
-        }
-      }
-      float best_v = st.best_v;
-      int best_i = argmin_finish(st, hi);
-      const float ov = __shfl_xor(best_v, 32);
-      const int oi = __shfl_xor(best_i, 32);
-      if (ov < best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+      const int best_i = exact_item<SUB, NT>(p, i, row, reinterpret_cast<const float4 *>(saL + ((size_t)il * NT * 2 + hi) * 16));
       if (hi == 0 && e0 + j < ne) p.codes[(size_t)row * m + i] = (uint8_t)best_i;
     }
   }
