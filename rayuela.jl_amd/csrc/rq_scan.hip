@@ -489,7 +489,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
             // one bit per row of the chunk in a per-lane mask: the rows are queued once per chunk below (a ballot + prefix
             // count + LDS store per ROW cost ~11 VALU instructions, a fifth of the loop's VALU time -- and with 5 % of the
             // rows alive almost every ballot of 64 rows finds somebody)
-            amask |= filt_alive<M, FINE>(a) ? (1u << (u * RPT + r)) : 0u;
+            amask |= filt_alive<M, FINE, BIAS>(a) ? (1u << (u * RPT + r)) : 0u;
           }
           __builtin_amdgcn_sched_barrier(0);
           }  // gather batches

@@ -38,8 +38,26 @@ constexpr uint32_t FILT_CLAMP = 31;
 #define RQ_FILT_THR8 95
 #endif
 constexpr uint32_t filt_thr8(bool fine) { return fine ? 191u : (uint32_t)RQ_FILT_THR8; }
-constexpr uint32_t filt_clamp8(bool fine) { return fine ? 63u : 31u; }
+// Round 5 (m = 8, coarse tables): the entries of sub-quantizer 0 carry an OFFSET of 127 - THR, so that "sum <= THR" IS bit 7
+// of the byte sum -- the alive test needs no compare arithmetic (5 of the hot loop's 25 VALU instructions per row) -- at the
+// price of a lower per-entry clamp: 8 * clamp + offset <= 255 keeps the byte sums from carrying into their neighbours
+// (THR 95: offset 32, clamp 27 instead of 31; clamping only lowers entries, i.e. lets a few more rows through).
+#ifndef RQ_FILT_OFFSET
+#define RQ_FILT_OFFSET 1
+#endif
+constexpr uint32_t filt_off8(bool fine) { return (!fine && RQ_FILT_OFFSET && RQ_FILT_THR8 < 127) ? 127u - (uint32_t)RQ_FILT_THR8 : 0u; }
+constexpr bool filt_bit7(bool fine) { return !fine && (filt_off8(false) != 0u || RQ_FILT_THR8 == 127); }
+constexpr uint32_t filt_clamp8(bool fine) { return fine ? 63u : (filt_off8(false) ? (255u - filt_off8(false)) / 8u : 31u); }
 constexpr uint32_t FILT_THR16 = 159;
+// m = 16, same trick (build knob RQ_FILT_OFFSET16, OFF): the first sub-quantizer of BOTH sets would carry (127 - (THR16 - 1) / 2)
+// = 48, so that the per-byte average of the two sums is <= (THR16 - 1) / 2 exactly when its bit 7 is clear (the offsets add 96,
+// an even number, to A + B: the floor of the average moves by exactly 48); clamp (255 - 48) / 8 = 25 instead of 31.  Measured
+// at Deep1M shape: k = 100 level (4.16 ms), k = 1000 4.93 vs 4.86 ms -- at m = 16 the lower clamp costs more rows than the
+// six instructions per row buy.  m = 8 (shipped): k = 1 1.458 vs 1.504 ms, k = 100 1.553 vs 1.596, k = 1000 2.019 vs 2.026.
+#ifndef RQ_FILT_OFFSET16
+#define RQ_FILT_OFFSET16 0
+#endif
+constexpr uint32_t filt_off16() { return RQ_FILT_OFFSET16 ? 127u - (FILT_THR16 - 1u) / 2u : 0u; }
 
 // (byte k of w) << SH in ONE VALU instruction (SDWA operand select; the compiler emits v_bfe_u32 + v_lshl_add_u32)
 template <int K, int SH>
@@ -80,7 +98,7 @@ template <> struct FiltVec<16> { using type = uint2; };
 // per-entry clamp of the byte tables: (entries per byte sum) * clamp <= 255.  LSQ scans add the row-norm entry to the
 // LAST byte sum: 5 entries of <= 51 at m = 8 (two sets of 4 and 4 + 1), 9 of <= 28 at m = 16 (sets of 8 and 8 + 1)
 template <int M, bool FINE, bool LSQ>
-constexpr uint32_t filt_clamp() { return LSQ ? (M == 8 ? 51u : 28u) : (M == 8 ? filt_clamp8(FINE) : FILT_CLAMP); }
+constexpr uint32_t filt_clamp() { return LSQ ? (M == 8 ? 51u : 28u) : (M == 8 ? filt_clamp8(FINE) : (M == 16 && filt_off16() ? (255u - filt_off16()) / 8u : FILT_CLAMP)); }
 
 // row norm -> its quantisation cell's LOWER edge, with exactly these two rounded operations (the quantiser checks its
 // choice against the same expression, so EDGE(byte of a row) <= the row's norm holds in exact arithmetic)
@@ -222,6 +240,12 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
         const float x = diff * ctrl->finv[quad * 4 + c];
         w |= (uint32_t)fminf(fmaxf(x, 0.0f), (float)filt_clamp<M, FINE, LSQ>()) << (8 * c);   // float -> uint truncates = floor (x >= 0)
       }
+      if constexpr (M == 8 && !LSQ && filt_off8(FINE) != 0u) {
+        if (kk == 0) w += filt_off8(FINE) * 0x01010101u;         // (clamp + offset <= 255: no carry between the bytes)
+      }
+      if constexpr (M == 16 && !LSQ && filt_off16() != 0u) {
+        if ((kk & 7) == 0) w += filt_off16() * 0x01010101u;      // first sub-quantizer of each of the two sets
+      }
       qtab[e * NQUAD + quad] = w;
     }
   }
@@ -248,7 +272,7 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
 //           sums s <= 252.  ((s | 0x80) - (T+1)) has bit 7 set iff (s & 0x7f) > T, and any s >= 0x80 is > T as well; no
 //           borrow crosses a byte because (s | 0x80) >= T + 1.
 //   M = 16: two sets of 4 byte sums; per query A + B <= THR16  <=>  their per-byte average <= (THR16 - 1) / 2, same trick.
-template <int M, bool FINE>
+template <int M, bool FINE, bool LSQ = false>
 __device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC * ScanCfg<M>::NQUAD]) {
   if constexpr (M == 8) {
     // NQUAD dwords of 4 byte sums per set; FINE: two sets (k < 4, k >= 4), compared through their per-byte average
@@ -261,7 +285,7 @@ __device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC 
       uint32_t v = a[j];
       if constexpr (FINE) v = (a[j] & a[NQ + j]) + (((a[j] ^ a[NQ + j]) >> 1) & 0x7f7f7f7fu);
       // THR = 127 (coarse tables): "sum <= THR" IS bit 7 of the byte sum -- no compare arithmetic at all
-      if constexpr (!FINE && filt_thr8(false) == 127u) all &= v;
+      if constexpr (filt_bit7(FINE)) all &= v;
       else all &= ((v | H) - TC) | v;
     }
     return (all & H) != H;
@@ -272,6 +296,7 @@ __device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC 
     constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR16 - 1u) / 2u + 1u) * 0x01010101u;
     const uint32_t v0 = (a[0] & a[2]) + (((a[0] ^ a[2]) >> 1) & 0x7f7f7f7fu);
     const uint32_t v1 = (a[1] & a[3]) + (((a[1] ^ a[3]) >> 1) & 0x7f7f7f7fu);
+    if constexpr (M == 16 && !LSQ && filt_off16() != 0u) return (v0 & v1 & H) != H;      // offset tables (PQ / CQ scans only)
     const uint32_t g0 = ((v0 | H) - TC) | v0, g1 = ((v1 | H) - TC) | v1;
     return (g0 & g1 & H) != H;
   } else {
@@ -295,7 +320,7 @@ __device__ __forceinline__ uint32_t high_bits4(uint32_t x) {   // bits 7, 15, 23
   return (((x >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xfu;
 }
 
-template <int M, bool FINE>
+template <int M, bool FINE, bool LSQ = false>
 __device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<M>::NACC * ScanCfg<M>::NQUAD]) {
   using Cfg = ScanCfg<M>;
   if constexpr (M == 8) {
@@ -307,7 +332,7 @@ __device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<
     for (int j = 0; j < NQ; ++j) {
       uint32_t v = a[j];
       if constexpr (FINE) v = (a[j] & a[NQ + j]) + (((a[j] ^ a[NQ + j]) >> 1) & 0x7f7f7f7fu);
-      if constexpr (!FINE && filt_thr8(false) == 127u) bits |= high_bits4(~v) << (4 * j);
+      if constexpr (filt_bit7(FINE)) bits |= high_bits4(~v) << (4 * j);
       else bits |= high_bits4(~(((v | H) - TC) | v)) << (4 * j);
     }
     return bits;
@@ -315,6 +340,7 @@ __device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<
     constexpr uint32_t H = 0x80808080u, TC = ((FILT_THR16 - 1u) / 2u + 1u) * 0x01010101u;
     const uint32_t v0 = (a[0] & a[2]) + (((a[0] ^ a[2]) >> 1) & 0x7f7f7f7fu);
     const uint32_t v1 = (a[1] & a[3]) + (((a[1] ^ a[3]) >> 1) & 0x7f7f7f7fu);
+    if constexpr (M == 16 && !LSQ && filt_off16() != 0u) return (high_bits4(~v0) | (high_bits4(~v1) << 4));
     const uint32_t g0 = ((v0 | H) - TC) | v0, g1 = ((v1 | H) - TC) | v1;
     return (high_bits4(~g0) | (high_bits4(~g1) << 4));
   } else {
@@ -355,7 +381,7 @@ __device__ __noinline__ void refine_pairs(ScanCtrl<ScanCfg<M>::QG> *ctrl, uint64
 #pragma unroll
     for (int j = 0; j < NQUAD; ++j) a[(Cfg::NACC - 1) * NQUAD + j] += fv_word(e, j);
   }
-  uint32_t alive = valid ? filt_alive_bits<M, FINE>(a) : 0u;
+  uint32_t alive = valid ? filt_alive_bits<M, FINE, BIAS>(a) : 0u;
   const uint32_t selmask = __builtin_amdgcn_readfirstlane(ctrl->selmask);
   const float bias = BIAS ? row_bias[row] : 0.0f;
   const float *lutf = reinterpret_cast<const float *>(lut4);
