@@ -574,9 +574,13 @@ static int launch_encode_filter(EncParams p, int num_cu, hipStream_t stream) {
   const size_t budget = 160 * 1024 - 64;
   const int gmax = (int)std::min<size_t>(std::min<size_t>(budget / per_sub, (size_t)p.m), 32);
   if (gmax < 1) return fail(RQ_EUNSUPPORTED, "split encode: one sub-codebook needs %zu B of LDS", per_sub);
+  // Rows go through in pieces of ENC_CHUNK_ROWS (4 Mi rows: 16 MiB of flags), so the library's scratch for this path is bounded
+  // whatever n is (an encode of 1e8 rows would otherwise keep 400 MB of flags per device and stream); a 1e6-row call is one piece.
+  const int64_t rows_all = p.n;
+  const int64_t piece = std::max<int64_t>(FIX_ROWS, (int64_t)tuning("ENC_CHUNK_ROWS", 1 << 22));
   void *fl = nullptr;
   const size_t img_bytes = (filter_image_bytes<SUB>(gmax, NT) + 255) & ~(size_t)255;
-  RQ_TRY(workspace(WS_ENCFLAG, img_bytes + (size_t)p.n * sizeof(uint32_t), &fl, stream));
+  RQ_TRY(workspace(WS_ENCFLAG, img_bytes + (size_t)std::min(rows_all, piece) * sizeof(uint32_t), &fl, stream));
   p.image = static_cast<unsigned char *>(fl);
   p.flags = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(fl) + img_bytes);
   // ENC_STATS = 1 (tests, DESIGN's figures): count the pairs that take the exact pass; costs a synchronous read-back
@@ -589,10 +593,9 @@ static int launch_encode_filter(EncParams p, int num_cu, hipStream_t stream) {
     RQ_HIP(hipMemsetAsync(p.stat, 0, 8, stream));
   }
   auto kern = p.dbg_w ? encode_pq_filter_kernel<SUB, NT, NWAVES, true> : encode_pq_filter_kernel<SUB, NT, NWAVES, false>;
-  const int64_t ntiles = (p.n + 31) / 32;
-  const int grid = (int)std::min<int64_t>(num_cu, (ntiles + NWAVES - 1) / NWAVES);
-  const int64_t nchunks = (p.n + FIX_ROWS - 1) / FIX_ROWS;
-  if (nchunks > 0x7fffffff) return fail(RQ_EUNSUPPORTED, "encode: n=%lld rows in one launch", (long long)p.n);
+  const float *X_all = p.X;
+  uint8_t *codes_all = p.codes;
+  float *dbg_all = p.dbg_w;
   for (int i0 = 0; i0 < p.m; i0 += gmax) {
     p.i0 = i0;
     p.i1 = std::min(p.m, i0 + gmax);
@@ -600,13 +603,22 @@ static int launch_encode_filter(EncParams p, int num_cu, hipStream_t stream) {
     hipLaunchKernelGGL((encode_tables_kernel<SUB, NT>), dim3(p.i1 - p.i0), dim3(256), 0, stream, p);
     RQ_HIP(hipGetLastError());
     RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, p);
-    RQ_HIP(hipGetLastError());
     const size_t fix_lds = (size_t)(p.i1 - p.i0) * NT * 32 * sizeof(float) + 32 * sizeof(uint32_t) + (size_t)(p.i1 - p.i0) * FIX_ROWS * sizeof(uint16_t);
     RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encode_pq_fix_kernel<SUB, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fix_lds));
-    hipLaunchKernelGGL((encode_pq_fix_kernel<SUB, NT>), dim3((unsigned)nchunks), dim3(FIX_THREADS), fix_lds, stream, p);
-    RQ_HIP(hipGetLastError());
+    for (int64_t r0 = 0; r0 < rows_all; r0 += piece) {
+      p.n = std::min(piece, rows_all - r0);
+      p.X = X_all + (size_t)r0 * p.d;
+      p.codes = codes_all + (size_t)r0 * p.m;
+      p.dbg_w = dbg_all ? dbg_all + (size_t)r0 * p.m * p.h : nullptr;
+      const int64_t ntiles = (p.n + 31) / 32;
+      const int grid = (int)std::min<int64_t>(num_cu, (ntiles + NWAVES - 1) / NWAVES);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, stream, p);
+      RQ_HIP(hipGetLastError());
+      hipLaunchKernelGGL((encode_pq_fix_kernel<SUB, NT>), dim3((unsigned)((p.n + FIX_ROWS - 1) / FIX_ROWS)), dim3(FIX_THREADS), fix_lds, stream, p);
+      RQ_HIP(hipGetLastError());
+    }
   }
+  p.n = rows_all;
   if (want_stats) {
     unsigned long long fl_pairs = 0;
     RQ_HIP(hipMemcpyAsync(&fl_pairs, p.stat, 8, hipMemcpyDeviceToHost, stream));

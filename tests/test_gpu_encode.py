@@ -281,3 +281,22 @@ def test_share_of_pairs_that_take_the_exact_pass(rq):
     Xz = np.zeros((5000, 128), dtype=np.float32)          # |x|^2 + max|c|^2 may be fine, but all-equal data ties everywhere
     Cz = [np.zeros((256, 16), dtype=np.float32) for _ in range(8)]
     assert share(Xz, Cz, 8) == 1.0
+
+
+def test_encode_in_pieces_of_rows_equals_one_piece(rq, oracle):
+    """tuning ENC_CHUNK_ROWS: the filter + exact-pass launches run per piece of rows (bounded scratch); codes must not depend on it"""
+    import torch
+    import rayuela_jl_amd.synth as synth
+    from rayuela_jl_amd import device as rqd
+    n, d, m = 50_011, 128, 8
+    X = synth.sift_like(n, d, seed=21)
+    C = synth.codebooks(X[:8000], m, 256, seed=22, iters=2, sample=8000)
+    Ccat = synth.cat_codebooks(C)
+    ref = oracle.encode_pq(X, Ccat, m, 256)
+    Xd, Cd = torch.from_numpy(X).cuda(), torch.from_numpy(Ccat).cuda()
+    rq.set_tuning("ENC_CHUNK_ROWS", 4096)
+    try:
+        got = rqd.encode_pq(Xd, Cd, m, 256).cpu().numpy()
+    finally:
+        rq.set_tuning("ENC_CHUNK_ROWS", 1 << 22)
+    assert np.array_equal(got, ref)
