@@ -502,7 +502,7 @@ __device__ __forceinline__ int exact_item(const EncParams &p, int i, int64_t row
 }
 
 // ---- exact pass ----------------------------------------------------------------------------------------------------
-// One 256-thread workgroup per chunk of FIX_ROWS rows.  The flagged rows of the chunk are collected per sub-quantizer in LDS;
+// One 1024-thread workgroup per chunk of p.fix_rows rows (4096 where the lists fit LDS; fewer for many sub-quantizers).  The flagged rows of the chunk are collected per sub-quantizer in LDS;
 // a work item is (sub-quantizer, 32 flagged rows), taken by the wavefronts in turn.  The canonical evaluation is the one of
 // the direct kernels (rq_encode.hip): the h x 32 inner products come off v_mfma_f32_32x32x2_f32 -- bit for bit the k-ordered
 // fmaf chain of oracle/rq_oracle.c:264-328 -- with the centroids (A fragments) read straight from global memory (the
@@ -515,8 +515,16 @@ __device__ __forceinline__ int exact_item(const EncParams &p, int i, int64_t row
 // shape, 0.513 / 0.520 vs 0.522 / 0.532 at Deep shape; 41 vs 46 us at 8192 rows): a workgroup's 16 items over 12 wavefronts are two
 // rounds of the same dependent chain -- row -> sub-vector from HBM -> centroid rows from L2 -> 64 MFMAs -- behind a barrier all
 // its wavefronts reach at different times, and it needs 4 m bytes of list scratch per row instead of 4.)
-constexpr int FIX_ROWS = 2048;
-constexpr int FIX_THREADS = 512;
+// Chunk size, measured (rocprofv3, 1e6 rows; flagged pairs 1.5 % / 0.5 %): 1024 rows x 256 threads 46 / 49 us (SIFT / Deep shape),
+// 2048 x 512 40 / 37, 4096 x 512 38 / 23, 4096 x 1024 38 / 21.5 -- sparse flags want big chunks (fuller 32-row items).
+#ifndef RQ_FIX_ROWS
+#define RQ_FIX_ROWS 4096
+#endif
+#ifndef RQ_FIX_THREADS
+#define RQ_FIX_THREADS 1024
+#endif
+constexpr int FIX_ROWS_MAX = RQ_FIX_ROWS;       // rows per workgroup when the per-sub-quantizer lists (2 bytes per row) fit LDS
+constexpr int FIX_THREADS = RQ_FIX_THREADS;
 
 template <int SUB, int NT>
 __global__ __launch_bounds__(FIX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_pq_fix_kernel(EncParams p) {
@@ -525,7 +533,8 @@ __global__ __launch_bounds__(FIX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   const int mg = p.i1 - p.i0, h = p.h, d = p.d, m = p.m;
   float *saL = reinterpret_cast<float *>(smem);                                   // [mg][NT][2][16] |c|^2, C/D-fragment order
   uint32_t *cnt = reinterpret_cast<uint32_t *>(saL + (size_t)mg * NT * 32);       // [mg]
-  uint16_t *list = reinterpret_cast<uint16_t *>(cnt + 32);                        // [mg][FIX_ROWS] flagged rows of the chunk
+  uint16_t *list = reinterpret_cast<uint16_t *>(cnt + 32);                        // [mg][fix_rows] flagged rows of the chunk
+  const int FIX_ROWS = p.fix_rows;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hi = lane >> 5;
   const int64_t row_base = (int64_t)blockIdx.x * FIX_ROWS;
@@ -577,6 +586,16 @@ static int launch_encode_filter(EncParams p, int num_cu, hipStream_t stream) {
   // Rows go through in pieces of ENC_CHUNK_ROWS (4 Mi rows: 16 MiB of flags), so the library's scratch for this path is bounded
   // whatever n is (an encode of 1e8 rows would otherwise keep 400 MB of flags per device and stream); a 1e6-row call is one piece.
   const int64_t rows_all = p.n;
+  // rows per workgroup of the exact pass: as many as the LDS lists allow (2 bytes per row and sub-quantizer of the launch group)
+  {
+    const size_t fixed = (size_t)gmax * NT * 32 * sizeof(float) + 32 * sizeof(uint32_t);
+    int64_t fr = ((int64_t)(160 * 1024 - 256) - (int64_t)fixed) / ((int64_t)gmax * 2);
+    fr = std::min<int64_t>(FIX_ROWS_MAX, fr / 32 * 32);
+    if (p.n < 500000) fr = std::min<int64_t>(fr, FIX_ROWS_MAX / 4);      // short inputs: more, smaller workgroups (latency)
+    if (fr < 32) return fail(RQ_EUNSUPPORTED, "split encode: the exact pass's lists do not fit LDS (m=%d)", p.m);
+    p.fix_rows = (int)fr;
+  }
+  const int FIX_ROWS = p.fix_rows;
   const int64_t piece = std::max<int64_t>(FIX_ROWS, (int64_t)tuning("ENC_CHUNK_ROWS", 1 << 22));
   void *fl = nullptr;
   const size_t img_bytes = (filter_image_bytes<SUB>(gmax, NT) + 255) & ~(size_t)255;

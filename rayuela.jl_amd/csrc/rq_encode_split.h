@@ -20,6 +20,7 @@ struct EncParams {
   float *dbg_w;     // split kernel, tests only: [n][m][h] receives the filter's W values (nullptr in every product call)
   uint32_t *flags;  // filter + exact pass: [n] words, bit (i - i0) set = (row, sub-quantizer i) goes to the exact pass
   unsigned char *image;  // filter + exact pass: the launch's LDS table image (encode_tables_kernel, rq_encode_filter.hip)
+  int fix_rows;          // exact pass: rows per workgroup (its per-sub-quantizer LDS lists hold 2 bytes per row)
   unsigned long long *stat;  // tuning ENC_STATS only: [0] += flagged (row, sub-quantizer) pairs (exact pass); nullptr otherwise
 };
 
