@@ -206,30 +206,30 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_filter_kernel(EncParams
     uint32_t fl = 0;                 // bit il: (this row, sub-quantizer i0 + il) goes to the exact pass
     // the tile loop's result for one sub-quantizer, consumed by `settle` (one candidate, or the exact pass)
     struct Pend { f32x16 ub; float b1, delta; int t1, il; uint64_t amb; bool slow; };
-    auto settle = [&](const Pend &q) {
-      const int i = i0 + q.il;
-      float bo_a = q.b1, bo_b = q.b1;                              // the other half of this vector's centroids
+    auto settle_v = [&](const f32x16 &q_ub, float q_b1, float q_delta, int q_t1, int q_il, uint64_t q_amb, bool q_slow) {
+      const int i = i0 + q_il;
+      float bo_a = q_b1, bo_b = q_b1;                              // the other half of this vector's centroids
       swap32(bo_a, bo_b);
       const float bo = hi ? bo_a : bo_b;
-      const float thr = __builtin_fminf(q.b1, bo) + q.delta;
-      const bool contend = (q.b1 <= thr) && !q.slow;
+      const float thr = __builtin_fminf(q_b1, bo) + q_delta;
+      const bool contend = (q_b1 <= thr) && !q_slow;
 #if defined(RQ_FILT_ABL) && RQ_FILT_ABL == 5
-      uint32_t cm = __float_as_uint(q.ub[3]) & 0xffffu;
+      uint32_t cm = __float_as_uint(q_ub[3]) & 0xffffu;
 #else
-      uint32_t cm = mask_leq16_4(q.ub, thr);
+      uint32_t cm = mask_leq16_4(q_ub, thr);
 #endif
       if (!contend) cm = 0;
-      const bool todo = contend && __builtin_amdgcn_inverse_ballot_w64(q.amb);
+      const bool todo = contend && __builtin_amdgcn_inverse_ballot_w64(q_amb);
       const int r1 = __builtin_ctz(cm | 0x10000u);
-      const uint32_t kmine = cm != 0u ? (uint32_t)(q.t1 * 32 + cbase + 8 * (r1 >> 2) + (r1 & 3)) : 0xffffu;
+      const uint32_t kmine = cm != 0u ? (uint32_t)(q_t1 * 32 + cbase + 8 * (r1 >> 2) + (r1 & 3)) : 0xffffu;
       // candidate counts of the two halves add; a flagged tile or an unusable bound in either half shows
-      const uint32_t mine_w = ((uint32_t)__builtin_popcount(cm) | (todo ? 0x100u : 0u) | (q.slow ? 0x200u : 0u)) << 16 | kmine;
+      const uint32_t mine_w = ((uint32_t)__builtin_popcount(cm) | (todo ? 0x100u : 0u) | (q_slow ? 0x200u : 0u)) << 16 | kmine;
       float ow_a = __uint_as_float(mine_w), ow_b = __uint_as_float(mine_w);
       swap32(ow_a, ow_b);
       const uint32_t other_w = __float_as_uint(hi ? ow_a : ow_b);
       const bool single = (mine_w >> 16) + (other_w >> 16) == 1u;
       const uint32_t kk = min(mine_w & 0xffffu, other_w & 0xffffu);       // the candidate (single) or any stand-in
-      fl |= single ? 0u : (1u << q.il);
+      fl |= single ? 0u : (1u << q_il);
       const uint64_t bk = (uint64_t)(kk & 0xffu) << (8 * (i & 7));
       switch (i >> 3) {          // (uniform: one 64-bit shift and OR instead of four selected ones)
         case 0: cw[0] |= bk; break;
@@ -238,6 +238,7 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_filter_kernel(EncParams
         default: cw[3] |= bk; break;
       }
     };
+    auto settle = [&](const Pend &q) { settle_v(q.ub, q.b1, q.delta, q.t1, q.il, q.amb, q.slow); };
     Pend pend;
     // One sub-quantizer: B fragments, tile loop.  EPI: the PREVIOUS sub-quantizer's `settle` -- ~80 VALU instructions in
     // dependent chains with two half-wave exchanges, no matrix work of its own -- is placed inside this one's straight-line
@@ -371,7 +372,11 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_filter_kernel(EncParams
         }
         filter(done, NT - 1);
       }
+#if defined(RQ_FILT_PIPE) && RQ_FILT_PIPE
       pend.ub = ub; pend.b1 = b1; pend.delta = delta; pend.t1 = t1; pend.il = il; pend.amb = amb; pend.slow = slow;
+#else
+      settle_v(ub, b1, delta, t1, il, amb, slow);       // (directly on the live registers: no copy of the 16 kept values)
+#endif
     };
 
 #if defined(RQ_FILT_PIPE) && RQ_FILT_PIPE
@@ -381,10 +386,9 @@ __global__ __launch_bounds__(NWAVES * 64) void encode_pq_filter_kernel(EncParams
     settle(pend);
 #else
 #pragma unroll 1
-    for (int il = 0; il < mg; ++il) {
-      unit(il, std::false_type{});
-      settle(pend);
-    }
+    for (int il = 0; il < mg; ++il) unit(il, std::false_type{});
+    (void)settle;
+    (void)pend;
 #endif
     if (hi == 0 && row0 + j < p.n) {
       uint8_t *o = p.codes + (size_t)(row0 + j) * m;
