@@ -581,7 +581,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
       const bool shortfall = ctrl->cnt[g] < min((uint32_t)p.K, rows);
       if (block_any(shortfall, ctrl->st.vote, vseq)) continue;  // exact fallback: redo the slice from tau = +inf
     }
-    if (!p.bigk) {
+    if (!p.bigk && !p.bfin) {
       bool need = ctrl->cnt[g] > (uint32_t)p.K;
       if (block_any(need, ctrl->st.vote, vseq)) compact_group<M>(ctrl, cand_wg, p, need, g, gi, vseq);
     }
@@ -596,6 +596,44 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
                   (uint32_t)p.id_base, smem + CTRL_BYTES, p.stats);
       RQ_STAT_ADD(5, t_ph);
       continue;
+    }
+    if (p.bfin) {
+      // Round 5: one wavefront per query cuts and sorts its candidates through distance buckets (bucket_finish_wave, rq_topk.h)
+      // -- no barrier, a fraction of the select + sorting-network work.  A query whose kept keys crowd one bucket (mass ties)
+      // gives up before writing anything; then the whole group takes the select + bitonic path below.
+      bool gave_up = false;
+      if (gi < 64) {
+        const uint32_t cnt = ctrl->cnt[g];
+        const uint32_t sel = ctrl->sel[g];
+        const uint64_t *src = cand_wg + ((size_t)g * 2 + sel) * p.cap;
+        uint64_t *dst = cand_wg + ((size_t)g * 2 + (sel ^ 1u)) * p.cap;
+        const uint32_t qq = q0 + (uint32_t)g;
+        if (qq < p.nq) {
+          // the wavefront's share of the (dead) table space: BF_NB bucket words, then room for the kept keys
+          const uint32_t share = (p.scratch_keys / (uint32_t)QG) * 8u & ~7u;          // bytes
+          unsigned char *mine = reinterpret_cast<unsigned char *>(scratch) + (size_t)g * share;
+          uint32_t *nxt = reinterpret_cast<uint32_t *>(mine) + 2;                  // nxt[-1] is part of the share
+          uint64_t *kbuf = reinterpret_cast<uint64_t *>(mine + BF_NB * 4u + 8u);
+          const uint32_t kcap = p.bfin == 2 ? 0u : (share - BF_NB * 4u - 8u) / 8u;     // (SCAN_BUCKET_FINISH=2: tests, kept keys through global memory)
+          uint64_t *ok = keys_base ? keys_base + (size_t)qq * key_stride : nullptr;
+          float *od = p.dists + (size_t)qq * p.K;
+          uint32_t *oi = p.ids + (size_t)qq * p.K;
+          const uint32_t idb = (uint32_t)p.id_base;
+          auto emit = [&](uint32_t r, uint64_t key) {
+            if (ok) ok[r] = key;
+            else { od[r] = key_dist(key); oi[r] = key_id(key) + idb; }
+          };
+          gave_up = !bucket_finish_wave(src, dst, cnt, (uint32_t)p.K, nxt, kbuf, kcap, (uint32_t)gi, emit, p.stats);
+          if (!gave_up)      // fewer candidates than K (slices shorter than K): the tail is padding, as the LDS sort leaves it
+            for (uint32_t i = cnt + (uint32_t)gi; i < (uint32_t)p.K; i += 64u) emit(i, KEY_MAX);
+        }
+      }
+      if (!block_any(gave_up, ctrl->st.vote, vseq)) {
+        RQ_STAT_ADD(5, t_ph);
+        continue;
+      }
+      bool need = ctrl->cnt[g] > (uint32_t)p.K;
+      if (block_any(need, ctrl->st.vote, vseq)) compact_group<M>(ctrl, cand_wg, p, need, g, gi, vseq);
     }
     // sort `nconc` queries at a time in LDS (scratch aliases the LUT, which is dead now)
     uint32_t nconc = p.scratch_keys / p.p2;
@@ -1087,6 +1125,8 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.gtab = reinterpret_cast<float4 *>(reinterpret_cast<char *>(cand) + pl.gtab_off);
   p.bkt = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(cand) + pl.bkt_off);
   p.bigk = pl.bigk ? 1 : 0;
+  // the bucket finish needs BF_NB words of LDS per query of the group in the (dead) table space
+  p.bfin = (!pl.bigk && (size_t)pl.scratch_keys * 8 >= (size_t)8 * (BF_NB * 4 + 64)) ? tuning("SCAN_BUCKET_FINISH", 1) : 0;     // (QG <= 8)
   p.filter = (lut_mode != LUT_LSQ && !row_bias && tuning("SCAN_FILTER", 1)) ? 1 : 0;
   p.norm_bytes = nullptr; p.norm_info = nullptr; p.cnorm = nullptr;
   if (lut_mode == LUT_LSQ && row_bias && norm_buf && (m == 8 || m == 16) && tuning("SCAN_FILTER", 1) &&

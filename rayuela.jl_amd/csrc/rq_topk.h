@@ -326,6 +326,203 @@ __device__ __forceinline__ void bitonic_sort_tiled(uint64_t *a, uint32_t p2, uin
   __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------
+// Bucket finish (round 5; K <= 1024): "the n_out smallest of cnt keys, ascending" by ONE wavefront with no barrier.
+//
+// The cut to K (radix select: up to 8 passes over the candidates, each behind workgroup barriers) and the LDS bitonic sort
+// (55 stages at 1024 keys) were 13 % of the headline scan, and all of it exposed (skipping both: 2.01 -> 1.76 ms).  A sorting
+// network does O(log^2 n) work per key; the keys of one query, however, are distances from a narrow range [d_min, tau], so a
+// LINEAR map of the distance word onto BF_NB buckets spreads them a few per bucket (the density grows towards tau, the last
+// buckets hold ~4x the average).  Per query:
+//   0. min / max of the distance words;  1. histogram (one LDS atomic per key);  2. exclusive scan: bucket starts, and the
+//   bucket b* that holds rank n_out - 1 -- later buckets are dropped, which IS the cut;  3. kept keys scattered to their
+//   bucket's range of `dst` (the query's other candidate buffer, L2-resident);  4. every kept key counts the keys of its
+//   bucket below it (keys are unique: ranks are a permutation) and is emitted at start[b] + rank if that is < n_out.
+// Exact for any input: the map is monotone in the key, so bucket order is key order, and inside a bucket the count decides.
+// Ties in the distance (integer-valued tables, duplicated rows) land in one bucket and step 4 is O(bucket^2): a bucket of
+// more than BF_MAX_BUCKET kept keys makes the routine give up BEFORE anything is written (false), and the caller runs the
+// select + bitonic path.  `nxt`: BF_NB words of LDS private to the wavefront (LDS operations of one wavefront complete in
+// order, so no barrier separates the steps); src and dst must not overlap.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t BF_NB = 512;
+constexpr uint32_t BF_MAX_BUCKET = 48;
+
+// Bucket of a key: x = (distance word - mn) / range in [0, 1], warped by x -> x^(2^psteps) (psteps squarings), times BF_NB.
+// Every step is monotone in the key (unsigned subtract, int -> float, float multiplications of non-negative values, truncation),
+// which is all exactness needs; the warp only evens the buckets out: the candidates of one query are the LOW tail of its distance
+// distribution, whose density grows like a power of (d - d_min) -- on the bench data a linear map put 3 % of the keys into the
+// last of 512 buckets.  With CDF(x) = x^p the mean of x is p / (p + 1); the caller picks the power of two next to that estimate.
+struct BfMap {
+  uint32_t mn;
+  float inv;          // a little below 1 / range, so that x <= 1
+  uint32_t psteps;    // wave-uniform
+};
+__device__ __forceinline__ uint32_t bf_bucket(uint64_t key, const BfMap &m) {
+  float y = (float)((uint32_t)(key >> 32) - m.mn) * m.inv;
+#pragma unroll
+  for (uint32_t i = 0; i < 5u; ++i) y = (i < m.psteps) ? y * y : y;
+  return min((uint32_t)(y * ((float)BF_NB - 0.5f)), BF_NB - 1u);        // float -> uint truncates
+}
+
+// step 4 on the kept keys kb[0..kept) (kept >= 1), grouped by bucket (LDS or global); nxt[b] = end of bucket b, nxt[b - 1] its
+// start, nxt[-1] = 0.  Every load is unconditional on a clamped index and all U of a step are issued together: written with
+// `cond ? load : 0` the compiler branched around each load and waited for it alone -- 8 dependent LDS round trips per step.
+template <uint32_t U, class KeyPtr, class Emit>
+__device__ __forceinline__ void bf_rank_emit(KeyPtr kb, const uint32_t *nxt, uint32_t kept, uint32_t n_out, const BfMap &map,
+                                             uint32_t lane, Emit emit) {
+#pragma unroll 1
+  for (uint32_t p0 = lane; p0 < kept; p0 += 64u * U) {
+    uint64_t k[U];
+    uint32_t lo[U], hi[U], r[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) k[u] = kb[min(p0 + 64u * u, kept - 1u)];
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+      const uint32_t b = bf_bucket(k[u], map);
+      lo[u] = nxt[(int)b - 1];
+      hi[u] = nxt[b];
+    }
+    uint32_t trips = 0u;
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+      if (!(p0 + 64u * u < kept)) hi[u] = lo[u];          // nothing to count for a padding slot
+      r[u] = lo[u];
+      trips = max(trips, hi[u] - lo[u]);
+    }
+#pragma unroll 1
+    for (uint32_t t = 0; t < trips; ++t) {
+      uint64_t o[U];
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) o[u] = kb[min(lo[u] + t, kept - 1u)];
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) r[u] += (uint32_t)((lo[u] + t < hi[u]) & (o[u] < k[u]));
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u)
+      if (p0 + 64u * u < kept && r[u] < n_out) emit(r[u], k[u]);
+  }
+}
+
+// nxt: BF_NB words behind one more (nxt[-1]), kbuf: kcap keys -- LDS private to the wavefront (kept keys beyond kcap: through `dst` in global memory)
+template <class Emit>
+__device__ __forceinline__ bool bucket_finish_wave(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint32_t cnt,
+                                                   uint32_t n_out, uint32_t *nxt, uint64_t *kbuf, uint32_t kcap, uint32_t lane,
+                                                   Emit emit, unsigned long long *stats = nullptr) {
+  // stats (optional, the workgroup's thread 0): cycles of [9] range + histogram, [10] scan + scatter, [11] rank + emit
+#define BF_T() ((stats && threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull)
+#define BF_ADD(slot, t0) do { if (stats && threadIdx.x == 0) atomicAdd(&stats[slot], (unsigned long long)clock64() - (t0)); } while (0)
+  unsigned long long t_s = BF_T();
+  constexpr uint32_t U = 16;            // keys per lane in flight over the candidate list (L2 round trips are what these passes cost)
+  n_out = min(n_out, cnt);
+  if (n_out == 0u) return true;
+  // ---- 0. range and mean of the distance words ----------------------------------------------------
+  uint32_t mn = 0xffffffffu, mx = 0u;
+  const uint32_t h0 = (uint32_t)(src[0] >> 32);
+  float sum = 0.0f;                    // of (distance word - h0): only the warp's exponent is estimated from it
+#pragma unroll 1
+  for (uint32_t i0 = lane; i0 < cnt; i0 += 64u * U) {
+    uint64_t k[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) k[u] = src[min(i0 + 64u * u, cnt - 1u)];      // (a repeated key changes neither min nor max)
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+      const uint32_t hw = (uint32_t)(k[u] >> 32);
+      mn = min(mn, hw);
+      mx = max(mx, hw);
+      sum += (i0 + 64u * u < cnt) ? (float)(int32_t)(hw - h0) : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+    sum += __shfl_xor(sum, off);
+  }
+  const uint32_t range = mx - mn;
+  BfMap map;
+  map.mn = mn;
+  // range == 0 (one distance): everything in bucket 0
+  map.inv = range ? (1.0f / (float)range) * (1.0f - 9.5367431640625e-7f) : 0.0f;
+  {
+    // mean of x over the candidates (the padding lanes added (h0 - h0) = 0): E = p / (p + 1) under CDF(x) = x^p
+    const float ex = range ? ((float)(int32_t)(h0 - mn) + sum / (float)cnt) / (float)range : 0.5f;
+    map.psteps = ex > 0.957f ? 5u : ex > 0.918f ? 4u : ex > 0.85f ? 3u : ex > 0.74f ? 2u : ex > 0.59f ? 1u : 0u;
+  }
+  // ---- 1. histogram -----------------------------------------------------------------------------
+#pragma unroll
+  for (uint32_t b = lane; b < BF_NB; b += 64u) nxt[b] = 0u;
+  if (lane == 0u) nxt[-1] = 0u;        // "the end of bucket -1": bucket 0 starts at 0 (bf_rank_emit reads it unconditionally)
+#pragma unroll 1
+  for (uint32_t i0 = lane; i0 < cnt; i0 += 64u * U) {
+    uint64_t k[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) k[u] = src[min(i0 + 64u * u, cnt - 1u)];      // (unconditional: the U loads go out together)
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u)
+      if (i0 + 64u * u < cnt) atomicAdd(&nxt[bf_bucket(k[u], map)], 1u);
+  }
+  BF_ADD(9, t_s);
+  t_s = BF_T();
+  // ---- 2. exclusive scan (lane l owns buckets [l * PER, (l + 1) * PER)), b*, the crowding test ----
+  constexpr uint32_t PER = BF_NB / 64u;
+  uint32_t c[PER], s = 0u;
+#pragma unroll
+  for (uint32_t j = 0; j < PER; ++j) { c[j] = nxt[lane * PER + j]; s += c[j]; }
+  const uint32_t incl = wave_incl_scan(s, (int)lane);
+  uint32_t run = incl - s, my_bstar = 0xffffffffu, my_kept = 0u;
+  bool crowded = false;
+#pragma unroll
+  for (uint32_t j = 0; j < PER; ++j) {
+    const uint32_t end = run + c[j];
+    if (run < n_out) {
+      crowded |= c[j] > BF_MAX_BUCKET;
+      if (n_out <= end) { my_bstar = lane * PER + j; my_kept = end; }
+    }
+    nxt[lane * PER + j] = run;          // walks to the bucket's end during the scatter
+    run = end;
+  }
+  if (__ballot(crowded)) return false;
+  const uint64_t owner = __ballot(my_bstar != 0xffffffffu);       // exactly one lane
+  const int ol = __ffsll((unsigned long long)owner) - 1;
+  const uint32_t bstar = (uint32_t)__builtin_amdgcn_readlane((int)my_bstar, ol);
+  const uint32_t kept = (uint32_t)__builtin_amdgcn_readlane((int)my_kept, ol);      // keys of the buckets <= b*
+  const bool in_lds = kept <= kcap;     // wave-uniform
+  // ---- 3. scatter the kept keys (LDS when they fit the wavefront's share, else the query's other candidate buffer) ----
+  auto scatter = [&](auto *out) {
+#pragma unroll 1
+    for (uint32_t i0 = lane; i0 < cnt; i0 += 64u * U) {
+      uint64_t k[U];
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) k[u] = src[min(i0 + 64u * u, cnt - 1u)];      // (unconditional: the U loads go out together)
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) {
+        if (i0 + 64u * u < cnt) {
+          const uint32_t b = bf_bucket(k[u], map);
+          if (b <= bstar) out[atomicAdd(&nxt[b], 1u)] = k[u];
+        }
+      }
+    }
+  };
+  // ---- 4. rank inside the bucket, emit ----------------------------------------------------------
+  if (in_lds) {
+    scatter(kbuf);
+    BF_ADD(10, t_s);
+    t_s = BF_T();
+    bf_rank_emit<8>(kbuf, nxt, kept, n_out, map, lane, emit);
+  } else {
+    scatter(dst);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the wavefront's own stores, read back by its other lanes
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    BF_ADD(10, t_s);
+    t_s = BF_T();
+    bf_rank_emit<4>(static_cast<const uint64_t *>(dst), nxt, kept, n_out, map, lane, emit);
+  }
+  BF_ADD(11, t_s);
+#undef BF_T
+#undef BF_ADD
+  return true;
+}
+
 __host__ __device__ inline uint32_t next_pow2(uint32_t v) {
   uint32_t p = 1;
   while (p < v) p <<= 1;

@@ -404,3 +404,54 @@ def test_xcd_window_plan_on_a_small_base(rq, oracle, m, sub, K, nq):
         rq.set_tuning("SCAN_WINDOW_MB", 0)
         rq.set_tuning("SCAN_XCD_SLACK", -1)
     assert _lib.scan_plan(n, nq, m, m * sub, K)["xcd"] == 0            # 24-48 MB of codes: the ordinary plan
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("n,m,sub,nq,K,slices", [
+    (300_000, 8, 16, 24, 1000, 0),      # the headline shape: ~1.6 K candidates per query, kept keys in LDS
+    (300_000, 8, 16, 24, 1024, 0),      # K = the largest the path takes: kept keys may pass the LDS share
+    (200_000, 16, 6, 16, 100, 0),       # 1024-thread workgroups: one of a query's two wavefronts finishes it
+    (120_000, 8, 4, 40, 7, 3),          # sliced items: packed-key lists for the merge
+    (50_000, 4, 8, 9, 1, 0),
+])
+def test_bucket_finish_equals_select_and_sort(rq, oracle, mode, n, m, sub, nq, K, slices):
+    """K <= 1024 finishes per query through distance buckets (bucket_finish_wave, rq_topk.h): SCAN_BUCKET_FINISH = 1 (default:
+    kept keys staged in LDS), 2 (staged in global memory) and 0 (round 1-4: radix select + LDS bitonic sort) must all be the
+    reference's answer bit for bit (deps/src/linscan_aqd.cpp:91-97: the K smallest (dist, id) pairs, ascending)."""
+    import rayuela_jl_amd.synth as synth
+    rng = np.random.default_rng(n + 7 * K)
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    codes = synth.random_codes(n, m, seed=n + K)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    rq.set_tuning("SCAN_BUCKET_FINISH", mode)
+    rq.set_tuning("SCAN_SLICES", slices)
+    try:
+        d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+    finally:
+        rq.set_tuning("SCAN_BUCKET_FINISH", 1)
+        rq.set_tuning("SCAN_SLICES", 0)
+    assert np.array_equal(i0, i1)
+    assert _eq_bits(d0, d1)
+
+
+@pytest.mark.parametrize("distinct", [1, 3, 40, 400])
+def test_bucket_finish_gives_up_on_mass_ties_and_stays_exact(rq, oracle, distinct):
+    """Rows that share their codes share their distance: `distinct` different rows repeated over the base put hundreds of keys
+    into ONE distance bucket, where counting ranks is quadratic -- the wavefront gives up before writing anything and the group
+    takes the select + sort path; with 400 distinct rows only some queries do.  Ties resolve to the lowest row id either way."""
+    n, m, sub, nq, K = 100_000, 8, 16, 16, 1000
+    rng = np.random.default_rng(distinct)
+    centers = rng.integers(0, 8, (m, 256, sub)).astype(np.float32)
+    queries = rng.integers(0, 8, (nq, m * sub)).astype(np.float32)
+    pool = rng.integers(0, 256, (distinct, m), dtype=np.uint8)
+    codes = np.ascontiguousarray(pool[rng.integers(0, distinct, n)])
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    for mode in (1, 2):
+        rq.set_tuning("SCAN_BUCKET_FINISH", mode)
+        try:
+            d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+        finally:
+            rq.set_tuning("SCAN_BUCKET_FINISH", 1)
+        assert np.array_equal(i0, i1), (distinct, mode)
+        assert _eq_bits(d0, d1)
