@@ -593,7 +593,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
       // large K: select + sort in one sample-sort pass per query, keys stay in global memory
       finish_bigk<Cfg::THREADS>(ctrl->cnt, ctrl->sel, QG, cand_wg, p.bkt + (size_t)blockIdx.x * p.cap, p.cap, (uint32_t)p.K,
                   q0, p.nq, keys_base, key_stride, p.dists, p.ids,
-                  (uint32_t)p.id_base, smem + CTRL_BYTES, p.stats);
+                  (uint32_t)p.id_base, smem + CTRL_BYTES, p.stats, p.bigk != 2);
       RQ_STAT_ADD(5, t_ph);
       continue;
     }
@@ -691,6 +691,7 @@ struct MergeParams {
   const uint64_t *keys_in;  // [nq][P][K]
   uint32_t nq, P;
   int K, id_base;
+  int use_map;              // large K: buckets from the distance map first (SCAN_SS_MAP)
   uint32_t p2;
   float *dists;
   uint32_t *ids;
@@ -766,7 +767,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void merge_topk_big_kernel(MergeParam
       if (od) od[r] = key_dist(key);
       if (oi) oi[r] = key_id(key) + id_base;
     };
-    const uint32_t got = samplesort_topk<SCAN_THREADS>(src, dst, b, cnt, K, smem, emit);
+    const uint32_t got = samplesort_topk<SCAN_THREADS>(src, dst, b, cnt, K, smem, emit, nullptr, p.use_map != 0);
     for (uint32_t i = got + tid; i < K; i += SCAN_THREADS) emit(i, KEY_MAX);   // fewer than K real keys
   }
 }
@@ -1124,7 +1125,7 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.work_counter = work_counter; p.cand = cand;
   p.gtab = reinterpret_cast<float4 *>(reinterpret_cast<char *>(cand) + pl.gtab_off);
   p.bkt = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(cand) + pl.bkt_off);
-  p.bigk = pl.bigk ? 1 : 0;
+  p.bigk = pl.bigk ? (tuning("SCAN_SS_MAP", 1) ? 1 : 2) : 0;      // 2: sorted splitters only (tests, A/B)
   // the bucket finish needs BF_NB words of LDS per query of the group in the (dead) table space
   p.bfin = (!pl.bigk && (size_t)pl.scratch_keys * 8 >= (size_t)8 * (BF_NB * 4 + 64)) ? tuning("SCAN_BUCKET_FINISH", 1) : 0;     // (QG <= 8)
   p.filter = (lut_mode != LUT_LSQ && !row_bias && tuning("SCAN_FILTER", 1)) ? 1 : 0;
@@ -1160,6 +1161,7 @@ int merge_launch(float *dists, uint32_t *ids, uint64_t *keys_out, const uint64_t
   MergeParams p;
   p.keys_in = keys_in; p.nq = (uint32_t)nq; p.P = (uint32_t)P; p.K = K; p.id_base = id_base;
   p.p2 = next_pow2((uint32_t)K);
+  p.use_map = tuning("SCAN_SS_MAP", 1);
   p.dists = dists; p.ids = ids; p.keys_out = keys_out;
   if (P == 1) {
     const size_t total = (size_t)nq * K;

@@ -70,7 +70,7 @@ template <int NT>
 __device__ __noinline__ void finish_bigk(const uint32_t *cnt_q, const uint32_t *sel_q, uint32_t QG, uint64_t *cand_wg,
                                          uint16_t *bkt, uint32_t cap, uint32_t K, uint32_t q0, uint32_t nq,
                                          uint64_t *keys_base, uint32_t key_stride, float *dists, uint32_t *ids,
-                                         uint32_t id_base, unsigned char *lds, unsigned long long *stats) {
+                                         uint32_t id_base, unsigned char *lds, unsigned long long *stats, bool use_map) {
   const uint32_t tid = threadIdx.x;
 #pragma unroll 1
   for (uint32_t q = 0; q < QG; ++q) {
@@ -83,14 +83,14 @@ __device__ __noinline__ void finish_bigk(const uint32_t *cnt_q, const uint32_t *
     if (keys_base) {
       uint64_t *o = keys_base + (size_t)qq * key_stride;
       for (uint32_t i = n_out + tid; i < K; i += NT) o[i] = KEY_MAX;   // short slice
-      samplesort_topk<NT>(src, dst, bkt, cnt, n_out, lds, [o](uint32_t r, uint64_t key) { o[r] = key; }, stats);
+      samplesort_topk<NT>(src, dst, bkt, cnt, n_out, lds, [o](uint32_t r, uint64_t key) { o[r] = key; }, stats, use_map);
     } else {
       float *od = dists + (size_t)qq * K;
       uint32_t *oi = ids + (size_t)qq * K;
       samplesort_topk<NT>(src, dst, bkt, cnt, n_out, lds, [od, oi, id_base](uint32_t r, uint64_t key) {
         od[r] = key_dist(key);
         oi[r] = key_id(key) + id_base;
-      }, stats);
+      }, stats, use_map);
     }
   }
 }

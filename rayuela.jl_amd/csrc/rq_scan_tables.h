@@ -129,7 +129,7 @@ struct ScanParams {
   uint64_t *cand;           // [gridDim][QG][2][cap]
   uint16_t *bkt;            // [gridDim][cap] bucket ids of the large-K sample sort
   int filter;               // 1: 8-bit lower-bound pre-filter in front of the exact evaluation (FILT kernels)
-  int bigk;                 // K > SCAN_SS_MIN_K: finish with samplesort_topk instead of cut + LDS bitonic
+  int bigk;                 // K > SCAN_SS_MIN_K: finish with samplesort_topk instead of cut + LDS bitonic (1: map buckets first, 2: sorted splitters only)
   int bfin;                 // K <= SCAN_SS_MIN_K: cut + sort per query by one wavefront through distance buckets (SCAN_BUCKET_FINISH)
   // outputs of whole items: dists/ids [nq][K], or packed keys [nq][K] when keys != nullptr;
   // of sliced items: part [(query - whole*QG)][nslices][K] packed keys

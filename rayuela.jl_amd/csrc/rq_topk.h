@@ -357,11 +357,17 @@ struct BfMap {
   float inv;          // a little below 1 / range, so that x <= 1
   uint32_t psteps;    // wave-uniform
 };
-__device__ __forceinline__ uint32_t bf_bucket(uint64_t key, const BfMap &m) {
+template <uint32_t NB>
+__device__ __forceinline__ uint32_t bf_bucket_n(uint64_t key, const BfMap &m) {
   float y = (float)((uint32_t)(key >> 32) - m.mn) * m.inv;
 #pragma unroll
   for (uint32_t i = 0; i < 5u; ++i) y = (i < m.psteps) ? y * y : y;
-  return min((uint32_t)(y * ((float)BF_NB - 0.5f)), BF_NB - 1u);        // float -> uint truncates
+  return min((uint32_t)(y * ((float)NB - 0.5f)), NB - 1u);        // float -> uint truncates
+}
+__device__ __forceinline__ uint32_t bf_bucket(uint64_t key, const BfMap &m) { return bf_bucket_n<BF_NB>(key, m); }
+// the warp's exponent from the mean of x (see BfMap): 2^psteps next to p = E / (1 - E)
+__device__ __forceinline__ uint32_t bf_psteps(float ex) {
+  return ex > 0.957f ? 5u : ex > 0.918f ? 4u : ex > 0.85f ? 3u : ex > 0.74f ? 2u : ex > 0.59f ? 1u : 0u;
 }
 
 // step 4 on the kept keys kb[0..kept) (kept >= 1), grouped by bucket (LDS or global); nxt[b] = end of bucket b, nxt[b - 1] its
@@ -446,7 +452,7 @@ __device__ __forceinline__ bool bucket_finish_wave(const uint64_t *__restrict__ 
   {
     // mean of x over the candidates (the padding lanes added (h0 - h0) = 0): E = p / (p + 1) under CDF(x) = x^p
     const float ex = range ? ((float)(int32_t)(h0 - mn) + sum / (float)cnt) / (float)range : 0.5f;
-    map.psteps = ex > 0.957f ? 5u : ex > 0.918f ? 4u : ex > 0.85f ? 3u : ex > 0.74f ? 2u : ex > 0.59f ? 1u : 0u;
+    map.psteps = bf_psteps(ex);
   }
   // ---- 1. histogram -----------------------------------------------------------------------------
 #pragma unroll
@@ -558,8 +564,8 @@ constexpr uint32_t SS_LDS_BYTES = SS_NS * 8 + SS_NS * 4 + 128 + SS_NS * 8;
 template <int NT, class Emit>
 __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_t *dst, uint16_t *bkt, uint32_t cnt,
                                                 uint32_t n_out, unsigned char *lds, Emit emit,
-                                                unsigned long long *stats = nullptr) {
-  // stats (optional): cycles of [9] sample sort, [10] bucket search, [11] scan + scatter (rank = rest)
+                                                unsigned long long *stats = nullptr, bool use_map = true) {
+  // stats (optional): cycles of [9] sample sort (map: range + mean), [10] bucket search (map: histogram), [11] scan + scatter (rank = rest)
 #define SS_T() ((stats && threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull)
 #define SS_ADD(slot, t0) do { if (stats && threadIdx.x == 0) atomicAdd(&stats[slot], (unsigned long long)clock64() - (t0)); } while (0)
   constexpr uint32_t NS = SS_NS;
@@ -589,6 +595,79 @@ __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_
     return n_out;
   }
   unsigned long long t_s = SS_T();
+  // ---- 1m / 2m. Round 5: buckets from a MAP of the distance word instead of sorted splitters ------------------------------
+  // The candidates of one query are the low tail of its distance distribution; x = (distance word - min) / range warped by
+  // x -> x^(2^psteps) (BfMap above: every step monotone in the key, the exponent from the mean of x) fills NS buckets as evenly
+  // as random splitters do in the mean and more evenly in the spread (Poisson, not geometric sizes: sum of squares per key 8.9
+  // against 15 at ~7 keys per bucket) -- without the sample sort and the 11-step search, 13 % of the kernel at k = 10000.
+  // The map only sees the distance: rows that TIE in distance (duplicated codes, integer tables) share a bucket however many
+  // they are, where the splitters -- whole 64-bit keys -- would part them by id.  So a bucket of more than SSM_MAX_BUCKET keys
+  // among those that matter sends the query through the splitter path below; nothing has been written at that point.
+  constexpr uint32_t SSM_MAX_BUCKET = 192;
+  bool mapped = use_map;
+#pragma unroll 1
+  for (;;) {
+  if (mapped) {
+    uint32_t *red = reinterpret_cast<uint32_t *>(smp);       // the splitters' space is free on this path: [16 w] per quantity
+    float *fred = reinterpret_cast<float *>(smp);
+    uint32_t mn = 0xffffffffu, mx = 0u, nreal = 0u;
+    float sum = 0.0f;
+    const uint32_t h0 = (uint32_t)(src[0] >> 32);
+#pragma unroll 1
+    for (uint32_t i0 = tid; i0 < cnt; i0 += NT * 8) {
+      uint64_t k[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) k[u] = src[min(i0 + (uint32_t)u * NT, cnt - 1u)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool real = i0 + (uint32_t)u * NT < cnt && k[u] != KEY_MAX;
+        const uint32_t hw = (uint32_t)(k[u] >> 32);
+        mn = real ? min(mn, hw) : mn;
+        mx = real ? max(mx, hw) : mx;
+        sum += real ? (float)(int32_t)(hw - h0) : 0.0f;
+        nreal += (uint32_t)real;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+      mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+      sum += __shfl_xor(sum, off);
+      nreal += (uint32_t)__shfl_xor((int)nreal, off);
+    }
+    if (lane == 0) { red[wave] = mn; red[16 + wave] = mx; fred[32 + wave] = sum; red[48 + wave] = nreal; }
+    for (uint32_t i = tid; i < NS; i += NT) nxt[i] = 0;
+    __syncthreads();
+    for (uint32_t w = 0; w < (uint32_t)(NT / 64); ++w) {
+      mn = min(mn, red[w]); mx = max(mx, red[16 + w]);
+    }
+    sum = 0.0f; nreal = 0u;
+    for (uint32_t w = 0; w < (uint32_t)(NT / 64); ++w) { sum += fred[32 + w]; nreal += red[48 + w]; }
+    BfMap map;
+    const uint32_t range = mx - mn;
+    map.mn = mn;
+    map.inv = (nreal && range) ? (1.0f / (float)range) * (1.0f - 9.5367431640625e-7f) : 0.0f;
+    map.psteps = (nreal && range) ? bf_psteps(((float)(int32_t)(h0 - mn) + sum / (float)nreal) / (float)range) : 0u;
+    SS_ADD(9, t_s);
+    t_s = SS_T();
+#pragma unroll 1
+    for (uint32_t i0 = tid; i0 < cnt; i0 += NT * 8) {
+      uint64_t k[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) k[u] = src[min(i0 + (uint32_t)u * NT, cnt - 1u)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t idx = i0 + (uint32_t)u * NT;
+        if (idx < cnt) {
+          const bool real = k[u] != KEY_MAX;
+          const uint32_t b = bf_bucket_n<NS>(k[u], map);
+          if (real) atomicAdd(&nxt[b], 1u);
+          bkt[idx] = real ? (uint16_t)b : (uint16_t)0xFFFFu;
+        }
+      }
+    }
+    if (tid == 0) { aux[16] = 0; aux[17] = 0; aux[20] = 0; }       // aux[20]: a bucket that matters is crowded (set in the scan below)
+  } else {
   for (uint32_t i = tid; i < NS; i += NT) {
     if (i < ns) smp[i] = src[(uint32_t)(((uint64_t)i * cnt) >> depth)];
     nxt[i] = 0;
@@ -636,6 +715,7 @@ __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_
       }
     }
   }
+  }  // splitter path
   __syncthreads();
   SS_ADD(10, t_s);
   t_s = SS_T();
@@ -659,30 +739,43 @@ __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_
       const uint32_t end = run + c[j];
       nxt[tid * PER + j] = run;
       if (run < n_out && n_out <= end) { aux[16] = tid * PER + j; aux[17] = end; }
+      if (mapped && run < n_out && c[j] > SSM_MAX_BUCKET) aux[20] = 1u;
       run = end;
     }
     __syncthreads();
   }
-  const uint32_t bstar = aux[16], kept = aux[17];
+  if (mapped && aux[20]) {      // (uniform) distance ties crowd a bucket: partition again, by whole keys
+    mapped = false;
+    __syncthreads();            // everybody has read aux[20] before the splitter path resets aux
+    continue;
+  }
+  break;
+  }  // map, then splitters if the map crowds
+  const uint32_t bstar = aux[16];
 
   // ---- 4. scatter the kept keys; nxt[b] walks from the bucket's start to its end ----------------
+  // (keys and bucket ids are loaded unconditionally, 8 per thread at a time: behind `if (idx < cnt)` every key cost two dependent
+  // L2 round trips -- bucket id, then the key -- with four of them in flight)
 #pragma unroll 1
-  for (uint32_t i0 = 0; i0 < cnt; i0 += NT * 4) {
+  for (uint32_t i0 = tid; i0 < cnt; i0 += NT * 8) {
+    uint64_t k[8];
+    uint32_t b[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t idx = i0 + u * NT + tid;
-      if (idx < cnt) {
-        const uint32_t b = bkt[idx];
-        if (b <= bstar) {
-          const uint32_t pos = atomicAdd(&nxt[b], 1u);
-          dst[pos] = src[idx];
-        }
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t idx = min(i0 + (uint32_t)u * NT, cnt - 1u);
+      k[u] = src[idx];
+      b[u] = bkt[idx];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (i0 + (uint32_t)u * NT < cnt && b[u] <= bstar) {
+        const uint32_t pos = atomicAdd(&nxt[b[u]], 1u);
+        dst[pos] = k[u];
       }
     }
   }
   __syncthreads();
   SS_ADD(11, t_s);
-
   // ---- 5. rank inside the bucket, emit ---------------------------------------------------------
   // One 16-lane DPP row per bucket (buckets average cnt/2048 ~ 8-13 keys): the row loads the
   // bucket 16 keys at a time, one key per lane, and every lane counts the keys below its own by

@@ -455,3 +455,30 @@ def test_bucket_finish_gives_up_on_mass_ties_and_stays_exact(rq, oracle, distinc
             rq.set_tuning("SCAN_BUCKET_FINISH", 1)
         assert np.array_equal(i0, i1), (distinct, mode)
         assert _eq_bits(d0, d1)
+
+
+@pytest.mark.parametrize("distinct", [0, 1, 50, 3000])
+def test_large_k_map_buckets_and_their_splitter_fallback(rq, oracle, distinct):
+    """K > 1024 partitions a query's candidates into buckets by a monotone MAP of the distance word (samplesort_topk, rq_topk.h);
+    rows that tie in distance share a bucket however many they are, and a crowded bucket sends the query back through sorted
+    splitters (whole 64-bit keys, which part ties by id).  distinct = 0: random codes (the map alone); 1 / 50: every candidate
+    ties with hundreds of others (splitters); 3000: a mixture.  Ids and distance bits must equal the reference's either way."""
+    import rayuela_jl_amd.synth as synth
+    n, m, sub, nq, K = 120_000, 8, 16, 16, 3000
+    rng = np.random.default_rng(100 + distinct)
+    centers = rng.integers(0, 8, (m, 256, sub)).astype(np.float32)
+    queries = rng.integers(0, 8, (nq, m * sub)).astype(np.float32)
+    if distinct:
+        pool = rng.integers(0, 256, (distinct, m), dtype=np.uint8)
+        codes = np.ascontiguousarray(pool[rng.integers(0, distinct, n)])
+    else:
+        codes = synth.random_codes(n, m, seed=77)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    for use_map in (1, 0):
+        rq.set_tuning("SCAN_SS_MAP", use_map)
+        try:
+            d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+        finally:
+            rq.set_tuning("SCAN_SS_MAP", 1)
+        assert np.array_equal(i0, i1), (distinct, use_map)
+        assert _eq_bits(d0, d1)
