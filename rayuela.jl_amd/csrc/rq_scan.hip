@@ -602,7 +602,21 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
       // -- no barrier, a fraction of the select + sorting-network work.  A query whose kept keys crowd one bucket (mass ties)
       // gives up before writing anything; then the whole group takes the select + bitonic path below.
       bool gave_up = false;
-      if (gi < 64) {
+      // first a look at 64 candidates of every query: a group with a tie-heavy query (rows sharing their codes) goes straight to
+      // select + sort -- the bucket ranking is quadratic in a tie group, and giving up half-way would waste the group's work
+      {
+        bool heavy = false;
+        if (gi < 64 && q0 + (uint32_t)g < p.nq) {
+          const uint32_t share = (p.scratch_keys / (uint32_t)QG) * 8u & ~7u;
+          uint64_t *tab = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(scratch) + (size_t)g * share);
+          const uint64_t *src = cand_wg + ((size_t)g * 2 + ctrl->sel[g]) * p.cap;
+          const uint32_t twins = share >= 8192u ? bf_tie_twins<10>(src, ctrl->cnt[g], tab, (uint32_t)gi)
+                                                : bf_tie_twins<8>(src, ctrl->cnt[g], tab, (uint32_t)gi);
+          heavy = twins >= BF_TIE_MIN;
+        }
+        gave_up = block_any(heavy, ctrl->st.vote, vseq);
+      }
+      if (!gave_up && gi < 64) {
         const uint32_t cnt = ctrl->cnt[g];
         const uint32_t sel = ctrl->sel[g];
         const uint64_t *src = cand_wg + ((size_t)g * 2 + sel) * p.cap;
@@ -628,6 +642,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
             for (uint32_t i = cnt + (uint32_t)gi; i < (uint32_t)p.K; i += 64u) emit(i, KEY_MAX);
         }
       }
+      // (a group that skipped the attempt votes "gave up" with every thread: uniform either way)
       if (!block_any(gave_up, ctrl->st.vote, vseq)) {
         RQ_STAT_ADD(5, t_ph);
         continue;

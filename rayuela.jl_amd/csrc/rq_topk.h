@@ -345,7 +345,51 @@ __device__ __forceinline__ void bitonic_sort_tiled(uint64_t *a, uint32_t p2, uin
 // order, so no barrier separates the steps); src and dst must not overlap.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t BF_NB = 512;
-constexpr uint32_t BF_MAX_BUCKET = 48;
+#ifndef RQ_BF_MAX_BUCKET
+#define RQ_BF_MAX_BUCKET 48
+#endif
+#ifndef RQ_BF_MAX_S2
+#define RQ_BF_MAX_S2 10
+#endif
+constexpr uint32_t BF_MAX_BUCKET = RQ_BF_MAX_BUCKET;    // a kept bucket larger than this, or ...
+constexpr uint32_t BF_MAX_S2 = RQ_BF_MAX_S2;            // ... sum of squared sizes of the kept buckets > BF_MAX_S2 * kept keys: give up
+
+// Do the candidates of a query tie in distance a lot (rows that share their codes: clustered or duplicated data)?  The bucket
+// paths rank the keys of a bucket against each other, which is quadratic in a tie group; inputs like that belong on the paths that
+// order whole 64-bit keys (radix select + bitonic sort, sorted splitters).  A look at 64 keys: every lane stores {distance word,
+// lane} into a table slot chosen by a hash of the distance word and reads the slot back -- a lane that finds its own distance
+// under ANOTHER lane's number has a twin in the sample.  No atomics, no zeroing (a lane only reads the slot it has just written,
+// so stale contents never count), hash collisions between different distances do not count either.  `tab`: 2^TB_LOG2 8-byte
+// slots of LDS private to the wavefront.  On the bench data (no duplicated code rows) 0-2 of 64 lanes find a twin, on a base
+// drawn from 1024 tight clusters 2-19 (median 7); the callers take >= BF_TIE_MIN as "tie-heavy".
+#ifndef RQ_BF_TIE_MIN
+#define RQ_BF_TIE_MIN 4
+#endif
+constexpr uint32_t BF_TIE_MIN = RQ_BF_TIE_MIN;
+template <uint32_t TB_LOG2, uint32_t PER_LANE = 1>
+__device__ __forceinline__ uint32_t bf_tie_twins(const uint64_t *__restrict__ src, uint32_t cnt, uint64_t *tab, uint32_t lane) {
+  // (volatile: other lanes write the same slot -- the compiler must not forward the lane's own store to its load; LDS
+  // operations of one wavefront complete in order, so every store precedes every load)
+  volatile uint64_t *vt = tab;
+  uint32_t hw[PER_LANE], slot[PER_LANE];
+#pragma unroll
+  for (uint32_t u = 0; u < PER_LANE; ++u) {
+    const uint32_t i = lane + 64u * u;
+    hw[u] = (uint32_t)(src[i < cnt ? i : 0u] >> 32);
+    slot[u] = (hw[u] * 2654435761u) >> (32u - TB_LOG2);
+  }
+#pragma unroll
+  for (uint32_t u = 0; u < PER_LANE; ++u)
+    if (lane + 64u * u < cnt) vt[slot[u]] = ((uint64_t)hw[u] << 32) | (lane + 64u * u);
+  uint32_t twins = 0u;
+#pragma unroll
+  for (uint32_t u = 0; u < PER_LANE; ++u) {
+    const bool on = lane + 64u * u < cnt;
+    const uint64_t got = vt[on ? slot[u] : 0u];
+    twins += (uint32_t)__popcll(__ballot(on && (uint32_t)(got >> 32) == hw[u] && (uint32_t)got != lane + 64u * u));
+  }
+  return twins;
+}
 
 // Bucket of a key: x = (distance word - mn) / range in [0, 1], warped by x -> x^(2^psteps) (psteps squarings), times BF_NB.
 // Every step is monotone in the key (unsigned subtract, int -> float, float multiplications of non-negative values, truncation),
@@ -421,6 +465,9 @@ __device__ __forceinline__ bool bucket_finish_wave(const uint64_t *__restrict__ 
   constexpr uint32_t U = 16;            // keys per lane in flight over the candidate list (L2 round trips are what these passes cost)
   n_out = min(n_out, cnt);
   if (n_out == 0u) return true;
+#pragma unroll
+  for (uint32_t b = lane; b < BF_NB; b += 64u) nxt[b] = 0u;
+  if (lane == 0u) nxt[-1] = 0u;        // "the end of bucket -1": bucket 0 starts at 0 (bf_rank_emit reads it unconditionally)
   // ---- 0. range and mean of the distance words ----------------------------------------------------
   uint32_t mn = 0xffffffffu, mx = 0u;
   const uint32_t h0 = (uint32_t)(src[0] >> 32);
@@ -454,10 +501,7 @@ __device__ __forceinline__ bool bucket_finish_wave(const uint64_t *__restrict__ 
     const float ex = range ? ((float)(int32_t)(h0 - mn) + sum / (float)cnt) / (float)range : 0.5f;
     map.psteps = bf_psteps(ex);
   }
-  // ---- 1. histogram -----------------------------------------------------------------------------
-#pragma unroll
-  for (uint32_t b = lane; b < BF_NB; b += 64u) nxt[b] = 0u;
-  if (lane == 0u) nxt[-1] = 0u;        // "the end of bucket -1": bucket 0 starts at 0 (bf_rank_emit reads it unconditionally)
+  // ---- 1. histogram (the counters were zeroed above) ------------------------------------------------
 #pragma unroll 1
   for (uint32_t i0 = lane; i0 < cnt; i0 += 64u * U) {
     uint64_t k[U];
@@ -475,19 +519,23 @@ __device__ __forceinline__ bool bucket_finish_wave(const uint64_t *__restrict__ 
 #pragma unroll
   for (uint32_t j = 0; j < PER; ++j) { c[j] = nxt[lane * PER + j]; s += c[j]; }
   const uint32_t incl = wave_incl_scan(s, (int)lane);
-  uint32_t run = incl - s, my_bstar = 0xffffffffu, my_kept = 0u;
+  uint32_t run = incl - s, my_bstar = 0xffffffffu, my_kept = 0u, s2 = 0u;
   bool crowded = false;
 #pragma unroll
   for (uint32_t j = 0; j < PER; ++j) {
     const uint32_t end = run + c[j];
     if (run < n_out) {
       crowded |= c[j] > BF_MAX_BUCKET;
+      s2 += c[j] * c[j];
       if (n_out <= end) { my_bstar = lane * PER + j; my_kept = end; }
     }
     nxt[lane * PER + j] = run;          // walks to the bucket's end during the scatter
     run = end;
   }
   if (__ballot(crowded)) return false;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s2 += (uint32_t)__shfl_xor((int)s2, off);
+  if (s2 > BF_MAX_S2 * n_out) return false;      // ranking is a loop over a key's bucket: clumped distances make it the slow path
   const uint64_t owner = __ballot(my_bstar != 0xffffffffu);       // exactly one lane
   const int ol = __ffsll((unsigned long long)owner) - 1;
   const uint32_t bstar = (uint32_t)__builtin_amdgcn_readlane((int)my_bstar, ol);
@@ -604,7 +652,21 @@ __device__ __forceinline__ uint32_t samplesort_topk(const uint64_t *src, uint64_
   // they are, where the splitters -- whole 64-bit keys -- would part them by id.  So a bucket of more than SSM_MAX_BUCKET keys
   // among those that matter sends the query through the splitter path below; nothing has been written at that point.
   constexpr uint32_t SSM_MAX_BUCKET = 192;
+#ifndef RQ_SSM_TIE_MIN
+#define RQ_SSM_TIE_MIN 6
+#endif
+  constexpr uint32_t SSM_TIE_MIN = RQ_SSM_TIE_MIN;      // twins among 256 sampled keys that send the query to the splitters
   bool mapped = use_map;
+  if (mapped) {       // tie-heavy input (a 256-key look, bf_tie_twins): straight to the splitters, which part ties by id
+    if (wave == 0) {
+      // (256 keys: at this K a tie group is a smaller share of the candidates; the splitters' space: 2048 slots)
+      const uint32_t twins = bf_tie_twins<11, 4>(src, cnt, smp, lane);
+      if (lane == 0) aux[21] = twins >= SSM_TIE_MIN ? 1u : 0u;
+    }
+    __syncthreads();
+    mapped = aux[21] == 0u;
+    __syncthreads();          // smp is written again below
+  }
 #pragma unroll 1
   for (;;) {
   if (mapped) {

@@ -23,7 +23,7 @@ class _Tuning:
         defaults = {"SCAN_ORDER": 1, "ORDER_MIN_ROWS": 65536, "ORDER_MIN_NQ": 2048, "ORDER_BITS": 0, "ORDER_GRAN": 0,
                     "ORDER_SHUFFLE": 1, "SCAN_SRANK_MUL": 2, "SCAN_SLACK": 0, "SCAN_SLICES": 0, "SCAN_FILTER": 1,
                     "SCAN_RETUNE_Z": 6, "INDEX_ORDER": 1, "SCAN_XCD_MIN_MB": 0, "SCAN_WINDOW_MB": 0, "ORDER_SAMPLE_STRIDE": 16,
-                    "SCAN_STATS": 0}
+                    "SCAN_STATS": 0, "SCAN_BUCKET_FINISH": 1, "SCAN_SS_MAP": 1}
         for k in self.kv:
             self.rq.set_tuning(k, defaults[k])
 
@@ -223,6 +223,24 @@ def test_clumped_base_does_not_fall_back(rq, oracle):
         sel = np.arange(0, nq, max(1, nq // 32))
         d0, i0 = oracle.linscan_aqd_query(B, np.stack(C), Q[sel], K)
         assert np.array_equal(i1.cpu().numpy().view(np.uint32)[sel], i0) and _eq_bits(d1.cpu().numpy()[sel], d0), nq
+    # Round 5: the finish through distance buckets ranks the keys of a bucket against each other -- quadratic in a group of rows
+    # that TIE in distance, and this base is full of them (rows of a cluster share their codes).  A 64-key look per query
+    # (bf_tie_twins, rq_topk.h) sends such groups to select + sort before any bucket work is done: the bucket finish must not
+    # cost this base more than a few per cent (without the look: 2.19 against 2.00 ms; `tools/finish_ab.py`).
+    def clock(mode, iters=6):
+        with _Tuning(rq, SCAN_BUCKET_FINISH=mode):
+            rqd.linscan(ob, cen, qd, K)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                rqd.linscan(ob, cen, qd, K)
+            e1.record()
+            torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    t_sel = min(clock(0), clock(0))
+    t_bkt = min(clock(1), clock(1))
+    assert t_bkt <= 1.06 * t_sel, (t_bkt, t_sel)
 
 
 def test_tiny_base_of_an_untiled_row_width_through_order_rows(rq, oracle):
