@@ -47,6 +47,72 @@ namespace rq {
 #define RQ_STAT_ADD(slot, t0) do { if (p.stats && threadIdx.x == 0) atomicAdd(&p.stats[slot], (unsigned long long)clock64() - (t0)); } while (0)
 #define RQ_STAT_INC(slot) do { if (p.stats && threadIdx.x == 0) atomicAdd(&p.stats[slot], 1ull); } while (0)
 
+// One work item's bucket finish (K <= 1024): a look at every query's candidates for distance ties, then one wavefront per query
+// through bucket_finish_wave.  Returns whether this thread's query gave up or the group skipped the attempt (the caller votes);
+// nothing has been written for a query that gave up.  `scratch`: the dead table space, split evenly over the QG queries.  Out of
+// line so that the streaming loop's register allocation does not depend on it; LDS pointers are cast back to the LDS address
+// space here (through a generic pointer every access would be a flat instruction).
+struct BucketFinishArgs {      // by value: taking the address of the kernel's ScanParams would move the whole struct to scratch
+  uint32_t cap, scratch_keys, nq, K, id_base;
+  int bfin;
+  float *dists;
+  uint32_t *ids;
+  unsigned long long *stats;
+};
+template <int M>
+__device__ __noinline__ bool bucket_finish_item(ScanCtrl<ScanCfg<M>::QG> *ctrl_g, uint64_t *cand_wg, BucketFinishArgs p,
+                                                uint64_t *scratch_g, int g, int gi, uint32_t q0, uint64_t *keys_base,
+                                                uint32_t key_stride, uint32_t vseq_in, uint32_t *vseq_out) {
+  constexpr int QG = ScanCfg<M>::QG;
+  uint32_t vseq = vseq_in;
+  typedef ScanCtrl<QG> __attribute__((address_space(3))) lds_ctrl_t;
+  typedef unsigned char __attribute__((address_space(3))) lds_byte_t;
+  // (address-space casts: the same addresses, as LDS pointers)
+  ScanCtrl<QG> *ctrl = (ScanCtrl<QG> *)(lds_ctrl_t *)ctrl_g;
+  unsigned char *scratch = (unsigned char *)(lds_byte_t *)reinterpret_cast<unsigned char *>(scratch_g);
+  bool gave_up = false;
+  const uint32_t share = (p.scratch_keys / (uint32_t)QG) * 8u & ~7u;          // bytes of a query's share
+  const bool mine_on = gi < 64 && q0 + (uint32_t)g < p.nq;
+  // first a look at 64 candidates of every query: a group with a tie-heavy query (rows sharing their codes) goes straight to
+  // select + sort -- the bucket ranking is quadratic in a tie group, and giving up half-way would waste the group's work
+  {
+    bool heavy = false;
+    if (mine_on) {
+      uint64_t *tab = reinterpret_cast<uint64_t *>(scratch + (size_t)g * share);
+      const uint64_t *src = cand_wg + ((size_t)g * 2 + ctrl->sel[g]) * p.cap;
+      const uint32_t twins = share >= 8192u ? bf_tie_twins<10>(src, ctrl->cnt[g], tab, (uint32_t)gi)
+                                            : bf_tie_twins<8>(src, ctrl->cnt[g], tab, (uint32_t)gi);
+      heavy = twins >= BF_TIE_MIN;
+    }
+    gave_up = block_any(heavy, ctrl->st.vote, vseq);
+  }
+  if (!gave_up && mine_on) {
+    const uint32_t cnt = ctrl->cnt[g];
+    const uint32_t sel = ctrl->sel[g];
+    const uint64_t *src = cand_wg + ((size_t)g * 2 + sel) * p.cap;
+    uint64_t *dst = cand_wg + ((size_t)g * 2 + (sel ^ 1u)) * p.cap;
+    const uint32_t qq = q0 + (uint32_t)g;
+    // the wavefront's share of the (dead) table space: BF_NB bucket words, then room for the kept keys
+    unsigned char *mine = scratch + (size_t)g * share;
+    uint32_t *nxt = reinterpret_cast<uint32_t *>(mine) + 2;                  // nxt[-1] is part of the share
+    uint64_t *kbuf = reinterpret_cast<uint64_t *>(mine + BF_NB * 4u + 8u);
+    const uint32_t kcap = p.bfin == 2 ? 0u : (share - BF_NB * 4u - 8u) / 8u;     // (SCAN_BUCKET_FINISH=2: tests, kept keys through global memory)
+    uint64_t *ok = keys_base ? keys_base + (size_t)qq * key_stride : nullptr;
+    float *od = p.dists + (size_t)qq * p.K;
+    uint32_t *oi = p.ids + (size_t)qq * p.K;
+    const uint32_t idb = p.id_base;
+    auto emit = [&](uint32_t r, uint64_t key) {
+      if (ok) ok[r] = key;
+      else { od[r] = key_dist(key); oi[r] = key_id(key) + idb; }
+    };
+    gave_up = !bucket_finish_wave(src, dst, cnt, (uint32_t)p.K, nxt, kbuf, kcap, (uint32_t)gi, emit, p.stats);
+    if (!gave_up)      // fewer candidates than K (slices shorter than K): the tail is padding, as the LDS sort leaves it
+      for (uint32_t i = cnt + (uint32_t)gi; i < (uint32_t)p.K; i += 64u) emit(i, KEY_MAX);
+  }
+  *vseq_out = vseq;
+  return gave_up;
+}
+
 template <int M, bool BIAS, bool FILT, bool FINE = false>
 __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanParams p) {
   using Cfg = ScanCfg<M>;
@@ -598,50 +664,15 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
       continue;
     }
     if (p.bfin) {
-      // Round 5: one wavefront per query cuts and sorts its candidates through distance buckets (bucket_finish_wave, rq_topk.h)
-      // -- no barrier, a fraction of the select + sorting-network work.  A query whose kept keys crowd one bucket (mass ties)
-      // gives up before writing anything; then the whole group takes the select + bitonic path below.
-      bool gave_up = false;
-      // first a look at 64 candidates of every query: a group with a tie-heavy query (rows sharing their codes) goes straight to
-      // select + sort -- the bucket ranking is quadratic in a tie group, and giving up half-way would waste the group's work
-      {
-        bool heavy = false;
-        if (gi < 64 && q0 + (uint32_t)g < p.nq) {
-          const uint32_t share = (p.scratch_keys / (uint32_t)QG) * 8u & ~7u;
-          uint64_t *tab = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(scratch) + (size_t)g * share);
-          const uint64_t *src = cand_wg + ((size_t)g * 2 + ctrl->sel[g]) * p.cap;
-          const uint32_t twins = share >= 8192u ? bf_tie_twins<10>(src, ctrl->cnt[g], tab, (uint32_t)gi)
-                                                : bf_tie_twins<8>(src, ctrl->cnt[g], tab, (uint32_t)gi);
-          heavy = twins >= BF_TIE_MIN;
-        }
-        gave_up = block_any(heavy, ctrl->st.vote, vseq);
-      }
-      if (!gave_up && gi < 64) {
-        const uint32_t cnt = ctrl->cnt[g];
-        const uint32_t sel = ctrl->sel[g];
-        const uint64_t *src = cand_wg + ((size_t)g * 2 + sel) * p.cap;
-        uint64_t *dst = cand_wg + ((size_t)g * 2 + (sel ^ 1u)) * p.cap;
-        const uint32_t qq = q0 + (uint32_t)g;
-        if (qq < p.nq) {
-          // the wavefront's share of the (dead) table space: BF_NB bucket words, then room for the kept keys
-          const uint32_t share = (p.scratch_keys / (uint32_t)QG) * 8u & ~7u;          // bytes
-          unsigned char *mine = reinterpret_cast<unsigned char *>(scratch) + (size_t)g * share;
-          uint32_t *nxt = reinterpret_cast<uint32_t *>(mine) + 2;                  // nxt[-1] is part of the share
-          uint64_t *kbuf = reinterpret_cast<uint64_t *>(mine + BF_NB * 4u + 8u);
-          const uint32_t kcap = p.bfin == 2 ? 0u : (share - BF_NB * 4u - 8u) / 8u;     // (SCAN_BUCKET_FINISH=2: tests, kept keys through global memory)
-          uint64_t *ok = keys_base ? keys_base + (size_t)qq * key_stride : nullptr;
-          float *od = p.dists + (size_t)qq * p.K;
-          uint32_t *oi = p.ids + (size_t)qq * p.K;
-          const uint32_t idb = (uint32_t)p.id_base;
-          auto emit = [&](uint32_t r, uint64_t key) {
-            if (ok) ok[r] = key;
-            else { od[r] = key_dist(key); oi[r] = key_id(key) + idb; }
-          };
-          gave_up = !bucket_finish_wave(src, dst, cnt, (uint32_t)p.K, nxt, kbuf, kcap, (uint32_t)gi, emit, p.stats);
-          if (!gave_up)      // fewer candidates than K (slices shorter than K): the tail is padding, as the LDS sort leaves it
-            for (uint32_t i = cnt + (uint32_t)gi; i < (uint32_t)p.K; i += 64u) emit(i, KEY_MAX);
-        }
-      }
+      // Round 5: one wavefront per query cuts and sorts its candidates through distance buckets (bucket_finish_item above,
+      // bucket_finish_wave in rq_topk.h) -- no barrier inside, a fraction of the select + sorting-network work.  Out of line: with
+      // the attempt inlined the streaming loop's register allocation changed (k = 1 +2 %, the 1.25e8-row shard +8 %).
+      BucketFinishArgs fa;
+      fa.cap = p.cap; fa.scratch_keys = p.scratch_keys; fa.nq = p.nq; fa.K = (uint32_t)p.K; fa.id_base = (uint32_t)p.id_base;
+      fa.bfin = p.bfin; fa.dists = p.dists; fa.ids = p.ids; fa.stats = p.stats;
+      uint32_t vseq_new = vseq;
+      const bool gave_up = bucket_finish_item<M>(ctrl, cand_wg, fa, scratch, g, gi, q0, keys_base, key_stride, vseq, &vseq_new);
+      vseq = vseq_new;
       // (a group that skipped the attempt votes "gave up" with every thread: uniform either way)
       if (!block_any(gave_up, ctrl->st.vote, vseq)) {
         RQ_STAT_ADD(5, t_ph);
