@@ -341,13 +341,15 @@ void rq_host_free(void *p);
  *   SCAN_SLICES  force the number of row slices per shard (0 = automatic)
  *   ENC_WAVES    wavefronts per encode workgroup (8 or 16)
  *   SCAN_FILTER / SCAN_FILTER_LSQ  0 switches the integer pre-filter of the PQ/CQ / LSQ scans off (same results)
+ *   SCAN_BUCKET_FINISH / SCAN_SS_MAP  0 switches the bucket finish of K <= 1024 / the map buckets of K > 1024 off (same results)
  *   others (SCAN_SAMPLE, SCAN_SRANK_MUL, SCAN_SLACK, SCAN_SS_MIN_K, SCAN_TAIL_SLICES, SCAN_MIN_ROWS, ENC_DIRECT,
  *   ROT_V2, HOST_OVERLAP, SCAN_STATS) are experiment switches documented where they are read */
 int rq_set_tuning(const char *key, int value);
 /* Diagnostics: with tuning SCAN_STATS=1, summed shader-clock cycles (thread 0 of every workgroup) of the
  * last scan: [0] LUT build [1] threshold sample [2] streaming [3] in-stream cuts [4] final cut [5] sort+write,
  * [6] number of in-stream cuts, [7] number of exact fallbacks, [8] the row part of [1], [9..11] sort load / stages /
- * write-out, [12] work items, [13] items that kept the integer pre-filter to their end, [14] rows the pre-filter let
+ * write-out (bucket finish: range + histogram / scan + scatter / rank + write; large K: sample sort or range / bucket search
+ * or histogram / scan + scatter), [12] work items, [13] items that kept the integer pre-filter to their end, [14] rows the pre-filter let
  * through in the items' first blocks, [15] rows of those blocks; out has 16 slots. */
 int rq_scan_stats(unsigned long long *out16);
 

@@ -332,12 +332,14 @@ __device__ __forceinline__ void bitonic_sort_tiled(uint64_t *a, uint32_t p2, uin
 // The cut to K (radix select: up to 8 passes over the candidates, each behind workgroup barriers) and the LDS bitonic sort
 // (55 stages at 1024 keys) were 13 % of the headline scan, and all of it exposed (skipping both: 2.01 -> 1.76 ms).  A sorting
 // network does O(log^2 n) work per key; the keys of one query, however, are distances from a narrow range [d_min, tau], so a
-// LINEAR map of the distance word onto BF_NB buckets spreads them a few per bucket (the density grows towards tau, the last
-// buckets hold ~4x the average).  Per query:
-//   0. min / max of the distance words;  1. histogram (one LDS atomic per key);  2. exclusive scan: bucket starts, and the
-//   bucket b* that holds rank n_out - 1 -- later buckets are dropped, which IS the cut;  3. kept keys scattered to their
-//   bucket's range of `dst` (the query's other candidate buffer, L2-resident);  4. every kept key counts the keys of its
-//   bucket below it (keys are unique: ranks are a permutation) and is emitted at start[b] + rank if that is < n_out.
+// MONOTONE map of the distance word onto BF_NB buckets (linear, then warped by a power: BfMap below) spreads them a few per
+// bucket.  Per query:
+//   0. min / max / mean of the distance words;  1. histogram (one LDS atomic per key);  2. exclusive scan: bucket starts, and
+//   the bucket b* that holds rank n_out - 1 -- later buckets are dropped, which IS the cut;  3. kept keys scattered to their
+//   bucket's range of `kbuf` (LDS; or `dst`, the query's other candidate buffer in L2, when they do not fit);  4. every kept
+//   key counts the keys of its bucket below it (keys are unique: ranks are a permutation) and is emitted at start[b] + rank if
+//   that is < n_out.  (The candidates held in registers across steps 0, 1, 3 -- 32 per lane, one read instead of three -- made
+//   the compiler spill 392 registers in the CALLING kernel: 14.8 ms instead of 1.48.  Three streamed passes it is.)
 // Exact for any input: the map is monotone in the key, so bucket order is key order, and inside a bucket the count decides.
 // Ties in the distance (integer-valued tables, duplicated rows) land in one bucket and step 4 is O(bucket^2): a bucket of
 // more than BF_MAX_BUCKET kept keys makes the routine give up BEFORE anything is written (false), and the caller runs the
