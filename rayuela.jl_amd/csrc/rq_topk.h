@@ -353,6 +353,7 @@ constexpr uint32_t BF_NB = 512;
 #ifndef RQ_BF_MAX_S2
 #define RQ_BF_MAX_S2 10
 #endif
+constexpr uint32_t BF_MAX_CNT = 4u * BF_NB;              // candidates of a query the bucket finish is tried on (4 per bucket on average)
 constexpr uint32_t BF_MAX_BUCKET = RQ_BF_MAX_BUCKET;    // a kept bucket larger than this, or ...
 constexpr uint32_t BF_MAX_S2 = RQ_BF_MAX_S2;            // ... sum of squared sizes of the kept buckets > BF_MAX_S2 * kept keys: give up
 
@@ -411,9 +412,12 @@ __device__ __forceinline__ uint32_t bf_bucket_n(uint64_t key, const BfMap &m) {
   return min((uint32_t)(y * ((float)NB - 0.5f)), NB - 1u);        // float -> uint truncates
 }
 __device__ __forceinline__ uint32_t bf_bucket(uint64_t key, const BfMap &m) { return bf_bucket_n<BF_NB>(key, m); }
-// the warp's exponent from the mean of x (see BfMap): 2^psteps next to p = E / (1 - E)
+// the warp's exponent from the mean of x (see BfMap): the power of two BELOW p = E / (1 - E) -- E >= 2/3, 4/5, 8/9, 16/17, 32/33.
+// Rounding down, not to the nearest: too small an exponent leaves the top buckets a few times the average, too large a one
+// folds the sparse low end of the range into bucket 0 -- and real tails are heavier there than the power law (sum of Gaussian
+// tables: nearest put 54-72 keys into one bucket where the floor leaves 11; bench data: largest bucket 41 -> 23).
 __device__ __forceinline__ uint32_t bf_psteps(float ex) {
-  return ex > 0.957f ? 5u : ex > 0.918f ? 4u : ex > 0.85f ? 3u : ex > 0.74f ? 2u : ex > 0.59f ? 1u : 0u;
+  return ex >= 0.9697f ? 5u : ex >= 0.9412f ? 4u : ex >= 0.8889f ? 3u : ex >= 0.8f ? 2u : ex >= 0.6667f ? 1u : 0u;
 }
 
 // step 4 on the kept keys kb[0..kept) (kept >= 1), grouped by bucket (LDS or global); nxt[b] = end of bucket b, nxt[b - 1] its
