@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""K > 1024 finish A/B on random tables: buckets from the distance map (SCAN_SS_MAP = 1) against sorted splitters (0), alternating.
+usage: python tools/bigk_ab.py"""
 import sys, os, torch
 sys.path.insert(0, os.getcwd())
 import rayuela_jl_amd as rq

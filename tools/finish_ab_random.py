@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Round-5 finish A/B on random tables (random codes, Gaussian codebooks and queries): SCAN_BUCKET_FINISH = 1 / 0 alternating, with the
+phase clock of the first call; shapes where the bucket finish first LOST (one item per workgroup, short slices).  usage: python tools/finish_ab_random.py"""
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.getcwd())
 import rayuela_jl_amd as rq

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""ms per resident linscan call over 80 shapes (m = 4 ... 32, 8 ... 4096 queries, k = 10 ... 4096; random tables).  Run it twice on one box,
+once with RAYUELA_HIP_LIB pointing at another build, to compare builds (profiles/r5_shape_sweep.md).  usage: python tools/sweep_shapes.py"""
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.getcwd())
 import rayuela_jl_amd as rq
