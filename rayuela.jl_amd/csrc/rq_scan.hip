@@ -1175,7 +1175,9 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   p.bkt = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(cand) + pl.bkt_off);
   p.bigk = pl.bigk ? (tuning("SCAN_SS_MAP", 1) ? 1 : 2) : 0;      // 2: sorted splitters only (tests, A/B)
   // the bucket finish needs BF_NB words of LDS per query of the group in the (dead) table space
-  p.bfin = (!pl.bigk && (size_t)pl.scratch_keys * 8 >= (size_t)8 * (BF_NB * 4 + 64)) ? tuning("SCAN_BUCKET_FINISH", 1) : 0;     // (QG <= 8)
+  // (below k = 16 a query holds a few dozen candidates: select + sort of those costs 2.4 % of a k = 1 scan, the bucket finish's fixed
+  // work -- counters, the look, two votes -- 4.0 %)
+  p.bfin = (!pl.bigk && K >= 16 && (size_t)pl.scratch_keys * 8 >= (size_t)8 * (BF_NB * 4 + 64)) ? tuning("SCAN_BUCKET_FINISH", 1) : 0;     // (QG <= 8)
   p.filter = (lut_mode != LUT_LSQ && !row_bias && tuning("SCAN_FILTER", 1)) ? 1 : 0;
   p.norm_bytes = nullptr; p.norm_info = nullptr; p.cnorm = nullptr;
   if (lut_mode == LUT_LSQ && row_bias && norm_buf && (m == 8 || m == 16) && tuning("SCAN_FILTER", 1) &&
