@@ -115,33 +115,33 @@ def lib_build():
 
 
 def load_traffic(kernel_key):
-    """HBM/fabric bytes per launch of `kernel_key` from THIS round's committed PMC passes (profiles/r5_traffic.json: rocprofv3
+    """HBM/fabric bytes per launch of `kernel_key` from THIS round's committed PMC passes (profiles/r6_traffic.json: rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE, separate runs; FETCH doubled per MI355X_MICROARCH.md section HBM).  The figure is a REPLAY
     of a profiled run, so it is bound to what it was measured on: the entry names the kernel instantiation (as rocprofv3 and
     rq_last_scan_kernel() spell it) and the library build id (rq_version()); if either differs from what just ran, traffic
     is null and the reason is reported instead."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r5_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r6_traffic.json")))
     except Exception:
-        return None, "no profiles/r5_traffic.json"
+        return None, "no profiles/r6_traffic.json"
     e = tj.get(kernel_key)
     if e is None:
-        return None, "profiles/r5_traffic.json has no entry for this shape"
+        return None, "profiles/r6_traffic.json has no entry for this shape"
     from rayuela_jl_amd import _lib
     ran = (_lib.lib().rq_last_scan_kernel() or b"").decode()
     build = lib_build()
     if e.get("build") != build or e.get("kernel") != ran:
-        return None, ("not replayed: profiles/r5_traffic.json was measured on %s of build %s, this run launched %s of build %s"
+        return None, ("not replayed: profiles/r6_traffic.json was measured on %s of build %s, this run launched %s of build %s"
                       % (e.get("kernel"), e.get("build"), ran, build))
     return (2.0 * e["FETCH_SIZE_KiB"] * 1024 + e["WRITE_SIZE_KiB"] * 1024,
-            "profiles/r5_traffic.json (%s; kernel %s, build %s: the ones this run used)" % (e.get("source", ""), ran, build))
+            "profiles/r6_traffic.json (%s; kernel %s, build %s: the ones this run used)" % (e.get("source", ""), ran, build))
 
 
 def load_encode_counters(kernel, sub):
-    """per-launch instruction counters of the encode kernels from this round's PMC passes (profiles/r5_encode_counters.json), bound
+    """per-launch instruction counters of the encode kernels from this round's PMC passes (profiles/r6_encode_counters.json), bound
     to the library build like the traffic figures; None when they do not describe the library that just ran"""
     try:
-        ej = json.load(open(os.path.join(ROOT, "profiles", "r5_encode_counters.json")))
+        ej = json.load(open(os.path.join(ROOT, "profiles", "r6_encode_counters.json")))
     except Exception:
         return None
     e = ej.get("%s sub=%d" % (kernel, sub))
@@ -154,11 +154,12 @@ def scan_roofline(m, n_local, nq, K, kernel_ms):
     Algorithmic bytes per launch = nq * n * m (one table entry looked up per code byte per query).
     Since round 2 the hot loop looks a ONE-byte lower bound up for (almost) every (query, row, sub-quantizer) --
     8 queries per ds_read_b64 gather -- so nq*n*m is also the number of table bytes the LDS has to deliver, and
-    the roof is the conflict-free LDS rate, 256 CU x 256 B/clk x 2.4 GHz.  `frac` is what bank conflicts (~60 %
-    of the LDS cycles, profiles/), the exact re-evaluation of surviving rows and the top-k finish leave of it.
+    the roof is the conflict-free LDS rate, 256 CU x 256 B/clk x 2.4 GHz.  `frac` is what is left of it by bank conflicts
+    (47 % of the LDS cycles on the ordered 1e6-row base; 63 % in arrival order), by VALU issue that does not overlap the
+    LDS pipe (66 % / 63 % busy), by the exact re-evaluation of surviving rows and by the top-k finish (profiles/).
     `f32_table_roof` keeps round 1's yardstick (4-byte entries, 4 queries per ds_read_b128) for continuity.
     HBM: the same nq*n*m code bytes are shared by the 8 queries of a group and mostly served by L2/MALL, so
-    the PMC traffic is what reaches HBM."""
+    the PMC traffic is what reaches the fabric."""
     t = kernel_ms * 1e-3
     code_bytes = float(nq) * n_local * m
     achieved = code_bytes / t / 1e9
@@ -461,6 +462,7 @@ def main():
     # bank-aware row order ONCE here (rq_dev_order_rows: what an index handle does at load time), so the launches below are
     # the scan kernel and nothing else -- the same kernel on the same ordered rows as inside the headline call.
     kern_ms = None
+    kern_base = None
     order_info = None
     if not a.inproc:
         kl = min(K, n_local)
@@ -471,7 +473,14 @@ def main():
         elif world > 1 and ix.ordered is not None:
             ordered = ix.ordered
         else:
-            ordered = rqd.order_rows(codes) if os.environ.get("RQ_SCAN_ORDER", "1") != "0" else codes
+            # the kind of base the timed call scans: a raw-pointer call orders its scratch copy only when that pays (from 2048
+            # queries, below k = 8192: rq_scan_orders_in_call) -- at the reference's default k = 10000 it scans the rows as they
+            # arrive, and so does this leg (round 5 timed an ordered base there: kernel_ms > ms_per_step)
+            from rayuela_jl_amd import _lib as _lo
+            in_call = bool(_lo.lib().rq_scan_orders_in_call(n_local, nq, kl))
+            ordered = rqd.order_rows(codes) if in_call and os.environ.get("RQ_SCAN_ORDER", "1") != "0" else codes
+        kern_base = ("bank-aware row order (what the timed call scans: ordered inside the call, or once by the index)"
+                     if ordered is not codes else "arrival order (what the timed call scans at this shape: no in-call ordering)")
         kern_total, _ = timed(lambda: rqd.linscan(ordered, centers, Qs, kl, id_offset=r0, want_keys=True, out=kout), ks, 1, barrier)
         kern_ms = kern_total / ks
         if world == 1 and not big and ordered is not codes and not a.no_ab:
@@ -518,6 +527,8 @@ def main():
 
     # ---- roofline --------------------------------------------------------------------------------------------------
     roof = scan_roofline(m, n_local, nq, min(K, n_local), kern_ms_max) if kern_ms is not None else None
+    if roof is not None:
+        roof["kernel_base"] = kern_base
     encode = None
     if enc_ms is not None:
         enc_ms_step = enc_ms_max / a.steps
@@ -538,7 +549,7 @@ def main():
             # centroids x 32 vectors); pairs the filter cannot settle (2-3 %) get the canonical f32 evaluation in a second
             # launch.  What binds is instruction ISSUE on the SIMDs: a 32 x 32 x 16 bf16 MFMA holds the matrix pipe 32 cycles,
             # a wave64 VALU instruction its SIMD ~4, and in this kernel the two do not overlap (PMC: VALU-busy + MFMA-busy =
-            # the kernel's cycles, profiles/r5_pmc_counters.md).  frac = those issue cycles / (SIMDs x clock x time) -- a
+            # the kernel's cycles, profiles/r6_pmc_counters.md).  frac = those issue cycles / (SIMDs x clock x time) -- a
             # fraction of a real roof, never above 1; the SURVEY 8(d) yardsticks ride along.
             nmf = 2 if sub_w <= 8 else 3
             n_mfma = nmf * ((h + 31) // 32) * m * ((n_local + 31) // 32)        # wave-level MFMA instructions per launch
@@ -547,27 +558,40 @@ def main():
             f32eq = {"achieved_TFLOPs": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "frac": round(tf / FP32_PEAK_TFLOPS, 4),
                      "note": "SURVEY 8(d)'s yardstick (2*d*h flop per vector vs the f32 matrix peak); the products do not run at the "
                              "f32 rate, so this may pass 1 and is not a fraction of a roof"}
-            enc_roof = {"bound": "simd-issue", "kernel": enc_kernel, "unit": "issue cycles/s", "traffic": None,
-                        "peak": NUM_CU * 4 * CLK_GHZ * 1e9,
-                        "definition": "(VALU wave-instructions x 4 + MFMA instructions x 32 cycles) per second vs 4 SIMDs x %d CUs x "
-                                      "%.1f GHz; instruction counts per launch from profiles/r5_encode_counters.json (PMC "
-                                      "SQ_INSTS_VALU / SQ_INSTS_MFMA of the same library build), scaled to this run's rows" % (NUM_CU, CLK_GHZ),
-                        "bf16_mfma": {"issued_TFLOPs": round(bf_flops / t_enc / 1e12, 1), "peak": 2500.0,
-                                      "frac": round(bf_flops / t_enc / 1e12 / 2500.0, 4)},
-                        "hbm": {"algorithmic_GBps": round((4.0 * d + m) * n_local / t_enc / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
-                                "frac": round((4.0 * d + m) * n_local / t_enc / 1e9 / HBM_PEAK_GBS, 4)},
-                        "f32_equivalent": f32eq}
+            # The line LEADS with the hardware roof the kernel is closest to -- the bf16 matrix pipe (work issued / 2.5 PF dense) or
+            # HBM (algorithmic bytes / 8 TB/s), whichever fraction is larger -- and carries the issue-slot accounting (which says
+            # WHY it is not closer: VALU + MFMA issue fill the SIMDs without overlapping) as `simd_issue`.
+            bf_tf = bf_flops / t_enc / 1e12
+            hbm_gbs = (4.0 * d + m) * n_local / t_enc / 1e9
+            bf16 = {"issued_TFLOPs": round(bf_tf, 1), "peak": 2500.0, "frac": round(bf_tf / 2500.0, 4)}
+            hbm_e = {"algorithmic_GBps": round(hbm_gbs, 1), "peak_GBps": HBM_PEAK_GBS, "frac": round(hbm_gbs / HBM_PEAK_GBS, 4)}
+            if bf16["frac"] >= hbm_e["frac"]:
+                enc_roof = {"bound": "mfma", "kernel": enc_kernel, "achieved": bf16["issued_TFLOPs"], "peak": 2500.0, "unit": "TFLOP/s",
+                            "frac": bf16["frac"], "traffic": None,
+                            "definition": "bf16 matrix-core work the filter issues (%d x v_mfma_f32_32x32x16_bf16 per 32 centroids x 32 "
+                                          "vectors) per second vs the dense bf16 peak" % nmf}
+            else:
+                enc_roof = {"bound": "hbm", "kernel": enc_kernel, "achieved": hbm_e["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": hbm_e["frac"], "traffic": None,
+                            "definition": "algorithmic bytes (4 d + m per vector: X read once, codes written) per second vs HBM peak"}
+            enc_roof.update({"bf16_mfma": bf16, "hbm": hbm_e, "f32_equivalent": f32eq})
+            issue_peak = NUM_CU * 4 * CLK_GHZ * 1e9
+            simd = {"unit": "issue cycles/s", "peak": issue_peak,
+                    "definition": "(VALU wave-instructions x 4 + MFMA instructions x 32 cycles) per second vs 4 SIMDs x %d CUs x %.1f GHz; "
+                                  "instruction counts per launch from profiles/r6_encode_counters.json (PMC SQ_INSTS_VALU / SQ_INSTS_MFMA "
+                                  "of the same library build), scaled to this run's rows.  Not a distance to a hardware roof: it says "
+                                  "the SIMDs' issue slots are this full, i.e. the kernel is instruction-bound" % (NUM_CU, CLK_GHZ)}
             if cnt is not None:
                 scale = float(n_local) / cnt["rows"]
                 valu = (cnt["SQ_INSTS_VALU"] - cnt["SQ_INSTS_MFMA"]) * scale
                 issue = (valu * 4.0 + cnt["SQ_INSTS_MFMA"] * scale * 32.0) / t_enc
-                enc_roof.update({"achieved": round(issue, 1), "frac": round(issue / enc_roof["peak"], 4),
-                                 "valu_insts_per_launch": round(valu), "mfma_insts_per_launch": round(cnt["SQ_INSTS_MFMA"] * scale),
-                                 "launches": cnt.get("launches", "tables + filter + exact pass")})
+                simd.update({"achieved": round(issue, 1), "frac": round(issue / issue_peak, 4),
+                             "valu_insts_per_launch": round(valu), "mfma_insts_per_launch": round(cnt["SQ_INSTS_MFMA"] * scale),
+                             "launches": cnt.get("launches", "tables + filter + exact pass")})
             else:
-                enc_roof.update({"achieved": None, "frac": round(bf_flops / t_enc / 1e12 / 2500.0, 4),
-                                 "note": "no instruction counters for this library build in profiles/: frac falls back to the bf16 "
-                                         "matrix-core fraction"})
+                simd.update({"achieved": None, "frac": None,
+                             "note": "no instruction counters for this library build in profiles/"})
+            enc_roof["simd_issue"] = simd
         if use_R:
             enc_roof["note"] = (enc_roof.get("note", "") + "; time includes the R'X rotation kernel (2*d*d f32-MFMA flop per vector more, "
                                 "not counted in achieved)").lstrip("; ")

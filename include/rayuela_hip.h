@@ -125,6 +125,18 @@ int rq_dev_encode_rvq(uint8_t *codes, float *Xr, const float *codebooks, int64_t
  * 16-byte tilings only; m = 32 / 64 run the exact f32 loop (m = 32: 24.6 ms at that size) -- same answers, not tuned. */
 int rq_linscan_pq(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers,
                   const float *queries, int64_t n, int64_t nq, int m, int d, int k, int id_base);
+/* Non-finite inputs (every scan entry point; tests/test_gpu_nonfinite.py).  The reference builds its table and its distances in
+ * plain f32 (deps/src/linscan_aqd.cpp:66-87) and hands the pairs to std::partial_sort (:91-97): +Inf is an ordinary value there
+ * (ties part by id), while a NaN breaks the pair comparison's strict weak order -- the reference's answer for such a query is
+ * unspecified.  Here:
+ *   - the call always returns: no threshold, redo, barrier or pacing path waits on a poisoned query;
+ *   - +Inf / -Inf in a query or a codebook behave as in the reference, bit for bit (a query with an infinite coordinate has
+ *     distance +Inf to every row and gets the k smallest ids);
+ *   - a row whose distance to a query is NaN is never a neighbour of that query (NaN compares false with every threshold).  The
+ *     rows with comparable distances are returned exactly, in (dist, id) order; a list that runs out of them ends in the padding
+ *     pair (dist = NaN, id = 0xFFFFFFFF + id_base, i.e. 0 on the one-based Julia side: "no row");
+ *   - the other queries of the same 8-query group and of the same launch are unaffected, bit for bit (a group that holds a
+ *     NaN query takes the exact, un-sampled path: slower, same answer).  No status is raised: the poisoned rows are data. */
 /* linscan_opq (src/Linscan.jl:93-103): queries are rotated by R' on the device first. */
 int rq_linscan_opq(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers,
                    const float *queries, const float *R, int64_t n, int64_t nq, int m, int d,
@@ -345,6 +357,12 @@ void rq_host_free(void *p);
  *   others (SCAN_SAMPLE, SCAN_SRANK_MUL, SCAN_SLACK, SCAN_SS_MIN_K, SCAN_TAIL_SLICES, SCAN_MIN_ROWS, ENC_DIRECT,
  *   ROT_V2, HOST_OVERLAP, SCAN_STATS) are experiment switches documented where they are read */
 int rq_set_tuning(const char *key, int value);
+/* Diagnostics (pure host code): 1 if a raw-pointer PQ scan of n rows (m = 8 wide), nq queries and k neighbours puts a scratch copy
+ * of the base into bank-aware row order inside the call (csrc/rq_order.hip: from ORDER_MIN_NQ queries on, below ORDER_MAX_K
+ * neighbours, ORDER_MIN_ROWS rows up), 0 if it scans the rows as they arrive.  bench.py times the scan kernel alone on the kind of
+ * base the timed call really scans (at k = 10000 the call scans the arrival order). */
+int rq_scan_orders_in_call(int64_t n, int64_t nq, int k);
+
 /* Diagnostics: with tuning SCAN_STATS=1, summed shader-clock cycles (thread 0 of every workgroup) of the
  * last scan: [0] LUT build [1] threshold sample [2] streaming [3] in-stream cuts [4] final cut [5] sort+write,
  * [6] number of in-stream cuts, [7] number of exact fallbacks, [8] the row part of [1], [9..11] sort load / stages /
@@ -352,6 +370,10 @@ int rq_set_tuning(const char *key, int value);
  * or histogram / scan + scatter), [12] work items, [13] items that kept the integer pre-filter to their end, [14] rows the pre-filter let
  * through in the items' first blocks, [15] rows of those blocks; out has 16 slots. */
 int rq_scan_stats(unsigned long long *out16);
+/* ... and the finish of that launch (K <= 1024, distance-bucket finish): [0] work items that reached the bucket finish, [1] items
+ * the tie look (bf_tie_twins) sent to select + sort before any bucket work, [2] items that took select + sort in the end
+ * ([2] - [1] gave up after their histogram); [3..7] reserved (0).  Counts, not clocks: what tests assert on. */
+int rq_scan_finish_stats(unsigned long long *out8);
 
 /* Diagnostics (pure host code, no device needed): the scan planner's decision for a shard of n rows, nq queries,
  * m sub-quantizers, dimension d, k neighbours on a device with num_cu compute units.  out[0] queries per group,

@@ -91,6 +91,8 @@ SIGNATURES = {
     "rq_index_destroy": (None, [_vp]),
     "rq_set_tuning": (_i32, [C.c_char_p, _i32]),
     "rq_scan_stats": (_i32, [_vp]),
+    "rq_scan_orders_in_call": (_i32, [_i64, _i64, _i32]),
+    "rq_scan_finish_stats": (_i32, [_vp]),
     "rq_scan_plan": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "rq_last_timing": (_i32, [_vp, _vp, _vp, _vp]),
 }
@@ -146,7 +148,11 @@ def scan_stats():
     out = (C.c_uint64 * 16)()
     check(lib().rq_scan_stats(C.cast(out, C.c_void_p)))
     names = ["lut", "sample", "stream", "cuts", "final_cut", "sort_write", "n_cuts", "n_fallbacks", "sample_rows", "sort_load", "sort_stages", "sort_out", "n_items", "n_items_filtered", "first_block_pushed", "first_block_rows"]
-    return dict(zip(names, [int(x) for x in out]))
+    st = dict(zip(names, [int(x) for x in out]))
+    fin = (C.c_uint64 * 8)()
+    check(lib().rq_scan_finish_stats(C.cast(fin, C.c_void_p)))
+    st.update(zip(["bf_items", "bf_look_skips", "bf_select_sort"], [int(x) for x in fin[:3]]))
+    return st
 
 
 class _PinnedBlock:

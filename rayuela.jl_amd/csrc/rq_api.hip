@@ -39,6 +39,11 @@ int fail_hip(hipError_t e, const char *what, const char *file, int line) {
   return (int)e > 0 ? (int)e : 1;
 }
 
+void forgive_oom() {
+  g_err[0] = 0;
+  (void)hipGetLastError();
+}
+
 // ---- tuning knobs: env RQ_<KEY>, or rq_set_tuning() ---------------------------------------------
 struct Knob { char key[32]; int value; };
 static Knob g_knobs[64];
@@ -415,19 +420,23 @@ int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *code
   // ORDER_MIN_NQ (2048) queries on.  LSQ scans index row_bias / norm bytes by position and keep the arrival order.
   // The in-call order is an optimisation on hidden scratch (n * (mp + 8) bytes per device and stream, kept until
   // rq_release_workspaces): it is skipped above ORDER_MAX_SCRATCH_MB (default 2048 MiB = a 1.25e8-row m = 8 shard; bigger
-  // bases belong in an index handle or rq_dev_order_rows, which order ONCE), and a scratch or launch failure means "scan
-  // in arrival order" -- the round-3 path, which needs no extra memory -- never a failed search.
+  // bases belong in an index handle or rq_dev_order_rows, which order ONCE), and a scratch allocation that fails (out of memory)
+  // means "scan in arrival order" -- the round-3 path, which needs no extra memory -- never a failed search; any other error of
+  // the ordering kernels is returned.
   if (!perm && !row_bias && order_pays(n, nq, k) &&
       order_base_bytes(n, mp) + (size_t)n * 4 <= (size_t)std::max(0, tuning("ORDER_MAX_SCRATCH_MB", 2048)) * 1048576ull) {
     void *ord = nullptr;
     const uint8_t *ocodes = codes;
     const uint32_t *operm = nullptr;
-    if (workspace(WS_ORDER, order_base_bytes(n, mp), &ord, stream) == RQ_OK &&
-        order_base(&ocodes, &operm, ord, codes, n, mp, stream) == RQ_OK) {
+    int orc = workspace(WS_ORDER, order_base_bytes(n, mp), &ord, stream);
+    if (orc == RQ_OK) orc = order_base(&ocodes, &operm, ord, codes, n, mp, stream);
+    if (orc == RQ_OK) {
       codes = ocodes;
       perm = operm;
+    } else if (is_oom(orc)) {
+      forgive_oom();                // no memory for the scratch: not an error of the search, it runs in arrival order
     } else {
-      (void)hipGetLastError();      // out of memory for the scratch: not an error of the search
+      return orc;                   // a launch error of the ordering kernels is an error
     }
   }
   ScanPlan pl;
@@ -812,12 +821,29 @@ int rq_scan_plan(int64_t n, int64_t nq, int m, int d, int k, int num_cu, int64_t
   return RQ_OK;
 }
 
+int rq_scan_orders_in_call(int64_t n, int64_t nq, int k) {
+  // would a raw-pointer scan of this shape (rq_dev_linscan / rq_linscan_pq, PQ tables) order a scratch copy of the base itself?
+  return order_pays(n, nq, k) &&
+                 order_base_bytes(n, 8) + (size_t)n * 4 <= (size_t)std::max(0, tuning("ORDER_MAX_SCRATCH_MB", 2048)) * 1048576ull
+             ? 1 : 0;
+}
+
 int rq_scan_stats(unsigned long long *out8) {
   // diagnostics: phase cycle counters of the last scan launched with tuning SCAN_STATS=1
   void *counter = nullptr;
   RQ_TRY(workspace(WS_COUNTER, 256, &counter, nullptr));
   RQ_HIP(hipDeviceSynchronize());
   RQ_HIP(hipMemcpy(out8, (char *)counter + 64, 128, hipMemcpyDeviceToHost));
+  return RQ_OK;
+}
+
+int rq_scan_finish_stats(unsigned long long *out8) {
+  // diagnostics: the counters behind the 16 of rq_scan_stats (same launch, same tuning)
+  if (!out8) return fail(RQ_EINVAL, "rq_scan_finish_stats: null output");
+  void *counter = nullptr;
+  RQ_TRY(workspace(WS_COUNTER, 256, &counter, nullptr));
+  RQ_HIP(hipDeviceSynchronize());
+  RQ_HIP(hipMemcpy(out8, (char *)counter + 64 + 128, 64, hipMemcpyDeviceToHost));
   return RQ_OK;
 }
 
@@ -940,11 +966,13 @@ rq_lsq_index *rq_lsq_prepare(const uint8_t *codes, const float *codebooks, const
     // norm bytes are indexed by POSITION in the kernel, ids come from perm
     // (an ordered copy that cannot be allocated or built leaves the base in arrival order: slower gathers, same answer)
     if (tuning("INDEX_ORDER", 1) && order_pays(n, 0, 0) && hipMalloc(&ix->ordered, order_base_bytes(n, mp)) != hipSuccess) {
-      (void)hipGetLastError();
+      (void)hipGetLastError();      // out of memory: the base stays in arrival order
       ix->ordered = nullptr;
     }
     if (ix->ordered) {
-      if (order_base(&ix->ocodes, &ix->perm, ix->ordered, ix->codes, n, mp, nullptr) != RQ_OK) { (void)hipGetLastError(); ix->perm = nullptr; }
+      const int orc = order_base(&ix->ocodes, &ix->perm, ix->ordered, ix->codes, n, mp, nullptr);
+      if (is_oom(orc)) { forgive_oom(); ix->perm = nullptr; }      // (the key scratch)
+      else if (orc != RQ_OK) return orc;                           // launch errors surface
       if (ix->perm) {
         float *pn = nullptr;
         RQ_HIP(hipMalloc((void **)&pn, (size_t)n * 4));

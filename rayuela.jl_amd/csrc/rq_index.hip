@@ -319,21 +319,25 @@ static int index_set(rq_index *ix, int64_t n, uint32_t id_offset, Fill fill) {
     // other widths are padded and ordered per search.  Costs 4 bytes per row for perm; the arrival-order copy is freed.
     if (tuning("INDEX_ORDER", 1) && scan_padded_m(ix->m) == ix->m && order_pays(s.n, 0, 0)) {
       DeviceLock order_lock;      // scratch lookup + launches of this device, like a scan
-      // (an ordered copy that cannot be allocated or built -- memory -- leaves the shard in arrival order: slower gathers,
-      // the same answer; set_codes does not fail for the sake of an optimisation)
+      // (an ordered copy that cannot be ALLOCATED leaves the shard in arrival order: slower gathers, the same answer;
+      // set_codes does not fail for want of memory for an optimisation)
       void *ord = nullptr;
       const uint8_t *oc = nullptr;
       const uint32_t *op = nullptr;
-      int rc = hipMalloc(&ord, order_base_bytes(s.n, ix->m)) == hipSuccess ? RQ_OK : RQ_EUNSUPPORTED;
+      int rc = RQ_OK;
+      if (hipMalloc(&ord, order_base_bytes(s.n, ix->m)) != hipSuccess) { (void)hipGetLastError(); rc = (int)hipErrorOutOfMemory; ord = nullptr; }
       if (rc == RQ_OK) rc = order_base(&oc, &op, ord, s.codes, s.n, ix->m, dv.stream);
       if (rc == RQ_OK) { hipError_t e = hipStreamSynchronize(dv.stream); if (e != hipSuccess) rc = fail_hip(e, "order sync", __FILE__, __LINE__); }
-      if (rc != RQ_OK || !op) {
-        if (ord) (void)hipFree(ord);
-        (void)hipGetLastError();
-      } else {
+      if (rc == RQ_OK && op) {
         RQ_HIP(hipFree(s.codes));
         s.codes = (uint8_t *)ord;
         s.perm = op;
+      } else {
+        if (ord) (void)hipFree(ord);
+        // only "no memory" is forgiven; a launch or synchronisation error of the ordering kernels is a device fault and is
+        // returned (it used to be swallowed and reported as RQ_OK)
+        if (is_oom(rc)) forgive_oom();
+        else if (rc != RQ_OK) { (void)release_stream_workspace(dv.stream); return rc; }
       }
       (void)release_stream_workspace(dv.stream);    // the key scratch (4 bytes per row + the histogram) is not needed again
     }

@@ -13,6 +13,11 @@ namespace rq {
 // Records the message for rq_last_error() (thread-local) and returns `code`.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 int fail_hip(hipError_t e, const char *what, const char *file, int line);
+// The only failure an OPTIONAL step (the bank-aware ordering of a base) may swallow: no memory for its scratch.  fail_hip returns
+// the HIP code, so rc == hipErrorOutOfMemory identifies it; forgive_oom() then withdraws the message (the step is skipped, the
+// call succeeds).  Launch / synchronisation errors are never forgiven: a device fault must surface where it happened.
+inline bool is_oom(int rc) { return rc == (int)hipErrorOutOfMemory; }
+void forgive_oom();
 
 #define RQ_HIP(expr)                                                       \
   do {                                                                     \

@@ -87,6 +87,10 @@ __device__ __noinline__ bool bucket_finish_item(ScanCtrl<ScanCfg<M>::QG> *ctrl_g
       heavy = twins >= BF_TIE_MIN || ctrl->cnt[g] > max(BF_MAX_CNT, 3u * p.K);
     }
     gave_up = block_any(heavy, ctrl->st.vote, vseq);
+    if (p.stats && threadIdx.x == 0) {     // diagnostics: groups that came here / that the look sent to select + sort
+      atomicAdd(&p.stats[16], 1ull);
+      if (gave_up) atomicAdd(&p.stats[17], 1ull);
+    }
   }
   if (!gave_up && mine_on) {
     const uint32_t cnt = ctrl->cnt[g];
@@ -680,6 +684,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
         RQ_STAT_ADD(5, t_ph);
         continue;
       }
+      RQ_STAT_INC(18);     // groups that went on to select + sort (the look's skips included)
       bool need = ctrl->cnt[g] > (uint32_t)p.K;
       if (block_any(need, ctrl->st.vote, vseq)) compact_group<M>(ctrl, cand_wg, p, need, g, gi, vseq);
     }

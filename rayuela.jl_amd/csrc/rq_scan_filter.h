@@ -47,7 +47,17 @@ constexpr uint32_t filt_thr8(bool fine) { return fine ? 191u : (uint32_t)RQ_FILT
 #endif
 constexpr uint32_t filt_off8(bool fine) { return (!fine && RQ_FILT_OFFSET && RQ_FILT_THR8 < 127) ? 127u - (uint32_t)RQ_FILT_THR8 : 0u; }
 constexpr bool filt_bit7(bool fine) { return !fine && (filt_off8(false) != 0u || RQ_FILT_THR8 == 127); }
-constexpr uint32_t filt_clamp8(bool fine) { return fine ? 63u : (filt_off8(false) ? (255u - filt_off8(false)) / 8u : 31u); }
+// Round 6, the FINE tables (two sets of 4, k >= 8192): the same trick on the per-byte AVERAGE of the two sums -- the first
+// sub-quantizer of BOTH sets carries 127 - (THR - 1) / 2 = 32, the offsets add 64 (even) to A + B, so floor((A + B) / 2) moves by
+// exactly 32 and "A + B <= 191" is bit 7 of the average being clear: 6 of the 36 VALU instructions per row go, the clamp drops
+// from 63 to (255 - 32) / 4 = 55 (first block at k = 10000: 19.9 -> 20.3 % of the rows alive).  Same-box A/B at SIFT1M shape,
+// k = 10000, arrival order: 4.795 -> 4.725 ms (tools/k10000_ab.py; ab_libs variant -DRQ_FILT_OFFSET_FINE=0).  PQ / CQ scans
+// only; LSQ sets hold 5 entries of <= 51.
+#ifndef RQ_FILT_OFFSET_FINE
+#define RQ_FILT_OFFSET_FINE 1
+#endif
+constexpr uint32_t filt_off8_fine() { return RQ_FILT_OFFSET_FINE ? 127u - (filt_thr8(true) - 1u) / 2u : 0u; }
+constexpr uint32_t filt_clamp8(bool fine) { return fine ? (filt_off8_fine() ? (255u - filt_off8_fine()) / 4u : 63u) : (filt_off8(false) ? (255u - filt_off8(false)) / 8u : 31u); }
 constexpr uint32_t FILT_THR16 = 159;
 // m = 16, same trick (build knob RQ_FILT_OFFSET16, OFF): the first sub-quantizer of BOTH sets would carry (127 - (THR16 - 1) / 2)
 // = 48, so that the per-byte average of the two sums is <= (THR16 - 1) / 2 exactly when its bit 7 is clear (the offsets add 96,
@@ -243,6 +253,9 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
       if constexpr (M == 8 && !LSQ && filt_off8(FINE) != 0u) {
         if (kk == 0) w += filt_off8(FINE) * 0x01010101u;         // (clamp + offset <= 255: no carry between the bytes)
       }
+      if constexpr (M == 8 && !LSQ && FINE && filt_off8_fine() != 0u) {
+        if ((kk & 3) == 0) w += filt_off8_fine() * 0x01010101u;  // first sub-quantizer of each of the two sets of 4
+      }
       if constexpr (M == 16 && !LSQ && filt_off16() != 0u) {
         if ((kk & 7) == 0) w += filt_off16() * 0x01010101u;      // first sub-quantizer of each of the two sets
       }
@@ -285,7 +298,7 @@ __device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC 
       uint32_t v = a[j];
       if constexpr (FINE) v = (a[j] & a[NQ + j]) + (((a[j] ^ a[NQ + j]) >> 1) & 0x7f7f7f7fu);
       // THR = 127 (coarse tables): "sum <= THR" IS bit 7 of the byte sum -- no compare arithmetic at all
-      if constexpr (filt_bit7(FINE)) all &= v;
+      if constexpr (filt_bit7(FINE) || (FINE && !LSQ && filt_off8_fine() != 0u)) all &= v;
       else all &= ((v | H) - TC) | v;
     }
     return (all & H) != H;
@@ -332,7 +345,7 @@ __device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<
     for (int j = 0; j < NQ; ++j) {
       uint32_t v = a[j];
       if constexpr (FINE) v = (a[j] & a[NQ + j]) + (((a[j] ^ a[NQ + j]) >> 1) & 0x7f7f7f7fu);
-      if constexpr (filt_bit7(FINE)) bits |= high_bits4(~v) << (4 * j);
+      if constexpr (filt_bit7(FINE) || (FINE && !LSQ && filt_off8_fine() != 0u)) bits |= high_bits4(~v) << (4 * j);
       else bits |= high_bits4(~(((v | H) - TC) | v)) << (4 * j);
     }
     return bits;

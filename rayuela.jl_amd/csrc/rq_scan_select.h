@@ -80,17 +80,23 @@ __device__ __noinline__ void finish_bigk(const uint32_t *cnt_q, const uint32_t *
     const uint64_t *src = cand_wg + ((size_t)q * 2 + sel) * cap;
     uint64_t *dst = cand_wg + ((size_t)q * 2 + (sel ^ 1u)) * cap;
     const uint32_t n_out = min(K, cnt);
+    // Fewer candidates than K: a slice shorter than K, or rows whose distance is NaN (they compare false with every threshold
+    // and are never candidates: include/rayuela_hip.h "Non-finite inputs") -- the tail is the padding key, (NaN, no row).
+    // cnt is workgroup-uniform, so skipping the sort (which has barriers inside) for an empty list is uniform too.
     if (keys_base) {
       uint64_t *o = keys_base + (size_t)qq * key_stride;
-      for (uint32_t i = n_out + tid; i < K; i += NT) o[i] = KEY_MAX;   // short slice
-      samplesort_topk<NT>(src, dst, bkt, cnt, n_out, lds, [o](uint32_t r, uint64_t key) { o[r] = key; }, stats, use_map);
+      for (uint32_t i = n_out + tid; i < K; i += NT) o[i] = KEY_MAX;
+      if (cnt != 0u)
+        samplesort_topk<NT>(src, dst, bkt, cnt, n_out, lds, [o](uint32_t r, uint64_t key) { o[r] = key; }, stats, use_map);
     } else {
       float *od = dists + (size_t)qq * K;
       uint32_t *oi = ids + (size_t)qq * K;
-      samplesort_topk<NT>(src, dst, bkt, cnt, n_out, lds, [od, oi, id_base](uint32_t r, uint64_t key) {
-        od[r] = key_dist(key);
-        oi[r] = key_id(key) + id_base;
-      }, stats, use_map);
+      for (uint32_t i = n_out + tid; i < K; i += NT) { od[i] = key_dist(KEY_MAX); oi[i] = key_id(KEY_MAX) + id_base; }
+      if (cnt != 0u)
+        samplesort_topk<NT>(src, dst, bkt, cnt, n_out, lds, [od, oi, id_base](uint32_t r, uint64_t key) {
+          od[r] = key_dist(key);
+          oi[r] = key_id(key) + id_base;
+        }, stats, use_map);
     }
   }
 }

@@ -248,13 +248,15 @@ static int check_train(int64_t n, int d, int m, int h, int niter) {
 // bench runs), so this runs on the host: the sub-space columns and the stage's codes come down once per affected sub-space.
 // dCsub: device [h][sub] block of the sub-codebook; dX: device rows of `d` floats, the sub-space starts at column col0;
 // codes: device bytes, the row's code at codes[row * cstride + ci].  The draws use the library's seeded stream (not Julia's).
-static int repick_unused(float *dCsub, const float *dX, int64_t n, int d, int col0, int sub, const uint8_t *codes, int cstride,
-                         int ci, int h, const std::vector<int> &unused, Rng &rng) {
+// dCassigned: the same block as it was when `codes` were assigned, i.e. BEFORE update_centers -- Clustering draws with the
+// costs of the last assignment (`costs` of update_assignments!), not with distances to the centres just recomputed.
+static int repick_unused(float *dCsub, const float *dCassigned, const float *dX, int64_t n, int d, int col0, int sub,
+                         const uint8_t *codes, int cstride, int ci, int h, const std::vector<int> &unused, Rng &rng) {
   std::vector<float> xs((size_t)n * sub), cs((size_t)h * sub);
   std::vector<uint8_t> cb((size_t)n);
   RQ_HIP(hipMemcpy2D(xs.data(), (size_t)sub * 4, dX + col0, (size_t)d * 4, (size_t)sub * 4, (size_t)n, hipMemcpyDeviceToHost));
   RQ_HIP(hipMemcpy2D(cb.data(), 1, codes + ci, (size_t)cstride, 1, (size_t)n, hipMemcpyDeviceToHost));
-  RQ_HIP(hipMemcpy(cs.data(), dCsub, (size_t)h * sub * 4, hipMemcpyDeviceToHost));
+  RQ_HIP(hipMemcpy(cs.data(), dCassigned, (size_t)h * sub * 4, hipMemcpyDeviceToHost));
   std::vector<double> tc((size_t)n);
   for (int64_t j = 0; j < n; ++j) {
     const float *x = &xs[(size_t)j * sub], *c = &cs[(size_t)cb[j] * sub];
@@ -337,6 +339,8 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
   // The change counter sits right behind the cluster counts: ONE small read-back per iteration serves the convergence test
   // and the empty-cluster check (the centres are recomputed before the test is known; with unchanged assignments that
   // reproduces them bit for bit).  The two code buffers swap roles instead of being copied.
+  DevMem dCold;        // the centres the current codes were assigned with (repick_unused draws with THOSE costs)
+  RQ_TRY(dCold.alloc((size_t)h * d * 4));
   DevMem dcc;
   const size_t cnt_bytes = (size_t)m * h * 4;
   RQ_TRY(dcc.alloc(cnt_bytes + 8));
@@ -351,6 +355,7 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
     prof.start();
     if (it > 0) RQ_TRY(codes_changed_launch(dchg_p, cur, prev, (size_t)n * m, nullptr));
     prof.stop(TP_CONVERGE);
+    RQ_HIP(hipMemcpyAsync(dCold.p, dC.p, (size_t)h * d * 4, hipMemcpyDeviceToDevice, nullptr));
     RQ_PH(TP_CENTERS, RQ_TRY(update_centers_launch(dC.as<float>(), dcnt_p, dX.as<float>(), cur, n, d, m, h, di.num_cu, nullptr)));
     prof.start();
     RQ_HIP(hipMemcpy(back.data(), dcc.p, cnt_bytes + 8, hipMemcpyDeviceToHost));
@@ -365,8 +370,8 @@ int rq_train_pq(float *C, int16_t *B1, double *error, const float *X, int64_t n,
       for (int k = 0; k < h; ++k)
         if (counts[(size_t)i * h + k] == 0) unused.push_back(k);
       if (!unused.empty())
-        RQ_TRY(repick_unused(dC.as<float>() + (size_t)h * off[i], dX.as<float>(), n, d, off[i], off[i + 1] - off[i], cur, m, i, h,
-                             unused, rng));
+        RQ_TRY(repick_unused(dC.as<float>() + (size_t)h * off[i], dCold.as<float>() + (size_t)h * off[i], dX.as<float>(), n, d,
+                             off[i], off[i + 1] - off[i], cur, m, i, h, unused, rng));
     }
     std::swap(cur, prev);
   }
@@ -404,8 +409,9 @@ int rq_train_rvq(float *C, int16_t *B1, double *error, const float *X, int64_t n
   DeviceLock call_lock;
   int off1[2] = {0, d};
   Rng rng{seed * 0x9E3779B97F4A7C15ull + 3};
-  DevMem dXr, dCi, dstage, dcnt, dcodes, dacc, d16;
-  RQ_TRY(dXr.alloc((size_t)n * d * 4)); RQ_TRY(dCi.alloc((size_t)h * d * 4)); RQ_TRY(dstage.alloc((size_t)n));
+  DevMem dXr, dCi, dCold, dstage, dcnt, dcodes, dacc, d16;
+  RQ_TRY(dXr.alloc((size_t)n * d * 4)); RQ_TRY(dCi.alloc((size_t)h * d * 4)); RQ_TRY(dCold.alloc((size_t)h * d * 4));
+  RQ_TRY(dstage.alloc((size_t)n));
   RQ_TRY(dcnt.alloc((size_t)h * 4)); RQ_TRY(dcodes.alloc((size_t)n * m)); RQ_TRY(dacc.alloc(8));
   RQ_TRY(d16.alloc((size_t)n * m * 2));
   RQ_HIP(hipMemcpy(dXr.p, X, (size_t)n * d * 4, hipMemcpyHostToDevice));
@@ -419,6 +425,7 @@ int rq_train_rvq(float *C, int16_t *B1, double *error, const float *X, int64_t n
       RQ_HIP(hipMemcpy(cur.data(), dstage.p, (size_t)n, hipMemcpyDeviceToHost));
       if (!prev.empty() && prev == cur) break;   // assignments stable: Lloyd has converged
       prev = cur;
+      RQ_HIP(hipMemcpyAsync(dCold.p, dCi.p, (size_t)h * d * 4, hipMemcpyDeviceToDevice, nullptr));
       RQ_TRY(update_centers_launch(dCi.as<float>(), dcnt.as<unsigned int>(), dXr.as<float>(), dstage.as<uint8_t>(), n,
                                    d, 1, h, di.num_cu, nullptr));
       RQ_HIP(hipMemcpy(counts.data(), dcnt.p, (size_t)h * 4, hipMemcpyDeviceToHost));
@@ -426,7 +433,7 @@ int rq_train_rvq(float *C, int16_t *B1, double *error, const float *X, int64_t n
       for (int k = 0; k < h; ++k)
         if (counts[k] == 0) unused.push_back(k);
       if (!unused.empty())
-        RQ_TRY(repick_unused(dCi.as<float>(), dXr.as<float>(), n, d, 0, d, dstage.as<uint8_t>(), 1, 0, h, unused, rng));
+        RQ_TRY(repick_unused(dCi.as<float>(), dCold.as<float>(), dXr.as<float>(), n, d, 0, d, dstage.as<uint8_t>(), 1, 0, h, unused, rng));
     }
     // the assignments of the final centres (what quantize_rvq would return for this stage), then the residual
     RQ_TRY(encode_launch(dstage.as<uint8_t>(), dXr.as<float>(), dCi.as<float>(), n, d, 1, h, di.num_cu, nullptr));

@@ -52,7 +52,7 @@ class ShardedIndex:
         self.always_exchange = always_exchange
         # host_staging: run the collectives on CPU copies (debug aid: a gloo group over ranks that share one GPU)
         self.host_staging = host_staging
-        self.codes = codes_local          # [n_local][m] uint8, resident on this rank's device
+        self._codes = codes_local         # [n_local][m] uint8, resident on this rank's device (see the `codes` property)
         self.centers = centers            # [m][256][sub] float32, replicated
         self.id_offset = int(id_offset)
         self.group = group
@@ -79,11 +79,21 @@ class ShardedIndex:
             # the ordered copy serves every search: the arrival-order rows are only kept on request (like the C index, which
             # frees them -- 1 GB of a 1.25e8 x 8 shard otherwise held twice; the caller's own reference is the caller's)
             if not keep_arrival_copy:
-                self.codes = None
+                self._codes = None
         if self.world > 1:
             t = torch.tensor([self.n_total], dtype=torch.int64, device="cpu" if host_staging else codes_local.device)
             dist.all_reduce(t, group=group)
             self.n_total = int(t.item())
+
+    @property
+    def codes(self):
+        """The shard's rows in ARRIVAL order.  Released once the bank-aware ordered copy exists (`self.ordered`: rows permuted,
+        `perm` maps position -> arrival row) unless the index was built with keep_arrival_copy=True; reading it then is an
+        error rather than a silent None.  The caller's own tensor is untouched."""
+        if self._codes is None:
+            raise AttributeError("ShardedIndex.codes: the arrival-order rows were released when the ordered copy was built; "
+                                 "pass keep_arrival_copy=True, or use .ordered (codes + perm)")
+        return self._codes
 
     def local_keys(self, queries, k):
         """[nq][k] int64 sorted keys of this shard, padded with KEY_MAX when the shard has < k rows."""
@@ -92,7 +102,7 @@ class ShardedIndex:
         k_local = min(k, n_local)
         if k_local == 0:
             return torch.full((nq, k), KEY_MAX, dtype=torch.int64, device=queries.device)
-        keys = self.scan_fn(self.ordered if self.ordered is not None else self.codes, self.centers, queries, k_local,
+        keys = self.scan_fn(self.ordered if self.ordered is not None else self._codes, self.centers, queries, k_local,
                             self.id_offset)
         if k_local < k:
             pad = torch.full((nq, k - k_local), KEY_MAX, dtype=torch.int64, device=keys.device)
