@@ -234,9 +234,12 @@ def test_clumped_base_does_not_fall_back(rq, oracle):
         rqd.linscan(ob, cen, qd, K)
         torch.cuda.synchronize()
         st = _lib.scan_stats()
+    # (which 64 candidates a query looks at depends on the order its rows were appended in, i.e. on wavefront timing: measured
+    # 509-512 of 512 groups turned away by the look, 0-3 giving up after their histogram; the failure this guards -- the look never
+    # firing, as in round 5's first version -- reads 0 of 512)
     assert st["bf_items"] == st["n_items"] > 0, st
-    assert st["bf_look_skips"] >= 0.99 * st["bf_items"], st
-    assert st["bf_select_sort"] - st["bf_look_skips"] <= 0.002 * st["bf_items"] + 1, st
+    assert st["bf_look_skips"] >= 0.97 * st["bf_items"], st
+    assert st["bf_select_sort"] - st["bf_look_skips"] <= 0.03 * st["bf_items"], st
 
 
 def test_tiny_base_of_an_untiled_row_width_through_order_rows(rq, oracle):
