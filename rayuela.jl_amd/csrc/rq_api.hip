@@ -443,7 +443,7 @@ int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *code
   RQ_TRY(scan_plan(pl, n, nq, m, d, k, di.num_cu, tuning("SCAN_SLICES", 0)));
   void *cand = nullptr, *counter = nullptr;
   RQ_TRY(workspace(WS_CAND, pl.cand_bytes, &cand, stream));
-  RQ_TRY(workspace(WS_COUNTER, 256, &counter, stream));
+  RQ_TRY(workspace(WS_COUNTER, WS_COUNTER_BYTES, &counter, stream));
   // whole items write the answer (or final keys) themselves; the sliced tail leaves per-slice key lists
   // that merge_topk turns into the same outputs for those queries
   const int64_t q_tail = std::min<int64_t>(nq, (int64_t)pl.whole * pl.qg);
@@ -831,7 +831,7 @@ int rq_scan_orders_in_call(int64_t n, int64_t nq, int k) {
 int rq_scan_stats(unsigned long long *out8) {
   // diagnostics: phase cycle counters of the last scan launched with tuning SCAN_STATS=1
   void *counter = nullptr;
-  RQ_TRY(workspace(WS_COUNTER, 256, &counter, nullptr));
+  RQ_TRY(workspace(WS_COUNTER, WS_COUNTER_BYTES, &counter, nullptr));
   RQ_HIP(hipDeviceSynchronize());
   RQ_HIP(hipMemcpy(out8, (char *)counter + 64, 128, hipMemcpyDeviceToHost));
   return RQ_OK;
@@ -841,7 +841,7 @@ int rq_scan_finish_stats(unsigned long long *out8) {
   // diagnostics: the counters behind the 16 of rq_scan_stats (same launch, same tuning)
   if (!out8) return fail(RQ_EINVAL, "rq_scan_finish_stats: null output");
   void *counter = nullptr;
-  RQ_TRY(workspace(WS_COUNTER, 256, &counter, nullptr));
+  RQ_TRY(workspace(WS_COUNTER, WS_COUNTER_BYTES, &counter, nullptr));
   RQ_HIP(hipDeviceSynchronize());
   RQ_HIP(hipMemcpy(out8, (char *)counter + 64 + 128, 64, hipMemcpyDeviceToHost));
   return RQ_OK;

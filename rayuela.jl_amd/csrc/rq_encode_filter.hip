@@ -611,7 +611,7 @@ static int launch_encode_filter(EncParams p, int num_cu, hipStream_t stream) {
   const bool want_stats = tuning("ENC_STATS", 0) != 0;
   void *stat_dev = nullptr;
   if (want_stats) {
-    RQ_TRY(workspace(WS_COUNTER, 256, &stat_dev, stream));
+    RQ_TRY(workspace(WS_COUNTER, WS_COUNTER_BYTES, &stat_dev, stream));
     p.stat = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(stat_dev) + 128);
     RQ_HIP(hipMemsetAsync(p.stat, 0, 8, stream));
   }

@@ -50,6 +50,10 @@ void host_pool_free(void *p);
 void host_pool_trim();
 void sharded_cache_release();
 int aux_streams(hipStream_t *compute, hipStream_t *transfer);
+// WS_COUNTER: [0..63] work tickets / finished items per XCD, [64..255] diagnostics (rq_scan_stats), [256..] chunk-pacing
+// counters of the big-base scan: 8 XCDs x SCAN_PACE_SLOTS x {chunks done, members}
+constexpr int SCAN_PACE_SLOTS = 64;
+constexpr size_t WS_COUNTER_BYTES = 256 + 8 * SCAN_PACE_SLOTS * 8;
 enum { WS_CAND = 0, WS_COUNTER = 1, WS_KEYS = 2, WS_TMP = 3, WS_PAD = 4, WS_MERGE = 5, WS_NORMB = 6, WS_ORDER = 7, WS_ORDER_TMP = 8, WS_ENCFLAG = 9, WS_SLOTS = 10 };
 
 // Per-device launch lock (recursive): held while a call looks up scratch, resets the work counter and

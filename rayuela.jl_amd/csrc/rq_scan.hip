@@ -40,6 +40,7 @@
 #include "rq_scan_filter.h"
 #include "rq_scan_select.h"
 
+
 namespace rq {
 
 // phase accounting (diagnostics only; p.stats == nullptr in normal runs)
@@ -87,10 +88,12 @@ __device__ __noinline__ bool bucket_finish_item(ScanCtrl<ScanCfg<M>::QG> *ctrl_g
       heavy = twins >= BF_TIE_MIN || ctrl->cnt[g] > max(BF_MAX_CNT, 3u * p.K);
     }
     gave_up = block_any(heavy, ctrl->st.vote, vseq);
+#ifndef RQ_NO_FINSTATS
     if (p.stats && threadIdx.x == 0) {     // diagnostics: groups that came here / that the look sent to select + sort
       atomicAdd(&p.stats[16], 1ull);
       if (gave_up) atomicAdd(&p.stats[17], 1ull);
     }
+#endif
   }
   if (!gave_up && mine_on) {
     const uint32_t cnt = ctrl->cnt[g];
@@ -118,6 +121,28 @@ __device__ __noinline__ bool bucket_finish_item(ScanCtrl<ScanCfg<M>::QG> *ctrl_g
   *vseq_out = vseq;
   return gave_up;
 }
+
+#if RQ_SCAN_PACE_BUILD
+// EXPERIMENT, compiled in with -DRQ_SCAN_PACE_BUILD=1 only (tools/build_variant.sh; EXPERIMENTS.md section 9.2: it buys L2 hits with
+// idle time -- 11.8x -> 5.6x the code bytes fetched on the 1.25e8-row shard for 15.4 -> 20.6 ms).
+// Chunk pacing of a big-base item (xcd_mode; one thread per workgroup, out of line so that the streaming loop's registers do
+// not depend on it).  The workgroups of an XCD that run the items of one pacing wave stream the same 32 MB window; they share it
+// through the XCD's 4 MiB L2 only while they are within a few hundred KB of each other.  slot[0] sums the chunks the wave's
+// workgroups have finished, slot[1] counts the workgroups that joined: a workgroup starts chunk c only when the wave's AVERAGE
+// progress is at least c - lag.  The slowest workgroups never wait (no cycle), stale or shared slots only shorten waits, the spin
+// is bounded: a speed hint like the item pacing above -- no data depends on it.
+__device__ __noinline__ void pace_chunk(uint32_t *slot, uint32_t chunk, uint32_t lag) {
+  if (chunk != 0u) atomicAdd(slot, 1u);
+  if (chunk <= lag) return;
+  const uint32_t want = chunk - lag;
+  for (uint32_t spin = 0; spin < (1u << 9); ++spin) {
+    const uint32_t done = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t members = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done >= want * members) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+#endif
 
 template <int M, bool BIAS, bool FILT, bool FINE = false>
 __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanParams p) {
@@ -180,6 +205,17 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
           if (j < cnt_x) {
             it = ((j / p.ngroups) * 8u + x) * p.ngroups + (j % p.ngroups);             // = slice * ngroups + group
             ctrl->pad[0] = x;
+            // chunk pacing: the items of a pacing round run in waves of one item per resident workgroup of the XCD; a wave
+            // shares one slot (workgroups that took another XCD's window sit behind another L2: they stay out)
+#if RQ_SCAN_PACE_BUILD
+            ctrl->pad[1] = 0xffffffffu;
+            if (p.pace != nullptr && y == 0u) {
+              const uint32_t nres = max(1u, gridDim.x / 8u);
+              const uint32_t wave = (j / p.xcd_round) * ((p.xcd_round + nres - 1u) / nres) + (j % p.xcd_round) / nres;
+              ctrl->pad[1] = (x * (uint32_t)SCAN_PACE_SLOTS + wave % (uint32_t)SCAN_PACE_SLOTS) * 2u;
+              atomicAdd(p.pace + ctrl->pad[1] + 1u, 1u);
+            }
+#endif
             const uint32_t before = (j / p.xcd_round) * p.xcd_round;                   // items of the earlier rounds
             const uint32_t need = before > p.xcd_slack ? before - p.xcd_slack : 0u;
             for (uint32_t spin = 0; spin < (1u << 10); ++spin) {      // bounded: ~2 ms at most, then the item starts anyway
@@ -354,6 +390,11 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
     // ---- stream the slice -----------------------------------------------------------------------
     // (all of this loop control is wave-uniform: readfirstlane keeps it in SGPRs -- as VGPRs it spilled the block's code words)
     uint32_t bi = 0;       // blocks processed in this attempt
+#if RQ_SCAN_PACE_BUILD
+    // chunk pacing (big bases): blocks per chunk, 0 = this item is not paced (pad[1]: written with the item, read behind its barrier)
+    const uint32_t pace_every = __builtin_amdgcn_readfirstlane(
+        (p.pace != nullptr && attempt == 0 && ctrl->pad[1] != 0xffffffffu) ? p.pace_votes * (uint32_t)Cfg::VP : 0u);
+#endif
     const uint32_t npass = __builtin_amdgcn_readfirstlane(two_pass ? 2u : 1u);
     const uint32_t samp_lim = __builtin_amdgcn_readfirstlane(two_pass ? min(r_end, p.samp_end) : 0u);
     const uint32_t samp_step = __builtin_amdgcn_readfirstlane(p.samp_stride * (uint32_t)BLK);
@@ -386,6 +427,10 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
       // The pre-barrier read of cnt may miss what slower wavefronts are still appending for the
       // previous period (at most VP * BLK keys), hence cap = trigger + 2 * VP * BLK; behind the barrier cnt is exact.
       const bool vote_now = Cfg::VP == 1 || bi % (uint32_t)Cfg::VP == 0u;
+#if RQ_SCAN_PACE_BUILD
+      if (pace_every != 0u && vote_now && bi % pace_every == 0u && tid == 0)
+        pace_chunk(p.pace + ctrl->pad[1], bi / pace_every, p.pace_lag);       // (the vote's barrier holds the other threads)
+#endif
       const bool maybe = ctrl->cnt[g] > p.trigger;
       if (vote_now && block_any(maybe, ctrl->st.vote, vseq)) {
         const unsigned long long t_c = RQ_STAT_T();
@@ -684,7 +729,9 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
         RQ_STAT_ADD(5, t_ph);
         continue;
       }
+#ifndef RQ_NO_FINSTATS
       RQ_STAT_INC(18);     // groups that went on to select + sort (the look's skips included)
+#endif
       bool need = ctrl->cnt[g] > (uint32_t)p.K;
       if (block_any(need, ctrl->st.vote, vseq)) compact_group<M>(ctrl, cand_wg, p, need, g, gi, vseq);
     }
@@ -1167,6 +1214,12 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
     const int sl = tuning("SCAN_XCD_SLACK", -1);
     p.xcd_slack = sl >= 0 ? (uint32_t)sl : p.xcd_round / 4u;
   }
+  // chunk pacing inside the rounds (round 6, SCAN_PACE = 1: off by default -- EXPERIMENTS.md section 9 has the trade-off curve)
+#if RQ_SCAN_PACE_BUILD      // (compiled out of the shipped library: the mere presence of the call in the streaming loop cost k = 1 1.8 %, the shard 2 %)
+  p.pace = (pl.xcd && tuning("SCAN_PACE", 0)) ? work_counter + 64 : nullptr;
+  p.pace_lag = (uint32_t)std::max(0, tuning("SCAN_PACE_LAG", 2));
+  p.pace_votes = (uint32_t)std::max(1, tuning("SCAN_PACE_VOTES", 1));
+#endif
   p.cap = pl.cap; p.trigger = pl.trigger; p.p2 = pl.p2; p.scratch_keys = pl.scratch_keys;
   p.sample = pl.sample;
   p.sample_rt = (uint32_t)tuning("SCAN_SAMPLE_RT", 4096);
@@ -1199,6 +1252,9 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   }
   p.stats = tuning("SCAN_STATS", 0) ? reinterpret_cast<unsigned long long *>(work_counter + 16) : nullptr;
   p.dists = dists; p.ids = ids; p.keys = keys; p.part = part;
+#if RQ_SCAN_PACE_BUILD
+  if (p.pace) RQ_HIP(hipMemsetAsync(work_counter + 64, 0, WS_COUNTER_BYTES - 256, stream));
+#endif
   RQ_HIP(hipMemsetAsync(work_counter, 0, p.stats ? 256 : 16 * sizeof(uint32_t), stream));   // [0..7] tickets, [8..15] finished items, per XCD
   switch (m) {
     case 2: return launch_scan<2>(p, pl, stream);

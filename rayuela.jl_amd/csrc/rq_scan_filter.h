@@ -51,8 +51,9 @@ constexpr bool filt_bit7(bool fine) { return !fine && (filt_off8(false) != 0u ||
 // sub-quantizer of BOTH sets carries 127 - (THR - 1) / 2 = 32, the offsets add 64 (even) to A + B, so floor((A + B) / 2) moves by
 // exactly 32 and "A + B <= 191" is bit 7 of the average being clear: 6 of the 36 VALU instructions per row go, the clamp drops
 // from 63 to (255 - 32) / 4 = 55 (first block at k = 10000: 19.9 -> 20.3 % of the rows alive).  Same-box A/B at SIFT1M shape,
-// k = 10000, arrival order: 4.795 -> 4.725 ms (tools/k10000_ab.py; ab_libs variant -DRQ_FILT_OFFSET_FINE=0).  PQ / CQ scans
-// only; LSQ sets hold 5 entries of <= 51.
+// k = 10000, arrival order: 4.795 -> 4.725 ms against the same tree without it, 4.709 -> 4.704 ms against round 5's final build
+// (tools/k10000_ab.py, tools/ab_shard.py): the instructions saved and the rows let through cancel -- level, kept for the
+// shorter loop.  PQ / CQ scans only; LSQ sets hold 5 entries of <= 51.
 #ifndef RQ_FILT_OFFSET_FINE
 #define RQ_FILT_OFFSET_FINE 1
 #endif

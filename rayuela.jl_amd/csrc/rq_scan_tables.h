@@ -4,6 +4,10 @@
 #include "rq_internal.h"
 #include "rq_topk.h"
 
+#ifndef RQ_SCAN_PACE_BUILD
+#define RQ_SCAN_PACE_BUILD 0
+#endif
+
 namespace rq {
 
 
@@ -113,6 +117,11 @@ struct ScanParams {
   uint32_t xcd_mode;        // 1: big base -- row windows are handed out per XCD (work_counter[0..7]), see the item loop
   uint32_t xcd_slack;       // ... an item may start while at most this many items of the XCD's earlier rounds still run
   uint32_t xcd_round;       // ... items per pacing round (a window's items, or the XCD's resident workgroups)
+#if RQ_SCAN_PACE_BUILD      // (experiment builds only: even unused kernel arguments moved the streaming loop's register allocation)
+  uint32_t *pace;           // chunk pacing inside a round (round 6): [8][SCAN_PACE_SLOTS][2] {chunks done, members}; nullptr = off
+  uint32_t pace_lag;        // ... a workgroup runs at most this many chunks ahead of its wave's average
+  uint32_t pace_votes;      // ... a chunk = this many capacity votes (VP blocks each)
+#endif
   uint32_t cap;             // candidate buffer capacity per query (keys)
   uint32_t trigger;         // compact when cnt > trigger  (cap - 2*VP*BLK >= trigger >= K)
   uint32_t p2;              // next_pow2(K)

@@ -399,10 +399,23 @@ def test_xcd_window_plan_on_a_small_base(rq, oracle, m, sub, K, nq):
             rq.set_tuning("SCAN_XCD_SLACK", slack)
             d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
             assert np.array_equal(i0, i1) and _eq_bits(d0, d1), (m, K, slack)
+        # round 6: chunk pacing inside the rounds (SCAN_PACE; a speed hint -- bounded spins, no data depends on it): strict, loose,
+        # coarse chunks; with and without item pacing.  (The call site is compiled in with -DRQ_SCAN_PACE_BUILD=1 only -- the shipped
+        # library ignores the knob, a variant build runs the paced kernel through these same assertions.)
+        for lag, votes, slack in ((0, 1, -1), (2, 1, 1 << 20), (1, 3, 0)):
+            rq.set_tuning("SCAN_PACE", 1)
+            rq.set_tuning("SCAN_PACE_LAG", lag)
+            rq.set_tuning("SCAN_PACE_VOTES", votes)
+            rq.set_tuning("SCAN_XCD_SLACK", slack)
+            d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
+            assert np.array_equal(i0, i1) and _eq_bits(d0, d1), (m, K, "pace", lag, votes, slack)
     finally:
         rq.set_tuning("SCAN_XCD_MIN_MB", 0)
         rq.set_tuning("SCAN_WINDOW_MB", 0)
         rq.set_tuning("SCAN_XCD_SLACK", -1)
+        rq.set_tuning("SCAN_PACE", 0)
+        rq.set_tuning("SCAN_PACE_LAG", 2)
+        rq.set_tuning("SCAN_PACE_VOTES", 1)
     assert _lib.scan_plan(n, nq, m, m * sub, K)["xcd"] == 0            # 24-48 MB of codes: the ordinary plan
 
 
