@@ -330,6 +330,100 @@ static void run_nib(const uint8_t *codes, const uint2 *tabs, uint32_t n, uint32_
          100.0 * (double)al / ((double)n * (nq / 16)), hipGetErrorString(hipGetLastError()));
 }
 
+
+// Round 6 (VERDICT r5 Next #7): 16 queries per gather with BYTE entries -- one ds_read_b128 per code byte, table [8][256] uint4
+// (32 KiB per 16-query group).  Same adds per query as the 8-query kernel (4 dwords of 4 byte sums), half the addresses.  With
+// ORDER4 the rows are sorted by the top 4 bits of their leading bytes (a 16-value window = the 16 sixteen-byte columns a
+// 16-lane group of ds_read_b128 covers).
+template <int NT>
+__global__ __launch_bounds__(NT) void filt16_kernel(const uint8_t *__restrict__ codes, const uint4 *__restrict__ tabs, uint32_t n,
+                                                    uint32_t ngroups, uint32_t nslices, uint32_t rows_per_slice,
+                                                    uint32_t thr, unsigned long long *alive_out, uint32_t *counter) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4 *qt = reinterpret_cast<uint4 *>(smem);                        // [8][256] entries of 16 bytes
+  uint32_t *queue = reinterpret_cast<uint32_t *>(qt + 8 * 256);
+  __shared__ uint32_t s_item;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t *myq = queue + __builtin_amdgcn_readfirstlane(wave * 256);
+  unsigned long long alive_total = 0;
+  const uint32_t nitems = ngroups * nslices;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_item = atomicAdd(counter, 1u);
+    __syncthreads();
+    const uint32_t item = s_item;
+    if (item >= nitems) break;
+    const uint32_t group = item % ngroups, slice = item / ngroups;
+    for (int i = tid; i < 8 * 256; i += NT) qt[i] = tabs[(size_t)group * 8 * 256 + i];
+    __syncthreads();
+    const uint32_t r_begin = slice * rows_per_slice, r_end = min(n, r_begin + rows_per_slice);
+    uint32_t qtail = 0;
+    constexpr int U = 2;
+    for (uint32_t base = r_begin; base < r_end; base += NT * 2 * U) {
+      uint4 wu[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t row0 = base + u * NT * 2 + tid * 2;
+        wu[u] = row0 + 2 <= r_end ? *reinterpret_cast<const uint4 *>(codes + (size_t)row0 * 8) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t w[4] = {wu[u].x, wu[u].y, wu[u].z, wu[u].w};
+        const uint32_t row0 = base + u * NT * 2 + tid * 2;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {          // one row at a time: 8 x 16 bytes = 32 registers of entries
+          uint4 e[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) e[k] = qt[k * 256 + ((w[(r * 8 + k) >> 2] >> (8 * ((r * 8 + k) & 3))) & 0xffu)];
+          __builtin_amdgcn_sched_barrier(0);
+          uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { a0 += e[k].x; a1 += e[k].y; a2 += e[k].z; a3 += e[k].w; }
+          constexpr uint32_t H = 0x80808080u;
+          const uint32_t TC = (thr + 1u) * 0x01010101u;
+          const uint32_t g = (((a0 | H) - TC) | a0) & (((a1 | H) - TC) | a1) & (((a2 | H) - TC) | a2) & (((a3 | H) - TC) | a3);
+          const bool cand = ((g & H) != H) && (row0 + r < r_end);
+          const uint64_t mq = __ballot(cand);
+          if (mq) {
+            if (cand) myq[(qtail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u))) & 255u] = row0 + r;
+            qtail += (uint32_t)__popcll(mq);
+          }
+        }
+      }
+    }
+    alive_total += qtail;
+  }
+  if (lane == 0) atomicAdd(alive_out, alive_total);
+}
+
+template <int NT>
+static void run16(const uint8_t *codes, const uint2 *tabs, uint32_t n, uint32_t nq, uint32_t thr, int wgs_per_cu) {
+  const uint32_t ngroups = nq / 16;
+  const uint32_t grid = 256 * wgs_per_cu;
+  uint32_t nslices = ngroups >= grid ? 1 : (grid + ngroups - 1) / ngroups;
+  uint32_t rps = (n + nslices - 1) / nslices;
+  rps = (rps + NT * 4 - 1) / (NT * 4) * (NT * 4);
+  nslices = (n + rps - 1) / rps;
+  unsigned long long *alive; uint32_t *counter;
+  hipMalloc(&alive, 8); hipMalloc(&counter, 4);
+  const size_t lds = (size_t)8 * 256 * 16 + (size_t)(NT / 64) * 256 * 4;
+  hipFuncSetAttribute(reinterpret_cast<const void *>(filt16_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9;
+  unsigned long long al = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    hipMemset(alive, 0, 8); hipMemset(counter, 0, 4);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((filt16_kernel<NT>), dim3(grid), dim3(NT), lds, 0, codes, reinterpret_cast<const uint4 *>(tabs), n, ngroups, nslices, rps, thr, alive, counter);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+    hipMemcpy(&al, alive, 8, hipMemcpyDeviceToHost);
+  }
+  printf("B128 16 queries per ds_read_b128 NT=%4d WGs/CU=%d slices=%u lds=%zu KB: %.3f ms for the same 1e10 (row, query) pairs  alive (row,16-query set) share %.3f%%  err=%s\n",
+         NT, wgs_per_cu, nslices, lds / 1024, best, 100.0 * (double)al / ((double)n * (nq / 16)), hipGetErrorString(hipGetLastError()));
+}
+
 template <int NT, int QGB, int R = 1, int KG = 0>
 static void run(const uint8_t *codes, const uint2 *tabs, uint32_t n, uint32_t nq, uint32_t thr, int wgs_per_cu) {
   constexpr int NS = QGB / 8;
@@ -372,7 +466,8 @@ int main() {
     std::vector<uint32_t> idx(n);
     for (uint32_t i = 0; i < n; ++i) {
       uint64_t k = 0; int left = bits;
-      for (int c = 0; c < 8 && left > 0; ++c) { const int nb = left < 3 ? left : 3; k = (k << nb) | (hc[(size_t)i * 8 + c] >> (8 - nb)); left -= nb; }
+      const int per = getenv("ORDER_BITS_PER_BYTE") ? atoi(getenv("ORDER_BITS_PER_BYTE")) : 3;     // 4: 16-value windows (ds_read_b128 groups)
+      for (int c = 0; c < 8 && left > 0; ++c) { const int nb = left < per ? left : per; k = (k << nb) | (hc[(size_t)i * 8 + c] >> (8 - nb)); left -= nb; }
       key[i] = (k << 32) | i; idx[i] = i;
     }
     std::sort(key.begin(), key.end());
@@ -399,6 +494,10 @@ int main() {
   const uint32_t thr = getenv("THR") ? atoi(getenv("THR")) : 62;   // ~ a few % of (row, set) pairs alive
   run<512, 8>(codes, tabs, n, nq, thr, 2);
   run<512, 8>(codes, tabs, n, nq, thr, 4);
+  run16<512>(codes, tabs, n, nq, thr, 2);
+  run16<512>(codes, tabs, n, nq, thr, 4);
+  run16<256>(codes, tabs, n, nq, thr, 8);
+  if (getenv("MICRO_B128_ONLY")) return 0;
   if (getenv("MICRO_QUICK")) {
     run<256, 8>(codes, tabs, n, nq, thr, 8);
     run<512, 16>(codes, tabs, n, nq, thr, 4);
