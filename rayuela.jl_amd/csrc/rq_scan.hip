@@ -548,8 +548,8 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
           const uint32_t *w = wu[u];
           // all RPT * M gathers of the sub-step are issued before the first sum (16 x ds_read_b64 / 32 x ds_read_b32)
           using FV = typename FiltVec<M>::type;
-          static_assert(sizeof(FV) == 8, "byte tables: 8 queries per ds_read_b64");
-          const uint32_t shreg = 3u;
+          static_assert(sizeof(FV) == (size_t)QG, "byte tables: one byte per query of the group (ds_read_b64; b128 in the QG = 16 experiment)");
+          const uint32_t shreg = sizeof(FV) == 16 ? 4u : 3u;
           // gathers in flight together: 16 (M = 8: both rows of the sub-step; M = 16: one row -- 32 of them with
           // their 32 addresses spill registers in this loop)
           constexpr int RB = (RPT * M * (int)sizeof(FV) > 128) ? 1 : RPT;      // rows per gather batch: <= 32 registers of entries
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
 #pragma unroll
             for (int k = 0; k < M; ++k) {
               // address = byte * sizeof(FV) (one SDWA shift) + compile-time offset of table k (in the instruction)
-              constexpr int SH = 3;
+              constexpr int SH = sizeof(FV) == 16 ? 4 : 3;
               const uint32_t w32 = w[(r * M + k) >> 2];
               uint32_t boff;
               switch ((r * M + k) & 3) {
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
               e[r][k] = lds_abs_load<FV>(boff + (uint32_t)(CTRL_BYTES + k * 256 * sizeof(FV)));
             }
             if constexpr (BIAS) {      // the row-norm table, indexed by the row's norm byte
-              constexpr int SHN = 3;
+              constexpr int SHN = sizeof(FV) == 16 ? 4 : 3;
               uint32_t boff;
               switch (r & 3) {
                 case 0: boff = byte_shl<0, SHN>(nbw[u], shreg); break;
@@ -1235,7 +1235,7 @@ int scan_launch(const ScanPlan &pl, float *dists, uint32_t *ids, uint64_t *keys,
   // the bucket finish needs BF_NB words of LDS per query of the group in the (dead) table space
   // (below k = 16 a query holds a few dozen candidates: select + sort of those costs 2.4 % of a k = 1 scan, the bucket finish's fixed
   // work -- counters, the look, two votes -- 4.0 %)
-  p.bfin = (!pl.bigk && K >= 16 && (size_t)pl.scratch_keys * 8 >= (size_t)8 * (BF_NB * 4 + 64)) ? tuning("SCAN_BUCKET_FINISH", 1) : 0;     // (QG <= 8)
+  p.bfin = (!pl.bigk && K >= 16 && (size_t)pl.scratch_keys * 8 >= (size_t)pl.qg * (BF_NB * 4 + 64)) ? tuning("SCAN_BUCKET_FINISH", 1) : 0;
   p.filter = (lut_mode != LUT_LSQ && !row_bias && tuning("SCAN_FILTER", 1)) ? 1 : 0;
   p.norm_bytes = nullptr; p.norm_info = nullptr; p.cnorm = nullptr;
   if (lut_mode == LUT_LSQ && row_bias && norm_buf && (m == 8 || m == 16) && tuning("SCAN_FILTER", 1) &&

@@ -101,9 +101,14 @@ template <> __device__ __forceinline__ uint32_t lds_abs_load<uint32_t>(uint32_t 
 
 // dword j of a byte-table entry (4 queries per dword)
 __device__ __forceinline__ uint32_t fv_word(const uint2 &v, int j) { return j == 0 ? v.x : v.y; }
+__device__ __forceinline__ uint32_t fv_word(const uint4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
 template <int M> struct FiltVec;               // table entry: one byte per query of the group
+#if RQ_QG16
+template <> struct FiltVec<8> { using type = uint4; };    // experiment: 16 queries per ds_read_b128
+#else
 template <> struct FiltVec<8> { using type = uint2; };    // 8 queries per ds_read_b64
+#endif
 template <> struct FiltVec<16> { using type = uint2; };
 
 // per-entry clamp of the byte tables: (entries per byte sum) * clamp <= 255.  LSQ scans add the row-norm entry to the

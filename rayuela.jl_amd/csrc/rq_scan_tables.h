@@ -7,6 +7,11 @@
 #ifndef RQ_SCAN_PACE_BUILD
 #define RQ_SCAN_PACE_BUILD 0
 #endif
+// EXPERIMENT build (EXPERIMENTS.md 9.3): m = 8 scans with 16 queries per group -- byte tables of 16 queries read by ds_read_b128,
+// one 1024-thread workgroup per CU, half of the f32 tables through L1.  tools/build_variant.sh qg16 rq_scan.hip "-DRQ_QG16=1"
+#ifndef RQ_QG16
+#define RQ_QG16 0
+#endif
 
 namespace rq {
 
@@ -43,7 +48,7 @@ struct ScanCfg {
   // queries per LDS gather: a float4 entry (ds_read_b128) up to m = 32; m = 64 only fits the 160 KiB of
   // LDS with float2 entries (ds_read_b64, 2 queries per gather)
   static constexpr int QPG = (M <= 32) ? 4 : 2;
-  static constexpr int QG = (M <= 16) ? 8 : (M <= 32) ? 4 : 2;   // queries per group
+  static constexpr int QG = (RQ_QG16 && M == 8) ? 16 : (M <= 16) ? 8 : (M <= 32) ? 4 : 2;   // queries per group
   static constexpr int NQUAD = QG / QPG;                         // gathers per code byte
   // rows per thread per sub-step: ~32 gathers' worth, and a whole number of 16-byte code loads
   static constexpr int RPT = (32 / (M * NQUAD)) > (M < 16 ? 16 / M : 1) ? 32 / (M * NQUAD) : (M < 16 ? 16 / M : 1);
@@ -63,7 +68,7 @@ struct ScanCfg {
   // slots).  The vector-memory path can gather the same 16 bytes from an L1-resident table in ~29
   // cycles per wavefront (tools/micro/gather_l1.hip) and runs beside the LDS, so the LAST KG
   // sub-quantizers (~25 % of the gathers, <= 16 KiB of table) are looked up through L1 instead.
-  static constexpr int KG = (M == 8) ? 2 : (M == 16) ? 4 : (M == 32) ? 4 : (M == 4) ? 1 : 0;   // M = 64: all in LDS
+  static constexpr int KG = (M == 8) ? (RQ_QG16 ? 4 : 2) : (M == 16) ? 4 : (M == 32) ? 4 : (M == 4) ? 1 : 0;   // M = 64: all in LDS
   static constexpr int KL = M - KG;                 // sub-quantizers [0, KL) gather from LDS
   static constexpr int GTAB_F4 = KG * NQUAD * 256;  // entries (float4 for QPG = 4) of the global (L1) table
   static constexpr int LUT_LDS_BYTES = KL * QG * 1024;
