@@ -474,7 +474,7 @@ __global__ __launch_bounds__(ScanCfg<M>::THREADS, 4) void adc_scan_kernel(ScanPa
 
       // (norm-adding kernels with 32 gathers per row: one sub-step at a time -- with all U code words live next to a row's
       // 64 + 32 registers of table entries the allocator spilled the code words themselves, 160 registers in all)
-      constexpr int UCH = (BIAS && M * Cfg::NQUAD >= 32 && 4 < Cfg::U) ? 4 : Cfg::U;
+      constexpr int UCH = ((BIAS && M * Cfg::NQUAD >= 32 && 4 < Cfg::U) || (FILT && Cfg::U * RPT > 31)) ? 4 : Cfg::U;      // (m = 4: 4 rows per sub-step, one alive bit per row of a chunk)
 #pragma unroll 1
       for (int uc = 0; uc < Cfg::U; uc += UCH) {
       // the thread's rows of this block: U sub-steps of RPT rows, each one packed little-endian
@@ -955,7 +955,9 @@ static int launch_scan(ScanParams &p, const ScanPlan &plan, hipStream_t stream) 
   if constexpr (Cfg::HAS_FILT) {
     if (p.filter) { kern = adc_scan_kernel<M, false, true>; t_filt = true; }
     // LSQ (signed tables + row norms): the two-set byte sums (m = 8: 4 and 4 + 1 entries, m = 16: 8 and 8 + 1)
-    if (p.filter && p.row_bias) { kern = adc_scan_kernel<M, true, true, (M == 8)>; t_fine = (M == 8); }
+    if constexpr (M >= 8) {      // (m = 4: PQ / CQ tables only -- the LSQ preparation is written for the 8- and 16-byte tilings)
+      if (p.filter && p.row_bias) { kern = adc_scan_kernel<M, true, true, (M == 8)>; t_fine = (M == 8); }
+    }
     // m = 8, large k: the finer byte tables (6-bit entries, two sum sets) -- more VALU work per row, fewer rows for
     // the exact evaluation.  Measured at SIFT1M shape, coarse vs fine: k = 1 2.23 / 2.34 ms, k = 100 2.36 / 2.39,
     // k = 1000 2.91 / 2.91, k = 10000 6.62 / 6.26.

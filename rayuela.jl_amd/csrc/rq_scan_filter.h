@@ -110,11 +110,16 @@ template <> struct FiltVec<8> { using type = uint4; };    // experiment: 16 quer
 template <> struct FiltVec<8> { using type = uint2; };    // 8 queries per ds_read_b64
 #endif
 template <> struct FiltVec<16> { using type = uint2; };
+template <> struct FiltVec<4> { using type = uint2; };
 
 // per-entry clamp of the byte tables: (entries per byte sum) * clamp <= 255.  LSQ scans add the row-norm entry to the
 // LAST byte sum: 5 entries of <= 51 at m = 8 (two sets of 4 and 4 + 1), 9 of <= 28 at m = 16 (sets of 8 and 8 + 1)
 template <int M, bool FINE, bool LSQ>
-constexpr uint32_t filt_clamp() { return LSQ ? (M == 8 ? 51u : 28u) : (M == 8 ? filt_clamp8(FINE) : (M == 16 && filt_off16() ? (255u - filt_off16()) / 8u : FILT_CLAMP)); }
+constexpr uint32_t filt_clamp() {
+  return LSQ ? (M <= 8 ? 51u : 28u)
+             : (M == 4 ? (filt_off8(false) ? (255u - filt_off8(false)) / 4u : 63u)      // m = 4: ONE set of 4 entries (round 6)
+                : M == 8 ? filt_clamp8(FINE) : (M == 16 && filt_off16() ? (255u - filt_off16()) / 8u : FILT_CLAMP));
+}
 
 // row norm -> its quantisation cell's LOWER edge, with exactly these two rounded operations (the quantiser checks its
 // choice against the same expression, so EDGE(byte of a row) <= the row's norm holds in exact arithmetic)
@@ -130,7 +135,7 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
   using Cfg = ScanCfg<M>;
   constexpr int QG = Cfg::QG, NQUAD = Cfg::NQUAD, KL = Cfg::KL;
   static_assert(Cfg::QPG == 4, "pre-filter tiling: float4 table entries");
-  constexpr float THR = (float)(M == 8 ? filt_thr8(FINE) : FILT_THR16);
+  constexpr float THR = (float)(M <= 8 ? filt_thr8(FINE) : FILT_THR16);
   const int wave = tid >> 6, lane = tid & 63;
   auto entry = [&](int kk, int quad, int r) -> float4 {
     float4 v = kk < KL ? lut4[(kk * NQUAD + quad) * 256 + r] : gtab4[((kk - KL) * NQUAD + quad) * 256 + r];
@@ -256,7 +261,7 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
         const float x = diff * ctrl->finv[quad * 4 + c];
         w |= (uint32_t)fminf(fmaxf(x, 0.0f), (float)filt_clamp<M, FINE, LSQ>()) << (8 * c);   // float -> uint truncates = floor (x >= 0)
       }
-      if constexpr (M == 8 && !LSQ && filt_off8(FINE) != 0u) {
+      if constexpr (M <= 8 && !LSQ && filt_off8(FINE) != 0u) {
         if (kk == 0) w += filt_off8(FINE) * 0x01010101u;         // (clamp + offset <= 255: no carry between the bytes)
       }
       if constexpr (M == 8 && !LSQ && FINE && filt_off8_fine() != 0u) {
@@ -293,7 +298,7 @@ __device__ __forceinline__ void build_qtab(ScanCtrl<ScanCfg<M>::QG> *ctrl, const
 //   M = 16: two sets of 4 byte sums; per query A + B <= THR16  <=>  their per-byte average <= (THR16 - 1) / 2, same trick.
 template <int M, bool FINE, bool LSQ = false>
 __device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC * ScanCfg<M>::NQUAD]) {
-  if constexpr (M == 8) {
+  if constexpr (M <= 8) {
     // NQUAD dwords of 4 byte sums per set; FINE: two sets (k < 4, k >= 4), compared through their per-byte average
     constexpr int NQ = ScanCfg<M>::NQUAD;
     constexpr uint32_t H = 0x80808080u;
@@ -304,7 +309,7 @@ __device__ __forceinline__ bool filt_alive(const uint32_t (&a)[ScanCfg<M>::NACC 
       uint32_t v = a[j];
       if constexpr (FINE) v = (a[j] & a[NQ + j]) + (((a[j] ^ a[NQ + j]) >> 1) & 0x7f7f7f7fu);
       // THR = 127 (coarse tables): "sum <= THR" IS bit 7 of the byte sum -- no compare arithmetic at all
-      if constexpr (filt_bit7(FINE) || (FINE && !LSQ && filt_off8_fine() != 0u)) all &= v;
+      if constexpr ((filt_bit7(FINE) && !LSQ) || (FINE && !LSQ && filt_off8_fine() != 0u)) all &= v;
       else all &= ((v | H) - TC) | v;
     }
     return (all & H) != H;
@@ -342,7 +347,7 @@ __device__ __forceinline__ uint32_t high_bits4(uint32_t x) {   // bits 7, 15, 23
 template <int M, bool FINE, bool LSQ = false>
 __device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<M>::NACC * ScanCfg<M>::NQUAD]) {
   using Cfg = ScanCfg<M>;
-  if constexpr (M == 8) {
+  if constexpr (M <= 8) {
     constexpr int NQ = Cfg::NQUAD;
     constexpr uint32_t H = 0x80808080u;
     constexpr uint32_t TC = (FINE ? (filt_thr8(true) - 1u) / 2u + 1u : filt_thr8(false) + 1u) * 0x01010101u;
@@ -351,7 +356,7 @@ __device__ __forceinline__ uint32_t filt_alive_bits(const uint32_t (&a)[ScanCfg<
     for (int j = 0; j < NQ; ++j) {
       uint32_t v = a[j];
       if constexpr (FINE) v = (a[j] & a[NQ + j]) + (((a[j] ^ a[NQ + j]) >> 1) & 0x7f7f7f7fu);
-      if constexpr (filt_bit7(FINE) || (FINE && !LSQ && filt_off8_fine() != 0u)) bits |= high_bits4(~v) << (4 * j);
+      if constexpr ((filt_bit7(FINE) && !LSQ) || (FINE && !LSQ && filt_off8_fine() != 0u)) bits |= high_bits4(~v) << (4 * j);
       else bits |= high_bits4(~(((v | H) - TC) | v)) << (4 * j);
     }
     return bits;

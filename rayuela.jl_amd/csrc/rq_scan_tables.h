@@ -73,9 +73,9 @@ struct ScanCfg {
   static constexpr int GTAB_F4 = KG * NQUAD * 256;  // entries (float4 for QPG = 4) of the global (L1) table
   static constexpr int LUT_LDS_BYTES = KL * QG * 1024;
   // integer pre-filter (see build_qtab): one byte per (sub-quantizer, code, query); tiled for M = 8 and 16
-  static constexpr bool HAS_FILT = (M == 8 || M == 16) && SCAN_THREADS == 512;     // (the default build)
+  static constexpr bool HAS_FILT = (M == 4 || M == 8 || M == 16) && SCAN_THREADS == 512;     // (the default build; m = 4 since round 6: PQ / CQ tables only)
   // byte accumulator sets: 8 sub-quantizers each; m = 8 in FINE mode: two sets of 4 with 6-bit entries (half the step)
-  static constexpr int NACC = HAS_FILT ? (M == 8 ? 2 : M / 8) : 1;
+  static constexpr int NACC = HAS_FILT ? (M == 8 ? 2 : M >= 8 ? M / 8 : 1) : 1;
   static constexpr int kpa(bool fine) { return (M == 8 && fine) ? 4 : 8; }   // sub-quantizers per accumulator set
   static constexpr int QTAB_BYTES = HAS_FILT ? (M + 1) * 256 * QG : 0;   // + 1: the row-norm table of LSQ scans
   // scratch behind the staged queries: the threshold sample's [QG][THREADS] minima, later the filter table

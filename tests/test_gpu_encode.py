@@ -190,6 +190,24 @@ def test_split_encode_every_width_and_codebook_size(rq, oracle, sub, h):
     assert np.array_equal(got, ref) and np.array_equal(old, ref)
 
 
+@pytest.mark.parametrize("sub", [2, 4, 6, 8, 10, 12, 14, 16])
+def test_split_encode_more_sub_quantizers_than_one_launch_holds(rq, oracle, sub):
+    """every instantiated width with h < 256 and with MORE sub-quantizers than one launch group holds in LDS (gmax = 6 at
+    sub > 8, 9 below: m = 12 runs two i0 groups of the filter and of the exact pass), on clustered small-integer data that sends
+    a visible share of the pairs through the exact pass; ALL assignments against the oracle, both encode paths."""
+    rng = np.random.default_rng(7000 + sub)
+    m, h, n = 12, 200, 20_011
+    cent = rng.integers(0, 24, (64, m * sub)).astype(np.float32)
+    X = cent[rng.integers(0, 64, n)] + rng.integers(-2, 3, (n, m * sub)).astype(np.float32)
+    C = [np.ascontiguousarray(X[rng.choice(n, h, replace=False)][:, i * sub:(i + 1) * sub]) for i in range(m)]
+    rq.set_tuning("ENC_STATS", 1)
+    try:
+        got, old, ref = _enc_both(rq, oracle, X, C, m, h)
+    finally:
+        rq.set_tuning("ENC_STATS", 0)
+    assert np.array_equal(got, ref) and np.array_equal(old, ref)
+
+
 @pytest.mark.parametrize("waves", [8, 12, 16])
 @pytest.mark.parametrize("case", ["ties", "dups", "exact_hits", "tiny", "huge", "mixed_scale", "negative_w"])
 def test_split_encode_hostile_inputs(rq, oracle, case, waves):

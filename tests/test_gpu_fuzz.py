@@ -34,9 +34,9 @@ def test_scan_fuzz(rq, oracle, seed):
 
 
 @pytest.mark.parametrize("style", range(7))
-@pytest.mark.parametrize("m,K", [(8, 10), (8, 1000), (16, 100)])
+@pytest.mark.parametrize("m,K", [(8, 10), (8, 1000), (16, 100), (4, 10), (4, 1000)])
 def test_scan_prefilter_on_hostile_tables(rq, oracle, style, m, K):
-    """Shapes that run the integer pre-filter (m in {8, 16}, rows >= 64 k) on tables built to break a lower-bound
+    """Shapes that run the integer pre-filter (m in {4, 8, 16}, rows >= 64 k) on tables built to break a lower-bound
     filter: no contrast, one dominating sub-quantizer, massive ties, few distinct rows, a large common offset
     (tau ~ sum of the table minima), high contrast.  The filter may only ever cost time: ids and distance bits
     must equal the reference's."""
@@ -71,6 +71,8 @@ def test_scan_prefilter_on_hostile_tables(rq, oracle, style, m, K):
     finally:
         rq.set_tuning("SCAN_FILTER", 1)
     assert np.array_equal(i1, i2) and _eq_bits(d1, d2)
+    from rayuela_jl_amd import _lib
+    assert (_lib.lib().rq_last_scan_kernel() or b"").decode().startswith("adc_scan_kernel<%d, false, false" % m)      # the knob did switch it off
     if m == 8:
         # ... and with the other byte-table variant (6-bit entries, two sum sets: the library's choice for k >= 8192)
         rq.set_tuning("SCAN_FINE_MIN_K", 1)
