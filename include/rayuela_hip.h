@@ -121,8 +121,9 @@ int rq_dev_encode_rvq(uint8_t *codes, float *Xr, const float *codebooks, int64_t
  * per device; rq_linscan_* then shard the base (see the index handle below). */
 /* linscan_pq (src/Linscan.jl:5-26).  id_base = 1 folds Julia's `res .+= 1` into the kernel.
  * Supported row widths: 1 <= m <= 64 (other widths are zero-padded to 2, 4, 8, 16, 32 or 64).  The integer pre-filter that
- * carries the BASELINE shapes (m = 8: 2.5 ms, m = 16: 5.2 ms for 1e6 rows x 1e4 queries, k = 1000) exists for the 8- and
- * 16-byte tilings only; m = 32 / 64 run the exact f32 loop (m = 32: 24.6 ms at that size) -- same answers, not tuned. */
+ * carries the BASELINE shapes exists for the 4-, 8- and 16-byte tilings (round-6 figures, 1e6 rows x 1e4 queries, k = 1000, resident:
+ * m = 8: 1.9 ms, m = 16: 4.6 ms, m = 4: 1.3 ms); m = 2, 32 and 64 run the exact f32 loop (m = 32: 4.9 ms for
+ * 5e5 rows x 4096 queries) -- same answers, not tuned. */
 int rq_linscan_pq(float *dists, uint32_t *ids, const uint8_t *codes, const float *centers,
                   const float *queries, int64_t n, int64_t nq, int m, int d, int k, int id_base);
 /* Non-finite inputs (every scan entry point; tests/test_gpu_nonfinite.py).  The reference builds its table and its distances in

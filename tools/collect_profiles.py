@@ -11,7 +11,7 @@ import re
 import shutil
 import sys
 
-RND = sys.argv[1] if len(sys.argv) > 1 else "r5"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r6"
 O = "gpurun_out/" + RND
 for f in ("bench_pq", "bench_opq", "bench_deep", "bench_pq_k10000", "bench_sift1b_1gpu", "bench_sift1b_shard", "bench_sift1b_inproc", "bench_train_opq", "bench_train_pq", "bench_sift1b_2ranks_gloo"):
     if os.path.exists("%s/%s.json" % (O, f)):
@@ -23,9 +23,13 @@ for w in ("pq", "opq", "deep", "k10000", "sift1b", "sift1b_shard", "train_opq"):
     rows = list(csv.reader(open(g[0])))
     csv.writer(open("profiles/%s_bench_%s_kernel_stats.csv" % (RND, w), "w")).writerows([rows[0]] + [r for r in rows[1:] if "rq::" in r[0]])
 shutil.copy(O + "/pmc_summary.txt", "profiles/%s_pmc_counters.md" % RND)
+for extra in ("phase_clock.md", "m4_filter.md", "shape_sweep.md"):
+    if os.path.exists(O + "/" + extra):
+        shutil.copy(O + "/" + extra, "profiles/%s_%s" % (RND, extra))
 if os.path.exists(O + "/index_overhead.md"):
     shutil.copy(O + "/index_overhead.md", "profiles/%s_index_overhead.md" % RND)
 shape = {"pmc_FETCH_SIZE": "adc_scan_kernel<8> n=1000000 nq=10000 k=1000", "pmc_WRITE_SIZE": "adc_scan_kernel<8> n=1000000 nq=10000 k=1000",
+         "pmc_k10000_FETCH_SIZE": "adc_scan_kernel<8> n=1000000 nq=10000 k=10000", "pmc_k10000_WRITE_SIZE": "adc_scan_kernel<8> n=1000000 nq=10000 k=10000",
          "pmc_deep_FETCH_SIZE": "adc_scan_kernel<16> n=1000000 nq=10000 k=1000", "pmc_deep_WRITE_SIZE": "adc_scan_kernel<16> n=1000000 nq=10000 k=1000",
          "pmc_sift1b_FETCH_SIZE": "adc_scan_kernel<8> n=1000000000 nq=1024 k=100", "pmc_sift1b_WRITE_SIZE": "adc_scan_kernel<8> n=1000000000 nq=1024 k=100",
          "pmc_shard_FETCH_SIZE": "adc_scan_kernel<8> n=125000000 nq=1024 k=100", "pmc_shard_WRITE_SIZE": "adc_scan_kernel<8> n=125000000 nq=1024 k=100"}

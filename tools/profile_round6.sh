@@ -52,6 +52,7 @@ for t in "pq:" "k10000:--k 10000" "deep:--workload deep"; do
   RQ_SCAN_STATS=1 python bench.py ${t#*:} --no-cpu --no-host --no-ref1 --no-ab --steps 3 2> $O/phase_${t%%:*}.err > /dev/null
 done
 python tools/phase_clock.py $O > $O/phase_clock.md
+( echo "# m = 4: the integer pre-filter on / off (tools/m4_filter_ab.py; random codes, Gaussian tables; resident; HIP events)"; echo; echo '```'; python tools/m4_filter_ab.py 2>/dev/null; echo '```' ) > $O/m4_filter.md
 cd /tmp
 if [ "$1" != "quick" ]; then
 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq1 -o p -- python $R/bench.py --no-cpu --no-host --no-ref1 --no-ab --steps 3 > /dev/null 2>&1
