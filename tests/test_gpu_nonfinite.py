@@ -32,6 +32,7 @@ SHAPES = [
     (120_000, 16, 2, 21, 100),     # m = 16: the 1024-thread kernel
     (40_000, 8, 4, 13, 4096),      # large k: sample-sort finish
     (3_000, 8, 4, 13, 50),         # short base: no sampled threshold
+    (200_000, 4, 4, 21, 100),      # m = 4: the pre-filter of round 6
 ]
 
 
@@ -57,7 +58,7 @@ def test_non_finite_queries(rq, oracle, n, m, sub, nq, K):
 def test_non_finite_table_entries(rq, oracle, n, m, sub, nq, K):
     centers, queries, codes = _case(43, n, m, sub, nq)
     centers[2, 77, 1] = np.nan           # rows with code 77 in position 2: NaN distance to every query
-    centers[5, 3, 0] = np.inf            # rows with code 3 in position 5: +Inf distance to every query
+    centers[m - 3, 3, 0] = np.inf        # rows with code 3 in position m - 3: +Inf distance to every query
     centers[0, 200, sub - 1] = -np.inf
     d1, i1 = rq.linscan_aqd_query(codes, centers, queries, K)
     keep = np.flatnonzero(codes[:, 2] != 77)
