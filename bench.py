@@ -477,10 +477,21 @@ def main():
             # queries, below k = 8192: rq_scan_orders_in_call) -- at the reference's default k = 10000 it scans the rows as they
             # arrive, and so does this leg (round 5 timed an ordered base there: kernel_ms > ms_per_step)
             from rayuela_jl_amd import _lib as _lo
-            in_call = bool(_lo.lib().rq_scan_orders_in_call(n_local, nq, kl))
-            ordered = rqd.order_rows(codes) if in_call and os.environ.get("RQ_SCAN_ORDER", "1") != "0" else codes
-        kern_base = ("bank-aware row order (what the timed call scans: ordered inside the call, or once by the index)"
-                     if ordered is not codes else "arrival order (what the timed call scans at this shape: no in-call ordering)")
+            in_call = int(_lo.lib().rq_scan_orders_in_call(n_local, nq, kl))     # 0 arrival order, 1 sorted, 2 sorted + balanced
+            if in_call and os.environ.get("RQ_SCAN_ORDER", "1") != "0":
+                # (a base ordered ONCE is always balanced -- the greedy pass of rq_order.hip --; a call that orders its own
+                # copy balances it only from 16384 queries on: this leg orders the way the timed call does)
+                rq.set_tuning("ORDER_GREEDY", 1 if in_call == 2 else 0)
+                ordered = rqd.order_rows(codes)
+                rq.set_tuning("ORDER_GREEDY", 1)
+            else:
+                ordered = codes
+        if ordered is codes:
+            kern_base = "arrival order (what the timed call scans at this shape: no in-call ordering)"
+        elif world == 1 and not big and in_call == 1:
+            kern_base = "bank-aware row order, sorted not balanced (what the timed call scans: it orders its own copy, and at this batch size without the greedy balance)"
+        else:
+            kern_base = "bank-aware row order, sorted and balanced (what the timed call scans: ordered inside the call, or once by the index)"
         kern_total, _ = timed(lambda: rqd.linscan(ordered, centers, Qs, kl, id_offset=r0, want_keys=True, out=kout), ks, 1, barrier)
         kern_ms = kern_total / ks
         if world == 1 and not big and ordered is not codes and not a.no_ab:
@@ -489,7 +500,8 @@ def main():
             #   prepared  = the base ordered once (index handle / rq_dev_order_rows), searches pay nothing for it
             #   arrival   = ordering switched off (round 3's path)
             o2 = (torch.empty((nq, K), dtype=torch.float32, device=device), torch.empty((nq, K), dtype=torch.int32, device=device))
-            prep_ms, _ = timed(lambda: rqd.linscan(ordered, centers, Qs, K, out=o2), a.steps, a.warmup, barrier)
+            prepared = rqd.order_rows(codes)          # ordered ONCE: sorted and balanced, whatever the batch size
+            prep_ms, _ = timed(lambda: rqd.linscan(prepared, centers, Qs, K, out=o2), a.steps, a.warmup, barrier)
             same_prep = bool(torch.equal(o2[0].view(torch.int32), res["r"][0].view(torch.int32)) and torch.equal(o2[1], res["r"][1]))
             ord_ms, _ = timed(lambda: rqd.order_rows(codes), 3, 1, barrier)
             rq.set_tuning("SCAN_ORDER", 0)
@@ -498,13 +510,16 @@ def main():
             same_arr = bool(torch.equal(o2[0].view(torch.int32), res["r"][0].view(torch.int32)) and torch.equal(o2[1], res["r"][1]))
             order_info = {
                 "what": "bank-aware row order of the base (csrc/rq_order.hip): rows sorted by the top 3 bits of their leading code "
-                        "bytes so that the 32 lanes of an LDS table gather hit distinct bank columns; ids stay original row numbers",
+                        "bytes so that the 32 lanes of an LDS table gather hit distinct bank columns; a base that is ordered ONCE "
+                        "(prepared: index handles, rq_dev_order_rows) is also balanced -- the rows of a sort bucket are dealt to its "
+                        "lane groups so that the uncovered tables' columns fill evenly --, a call that orders its own copy does that "
+                        "from 16384 queries on (it costs 0.11 ms per 1e6 rows); ids stay original row numbers",
                 "in_call_ms_per_step": round(scan_ms / a.steps, 4),
                 "prepared_ms_per_step": round(prep_ms / a.steps, 4), "prepared_value": round(nq / (prep_ms / a.steps * 1e-3), 1),
                 "order_rows_ms_once": round(ord_ms / 3, 4),
                 "arrival_order_ms_per_step": round(arr_ms / a.steps, 4), "arrival_order_value": round(nq / (arr_ms / a.steps * 1e-3), 1),
                 "answers_identical": bool(same_prep and same_arr)}
-            del o2
+            del o2, prepared
         del ordered
 
     vals = [scan_ms, enc_ms or 0.0, scan_wall, kern_ms or 0.0]

@@ -429,7 +429,9 @@ int dev_linscan(float *dists, uint32_t *ids, uint64_t *keys, const uint8_t *code
     const uint8_t *ocodes = codes;
     const uint32_t *operm = nullptr;
     int orc = workspace(WS_ORDER, order_base_bytes(n, mp), &ord, stream);
+    order_set_call_queries(nq);      // (the greedy balance of the order costs more than the sort: only for batches it pays for)
     if (orc == RQ_OK) orc = order_base(&ocodes, &operm, ord, codes, n, mp, stream);
+    order_set_call_queries(0);
     if (orc == RQ_OK) {
       codes = ocodes;
       perm = operm;
@@ -823,9 +825,11 @@ int rq_scan_plan(int64_t n, int64_t nq, int m, int d, int k, int num_cu, int64_t
 
 int rq_scan_orders_in_call(int64_t n, int64_t nq, int k) {
   // would a raw-pointer scan of this shape (rq_dev_linscan / rq_linscan_pq, PQ tables) order a scratch copy of the base itself?
-  return order_pays(n, nq, k) &&
-                 order_base_bytes(n, 8) + (size_t)n * 4 <= (size_t)std::max(0, tuning("ORDER_MAX_SCRATCH_MB", 2048)) * 1048576ull
-             ? 1 : 0;
+  // 2: ... and balance it (greedy pass of rq_order.hip: from ORDER_GREEDY_MIN_NQ queries on)
+  if (!(order_pays(n, nq, k) &&
+        order_base_bytes(n, 8) + (size_t)n * 4 <= (size_t)std::max(0, tuning("ORDER_MAX_SCRATCH_MB", 2048)) * 1048576ull))
+    return 0;
+  return tuning("ORDER_GREEDY", 1) && nq >= tuning("ORDER_GREEDY_MIN_NQ", 16384) ? 2 : 1;
 }
 
 int rq_scan_stats(unsigned long long *out8) {
@@ -1313,6 +1317,13 @@ int rq_order_plan(int64_t n, int m, int *out, int cap) {
   const int total = order_key_bits(n, mp, ot, nb);
   for (int c = 0; c < 8; ++c) out[c] = nb[c];
   out[8] = total; out[9] = ot.group; out[10] = ot.gran; out[11] = mp;
+  if (cap >= 14) {          // [12] tables the greedy balance deals over (0: plain sort), [13] wavefronts per workgroup that balance
+    uint32_t gp[4] = {0, 0, 0, 0};
+    const int64_t ns = n - order_sample_rows(n, ot.blk, nullptr);
+    const bool on = total > 0 && order_greedy_plan(ns, mp, total + 3, gp) && tuning("ORDER_BITS", 0) <= 0;
+    out[12] = on ? (int)gp[0] : 0;
+    out[13] = on ? (int)gp[1] : 0;
+  }
   return RQ_OK;
 }
 

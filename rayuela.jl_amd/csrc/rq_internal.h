@@ -118,6 +118,8 @@ int order_base(const uint8_t **out_codes, const uint32_t **out_perm, void *dst, 
 // ---- bank-aware row order (rq_order.hip) ---------------------------------------------------------
 struct OrderTiling { int rpt, gran, group, cbits, blk; };                    // see scan_order_tiling (rq_scan.hip)
 void scan_order_tiling(int mp, OrderTiling *t);
+void order_set_call_queries(int64_t nq);   // > 0: the ordering that follows serves ONE scan of nq queries (greedy balance only if it pays)
+bool order_greedy_plan(int64_t n, int mp, int budget, uint32_t out[4]);
 int order_key_bits(int64_t n, int mp, const OrderTiling &t, int nb[8]);  // key layout; returns the total bits (0: no ordering)
 size_t order_scratch_bytes(int64_t n, int total_bits);
 int order_sample_stride();                                               // ORDER_SAMPLE_STRIDE (16; < 2: no sample blocks)

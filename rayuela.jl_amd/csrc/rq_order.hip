@@ -53,6 +53,10 @@ struct OrderParams {
   uint32_t stride, blk, sgroups;
   uint32_t rnd_rows;      // sample rows in all: sgroups * blk
   uint32_t nsorted;       // n - rnd_rows
+  // GREEDY BALANCE (round 6, order_fine_greedy_kernel): the tables the sort key does not cover, LDS budget
+  int gfree;              // number of free tables: the row's last 4 (8-byte rows) or 12 (16-byte rows) bytes; 0: plain order
+  uint32_t glist;         // rows of a coarse bucket the LDS list holds (a bigger bucket takes the plain path)
+  uint32_t gwaves;        // wavefronts of the workgroup that balance (LDS: 16 groups x gfree tables x 64 bytes each)
 };
 
 // Is row i a sample row?  It is sample row number i / stride.
@@ -290,6 +294,168 @@ __global__ __launch_bounds__(ORDER_SMALL_THREADS) void order_fine_kernel(OrderPa
   }
 }
 
+
+// ---- round 6: balance the rows of a sort bucket over the bucket's lane groups -------------------------------------------------
+// The sort key makes the gathers of the tables it covers conflict-free and leaves the others at 3.15 passes (32 random bytes in
+// 32 columns).  But a bucket of the 12-bit key holds ~8 lane groups' worth of rows (244 at 1e6 rows), and WHICH of them share a
+// group is still free.  One wavefront per fine bucket deals the bucket's rows to its groups one by one (arrival order): the row
+// goes to the group -- among those with room -- where it adds the least to sum over the free tables of (column load)^2; a row whose
+// byte equals the last one stored in that column is free (same address: broadcast).  Measured on the bench codes (host probe,
+// tools/greedy_order_probe.py): passes per row and lane group 15.5 -> 12.7 at m = 8 (the four free tables 3.15 -> 2.13 each),
+// 40.7 -> 33.2 at m = 16; scan kernel k = 1 / 1000: m = 8 -8.0 / -4.0 %, m = 16 -9.1 / -6.6 %.  Any result is a permutation, so the
+// scan's answer cannot depend on it (tests/test_gpu_order.py).
+// Lanes: 16 groups x 4 lanes, lane (g, q) prices the free tables q, q + 4, q + 8 (the minimum over the groups is a DPP reduction).
+// Buckets are cut at multiples of 512 sorted
+// ranks (16 groups); a group shared with the neighbouring bucket takes part with the slots this bucket owns in it.
+constexpr uint32_t GREEDY_GROUPS = 16;
+
+__device__ __forceinline__ uint32_t dpp_quad_sum(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+  return v;
+}
+// minimum over the wavefront (unsigned), in every lane's return value: row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then
+// row_bcast 15 / 31 across them (GFX9 DPP); the lanes a shift does not reach keep the identity
+__device__ __forceinline__ uint32_t dpp_wave_min(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xa, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xc, 0xf, false));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// One chunk [c0, c1) of sorted ranks (inside one fine bucket, inside one 512-rank window): deal its rows to its lane groups.
+// list: the coarse bucket's row numbers in fine-sorted order, list[s - b0] = row of sorted rank s; st: this wave's LDS state,
+// [16 groups][T][32 columns] of {rows in the column, last byte stored there} as one 16-bit word.  MP = row bytes, TPL = tables
+// per lane: the free tables are the last T = 4 * TPL bytes of the row, lane (g, q) prices bytes MP - T + q + 4 i (i < TPL), which
+// sit in word (MP - T) / 4 + i of the row at byte q.
+template <int MP, int TPL>
+__device__ __forceinline__ void greedy_chunk(const OrderParams &p, const uint32_t *list, uint32_t b0, uint32_t c0, uint32_t c1,
+                                             uint16_t *st) {
+  constexpr uint32_t T = 4u * TPL, W0 = (MP - (int)T) / 4, NW = MP / 4;
+  const uint32_t lane = threadIdx.x & 63u, gl = lane >> 2, q4 = lane & 3u;
+  const uint32_t grp = p.group;
+  const uint32_t g_first = c0 / grp, ng = (c1 - 1u) / grp - g_first + 1u, R = c1 - c0;
+  if (ng < 2u || R < 4u) {          // nothing to choose
+    for (uint32_t i = lane; i < R; i += 64u) order_copy_row(p, list[c0 - b0 + i], order_deal(p, c0 + i));
+    return;
+  }
+  for (uint32_t i = lane; i < GREEDY_GROUPS * T * 32u / 2u; i += 64u) reinterpret_cast<uint32_t *>(st)[i] = 0u;
+  const uint32_t glo = max(c0, (g_first + gl) * grp), ghi = min(c1, (g_first + gl + 1u) * grp);
+  const uint32_t cap = (gl < ng && ghi > glo) ? ghi - glo : 0u;
+  uint32_t next = glo;                 // the next free rank of this lane's group
+  const uint32_t sh = 8u * q4;
+  uint16_t *mine_st = st + (gl * T + q4) * 32u;          // table i of this lane: + i * 4 * 32
+  __builtin_amdgcn_wave_barrier();
+  // rows travel in batches of 64, one per lane, and are broadcast from there; the next batch is in flight during the deal
+  uint32_t row = list[c0 - b0 + min(lane, R - 1u)];
+  uint32_t w[NW];
+  auto load_words = [&](uint32_t r, uint32_t (&o)[NW]) {
+    const uint8_t *r8 = p.src + (size_t)r * MP;
+    if constexpr (MP == 16) { const uint4 v = *reinterpret_cast<const uint4 *>(r8); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    else { const uint2 v = *reinterpret_cast<const uint2 *>(r8); o[0] = v.x; o[1] = v.y; }
+  };
+  load_words(row, w);
+  for (uint32_t b = 0; b < R; b += 64u) {
+    const bool have = b + lane < R;
+    const uint32_t nb = min(64u, R - b);
+    uint32_t row_n = row, w_n[NW];
+    if (b + 64u < R) row_n = list[c0 - b0 + min(b + 64u + lane, R - 1u)];
+    load_words(row_n, w_n);
+    uint32_t myrank = c0 + b + lane;
+    for (uint32_t j = 0; j < nb; ++j) {
+      uint32_t cost = 0, val[TPL], x[TPL];
+      bool fresh[TPL];
+#pragma unroll
+      for (int i = 0; i < TPL; ++i) {
+        const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane((int)w[W0 + i], (int)j);      // word W0 + i of row j (uniform)
+        val[i] = (cw >> sh) & 255u;
+        x[i] = mine_st[i * 128 + (val[i] & 31u)];
+      }
+#pragma unroll
+      for (int i = 0; i < TPL; ++i) {
+        const uint32_t c = x[i] & 255u;
+        fresh[i] = !(c != 0u && (x[i] >> 8) == val[i]);
+        cost += fresh[i] ? 2u * c + 1u : 0u;
+      }
+      cost = dpp_quad_sum(cost);
+      cost = (next < ghi && cap != 0u) ? min(cost, 1022u) : 1023u;
+      const uint32_t best = dpp_wave_min((cost << 6) | lane);          // the cheapest group, lowest lane first
+      const uint32_t wl = best & 63u;
+      const uint32_t newrank = (uint32_t)__builtin_amdgcn_readlane((int)next, (int)wl);
+      if (gl == (wl >> 2)) {
+#pragma unroll
+        for (int i = 0; i < TPL; ++i)
+          mine_st[i * 128 + (val[i] & 31u)] = (uint16_t)(((x[i] & 255u) + (fresh[i] ? 1u : 0u)) | (val[i] << 8));
+        next += 1u;
+      }
+      myrank = lane == j ? newrank : myrank;
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (have) order_copy_row(p, row, order_deal(p, myrank));
+    row = row_n;
+#pragma unroll
+    for (uint32_t i = 0; i < NW; ++i) w[i] = w_n[i];
+  }
+}
+
+__global__ __launch_bounds__(ORDER_SMALL_THREADS) void order_fine_greedy_kernel(OrderParams p, OrderSmall q) {
+  __shared__ uint32_t f[ORDER_FINE_MAX], fst[ORDER_FINE_MAX + 1], starts[ORDER_COARSE + 1], wsum[16];
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];         // [glist] row list | [gwaves] balance state
+  const uint32_t tid = threadIdx.x, nfine = 1u << q.fine_bits, fmask = nfine - 1u;
+  for (uint32_t i = tid; i < nfine; i += ORDER_SMALL_THREADS) f[i] = 0;
+  coarse_starts(starts, q.ctot);
+  const uint32_t b0 = starts[blockIdx.x], b1 = starts[blockIdx.x + 1];
+  const bool fits = b1 - b0 <= p.glist;
+  for (uint32_t i = b0 + tid; i < b1; i += ORDER_SMALL_THREADS) atomicAdd(&f[order_key_of(p, q.idx[i]) & fmask], 1u);
+  __syncthreads();
+  {   // exclusive scan of the <= 1024 fine counts: one per thread
+    const uint32_t v = tid < nfine ? f[tid] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off);
+      if ((tid & 63u) >= (uint32_t)off) x += y;
+    }
+    if ((tid & 63u) == 63u) wsum[tid >> 6] = x;
+    __syncthreads();
+    uint32_t wb = 0;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) wb += wsum[w];
+    if (tid < nfine) { f[tid] = b0 + wb + x - v; fst[tid] = b0 + wb + x - v; }
+    if (tid == nfine - 1u) fst[nfine] = b0 + wb + x;
+    __syncthreads();
+  }
+  if (!fits) {        // a coarse bucket too big for the LDS list (clumped data): the plain order of the (shorter) key
+    for (uint32_t i = b0 + tid; i < b1; i += ORDER_SMALL_THREADS) {
+      const uint32_t row = q.idx[i];
+      const uint32_t s = atomicAdd(&f[order_key_of(p, row) & fmask], 1u);
+      order_copy_row(p, row, order_deal(p, s));
+    }
+    return;
+  }
+  uint32_t *list = dyn;
+  for (uint32_t i = b0 + tid; i < b1; i += ORDER_SMALL_THREADS) {
+    const uint32_t row = q.idx[i];
+    list[atomicAdd(&f[order_key_of(p, row) & fmask], 1u) - b0] = row;
+  }
+  __syncthreads();
+  const uint32_t wave = tid >> 6;
+  if (wave >= p.gwaves) return;
+  uint16_t *st = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(dyn + p.glist) + (size_t)wave * GREEDY_GROUPS * (uint32_t)p.gfree * 64u);
+  const uint32_t window = GREEDY_GROUPS * p.group;
+  for (uint32_t fb = wave; fb < nfine; fb += p.gwaves) {
+    const uint32_t s0 = fst[fb], s1 = fst[fb + 1];
+    for (uint32_t c0 = s0; c0 < s1;) {
+      const uint32_t c1 = min(s1, (c0 / window + 1u) * window);
+      if (p.mp == 8) greedy_chunk<8, 1>(p, list, b0, c0, c1, st);
+      else greedy_chunk<16, 3>(p, list, b0, c0, c1, st);
+      c0 = c1;
+    }
+  }
+}
+
 static uint32_t gcd_u32(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
 
 // Key layout for n rows of mp bytes: `cbits` bits per leading code byte (the window 256 >> cbits = the bank columns one
@@ -317,6 +483,32 @@ uint32_t order_sample_rows(int64_t n, int blk, uint32_t *sgroups) {
   return g * (uint32_t)blk;
 }
 
+// Does the greedy balance run for a base of n (sorted) rows of mp bytes whose full key would have `budget` bits?  Rows of 4, 8 or
+// 16 bytes, the two-level path with at least 4 fine bits left after the key gives up 3, and coarse buckets (n / 256 rows) that fit
+// the LDS list with room for skew.  out: {free tables, balancing wavefronts, list capacity (rows), dynamic LDS bytes}.
+// A raw-pointer scan that orders its own scratch copy pays for the balance on EVERY call (0.11 ms per 1e6 rows of 8 bytes, 0.31 ms
+// of 16 bytes, against 0.06 for the plain sort) and gains ~4-6 % of its scan: it pays from ORDER_GREEDY_MIN_NQ queries on (16384;
+// measured at 1e4 queries: m = 8 +0.4 ... +2 %, m = 16 -0.7 ... +0.1 %).  dev_linscan announces its batch here; bases that are
+// ordered ONCE (index handles, rq_dev_order_rows, ShardedIndex) leave it at 0 and always balance.
+static thread_local int64_t g_order_call_nq = 0;
+void order_set_call_queries(int64_t nq) { g_order_call_nq = nq; }
+
+bool order_greedy_plan(int64_t n, int mp, int budget, uint32_t out[4]) {
+  if (!tuning("ORDER_GREEDY", 1) || !tuning("ORDER_TWO_LEVEL", 1) || tuning("ORDER_CBITS", 0) > 0) return false;
+  if (g_order_call_nq > 0 && g_order_call_nq < tuning("ORDER_GREEDY_MIN_NQ", 16384)) return false;
+  if (mp != 8 && mp != 16) return false;
+  const int total = budget - 3;
+  if (total < 12 || total > 18) return false;      // (>= 4 tables under the key: the free tables are the row's last 4 / 12 bytes)
+  const int gfree = mp == 8 ? 4 : 12;
+  const size_t state = (size_t)GREEDY_GROUPS * gfree * 64;        // per balancing wavefront
+  const size_t lds_max = 160 * 1024 - 12 * 1024;                 // static arrays of the kernel: ~9.5 KiB
+  const size_t list_rows = (size_t)(n / 256) * 3 / 2 + 1024;     // 1.5 x the mean coarse bucket
+  if (list_rows * 4 + state * 4 > lds_max) return false;
+  const uint32_t waves = (uint32_t)std::min<size_t>(16, (lds_max - list_rows * 4) / state);
+  if (out) { out[0] = (uint32_t)gfree; out[1] = waves; out[2] = (uint32_t)list_rows; out[3] = (uint32_t)(list_rows * 4 + waves * state); }
+  return true;
+}
+
 int order_key_bits(int64_t n, int mp, const OrderTiling &t, int nb[8]) {
   for (int c = 0; c < 8; ++c) nb[c] = 0;
   if (n < 1024) return 0;
@@ -327,6 +519,9 @@ int order_key_bits(int64_t n, int mp, const OrderTiling &t, int nb[8]) {
   const int nc = std::min(mp, 8);
   int cb = tuning("ORDER_CBITS", 0);
   if (cb <= 0) cb = t.cbits;
+  // round 6: where the greedy balance runs (order_greedy_plan) the key gives up one table's bits -- the buckets it leaves hold
+  // ~8 lane groups of rows, and balancing those over ALL uncovered tables beats one more conflict-free table (15.5 -> 12.7 passes)
+  if (order_greedy_plan(n, mp, budget, nullptr)) budget -= cb;
   int total = 0;
   for (int c = 0; c < nc && total < budget; ++c) { nb[c] = std::min(cb, budget - total); total += nb[c]; }
   // narrow rows (m <= 4): more bits per byte once every byte has its window
@@ -347,6 +542,15 @@ int order_rows_launch(uint8_t *dst, uint32_t *perm, const uint8_t *src, int64_t 
   const int rpt = t.rpt, gran = t.gran;
   const int total = order_key_bits(n, mp, t, p.nb);
   if (total <= 0 || total > 24) return fail(RQ_EINVAL, "order_rows: nothing to order (n=%lld)", (long long)n);
+  p.gfree = 0; p.gwaves = 0; p.glist = 0;
+  bool greedy_on = false;
+  {   // did order_key_bits shorten the key for the greedy balance?  (same arithmetic: the budget of the sorted rows)
+    const int64_t ns = n - order_sample_rows(n, t.blk, nullptr);
+    int budget = tuning("ORDER_BITS", 0);
+    if (budget <= 0) budget = (int)std::floor(std::log2((double)ns / (double)t.group) + 0.5);
+    budget = std::min(budget, 24);
+    greedy_on = order_greedy_plan(ns, mp, budget, nullptr) && total == budget - 3;
+  }
   p.src = src; p.dst = dst; p.perm = perm;
   p.n = (uint32_t)n; p.mp = mp;
   p.ncoord = 0;
@@ -380,7 +584,17 @@ int order_rows_launch(uint8_t *dst, uint32_t *perm, const uint8_t *src, int64_t 
     RQ_HIP(hipMemsetAsync(q.ctot, 0, 2 * ORDER_COARSE * 4, stream));
     hipLaunchKernelGGL(order_coarse_count_kernel, dim3(nwg), dim3(ORDER_SMALL_THREADS), 0, stream, p, q);
     hipLaunchKernelGGL(order_coarse_scatter_kernel, dim3(nwg), dim3(ORDER_SMALL_THREADS), 0, stream, p, q);
-    hipLaunchKernelGGL(order_fine_kernel, dim3(ORDER_COARSE), dim3(ORDER_SMALL_THREADS), 0, stream, p, q);
+    uint32_t gp[4];
+    if (greedy_on && order_greedy_plan((int64_t)p.nsorted, mp, total + 3, gp)) {
+      // the free tables: the last gfree bytes of the row (the key covers the leading ones; a partly covered byte is balanced too)
+      p.gfree = (int)gp[0];
+      p.gwaves = gp[1]; p.glist = gp[2];
+      RQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(order_fine_greedy_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)gp[3]));
+      hipLaunchKernelGGL(order_fine_greedy_kernel, dim3(ORDER_COARSE), dim3(ORDER_SMALL_THREADS), gp[3], stream, p, q);
+    } else {
+      hipLaunchKernelGGL(order_fine_kernel, dim3(ORDER_COARSE), dim3(ORDER_SMALL_THREADS), 0, stream, p, q);
+    }
     RQ_HIP(hipGetLastError());
     return RQ_OK;
   }

@@ -116,16 +116,28 @@ def test_order_plan_host_logic():
     L = _lib.lib()
 
     def plan(n, m):
-        out = (C.c_int * 12)()
-        assert L.rq_order_plan(n, m, C.cast(out, C.c_void_p), 12) == 0
+        out = (C.c_int * 14)()
+        assert L.rq_order_plan(n, m, C.cast(out, C.c_void_p), 14) == 0
         return list(out)
 
+    # round 6: where the greedy balance runs (8- and 16-byte rows, two-level sort) the key gives up one table's bits and the rows
+    # of a sort bucket are dealt over its lane groups by the uncovered tables: 12 bits + 4 tables at SIFT1M shape
     p = plan(1_000_000, 8)
-    assert p[:8] == [3, 3, 3, 3, 3, 0, 0, 0] and p[8] == 15 and p[9] == 32 and p[11] == 8
+    assert p[:8] == [3, 3, 3, 3, 0, 0, 0, 0] and p[8] == 12 and p[9] == 32 and p[11] == 8 and p[12] == 4 and p[13] == 16
+    from rayuela_jl_amd import set_tuning
+    set_tuning("ORDER_GREEDY", 0)
+    try:
+        p = plan(1_000_000, 8)
+        assert p[:8] == [3, 3, 3, 3, 3, 0, 0, 0] and p[8] == 15 and p[12] == 0
+        assert plan(1_000_000, 16)[:8] == [3, 3, 3, 3, 3, 0, 0, 0]     # m = 16: 5 of 16 tables
+    finally:
+        set_tuning("ORDER_GREEDY", 1)
+    p = plan(1_000_000, 16)
+    assert p[:8] == [3, 3, 3, 3, 0, 0, 0, 0] and p[12] == 12 and 8 <= p[13] <= 16
+    assert plan(1_000_000, 4)[12] == 0                             # 4-byte rows: the key covers every table already
     p = plan(125_000_000, 8)                       # the per-GPU shard of BASELINE config 5: 22 bits
     assert p[:8] == [3, 3, 3, 3, 3, 3, 3, 1] and p[8] == 22
     assert plan(1_000_000_000, 8)[:9] == [3] * 8 + [24]            # every table conflict-free from 2^29 rows on
-    assert plan(1_000_000, 16)[:8] == [3, 3, 3, 3, 3, 0, 0, 0]     # m = 16: 5 of 16 tables
     assert plan(500, 8)[8] == 0                                    # tiny base: no ordering
     p = plan(200_000, 5)                                           # padded to 8 bytes; 15/16 of the rows are sorted
     assert p[11] == 8 and p[8] in (12, 13) and p[:4] == [3, 3, 3, 3]
