@@ -23,7 +23,7 @@ class _Tuning:
         defaults = {"SCAN_ORDER": 1, "ORDER_MIN_ROWS": 65536, "ORDER_MIN_NQ": 2048, "ORDER_BITS": 0, "ORDER_GRAN": 0,
                     "ORDER_SHUFFLE": 1, "SCAN_SRANK_MUL": 2, "SCAN_SLACK": 0, "SCAN_SLICES": 0, "SCAN_FILTER": 1,
                     "SCAN_RETUNE_Z": 6, "INDEX_ORDER": 1, "SCAN_XCD_MIN_MB": 0, "SCAN_WINDOW_MB": 0, "ORDER_SAMPLE_STRIDE": 16,
-                    "SCAN_STATS": 0, "SCAN_BUCKET_FINISH": 1, "SCAN_SS_MAP": 1}
+                    "SCAN_STATS": 0, "SCAN_BUCKET_FINISH": 1, "SCAN_SS_MAP": 1, "ORDER_GREEDY": 1, "ORDER_GREEDY_MIN_NQ": 16384}
         for k in self.kv:
             self.rq.set_tuning(k, defaults[k])
 
@@ -62,6 +62,43 @@ def test_order_rows_is_a_permutation_with_fewer_bank_conflicts(rq, n, m):
         # n = 1e6, m = 8: 3.15 -> 1.94 passes per gather (5 of 8 byte tables conflict-free)
         # (a sixteenth of the rows -- the arrival-order sample blocks -- keeps the old rate)
         assert after < (0.70 if m == 8 else 0.87) * before, (before, after)
+
+
+@pytest.mark.parametrize("m", [8, 16])
+@pytest.mark.parametrize("kind", ["uniform", "dups", "skew", "clumps"])
+def test_greedy_balance_is_a_permutation_and_lowers_the_passes(rq, oracle, kind, m):
+    """Round 6: where the key covers 4 tables (8- and 16-byte rows from ~8e5 rows on) the rows of every sort bucket are dealt to
+    the bucket's lane groups by a greedy pass over the uncovered tables (order_fine_greedy_kernel).  Whatever it does must be
+    a permutation -- the scan's answer then cannot depend on it --; on uniform codes it must beat the plain 15-bit sort in the
+    LDS-pass model; hostile bases (60 distinct rows, half of the rows in one bucket, 4096 tight clumps) send coarse buckets
+    past the LDS list (plain path) or whole buckets into one window after the other."""
+    import torch
+    from rayuela_jl_amd import device as rqd
+    rng = np.random.default_rng(600 + m)
+    n, sub, nq, K = 1_000_000, 2, 8, 100
+    if kind == "clumps":
+        pool = rng.integers(0, 256, (4096, m), dtype=np.uint8)
+        codes = pool[rng.integers(0, 4096, n)]
+        codes[:, m - 1] = rng.integers(0, 256, n, dtype=np.uint8)        # ... that differ in their last byte only
+    else:
+        codes = _hostile_codes(kind, n, m, rng)
+    cd = torch.from_numpy(codes).cuda()
+    res = {}
+    for greedy in (0, 1):
+        with _Tuning(rq, ORDER_GREEDY=greedy):
+            ob = rqd.order_rows(cd)
+        oc, perm = ob.codes.cpu().numpy(), ob.perm.cpu().numpy().view(np.uint32).astype(np.int64)
+        assert np.array_equal(np.sort(perm), np.arange(n)), (kind, m, greedy)
+        assert np.array_equal(oc[:, :m], codes[perm]), (kind, m, greedy)
+        res[greedy] = (ob, _lds_passes(oc[:, :m], 2 if m == 8 else 1))
+    if kind == "uniform":
+        # m = 8: 1.94 -> 1.63 passes per gather (tables 4..7: 3.15 -> 2.2 each); m = 16: 2.54 -> 2.14
+        assert res[1][1] < 0.90 * res[0][1], (m, res[0][1], res[1][1])
+    centers = rng.standard_normal((m, 256, sub)).astype(np.float32)
+    queries = rng.standard_normal((nq, m * sub)).astype(np.float32)
+    d0, i0 = oracle.linscan_aqd_query(codes, centers, queries, K)
+    d1, i1 = rqd.linscan(res[1][0], torch.from_numpy(centers).cuda(), torch.from_numpy(queries).cuda(), K)
+    assert np.array_equal(i1.cpu().numpy().view(np.uint32), i0) and _eq_bits(d1.cpu().numpy(), d0), (kind, m)
 
 
 def _hostile_codes(kind, n, m, rng):
