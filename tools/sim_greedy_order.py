@@ -1,4 +1,31 @@
-import numpy as np, sys, time
+#!/usr/bin/env python3
+"""Round 6 (EXPERIMENTS.md 9.7), CPU only: LDS-pass model of the greedy balance of the row order.  The bench codes (SIFT1M shape,
+encoded by the oracle) are sorted by a key of `bits`, then the rows of every bucket are dealt to the lane groups the bucket holds
+(capacities of boundary groups respected, arrival order, cost = sum over the free tables of the marginal (column load)^2, equal
+bytes free) and the passes per row and lane group are compared with the plain sort.  m = 16: uniform random codes.
+usage: python tools/sim_greedy_order.py [codes.npy]   (without a file the 1e6 x 8 bench codes are generated first: ~1 min)"""
+import os
+import sys
+
+sys.path.insert(0, os.getcwd())
+
+
+def bench_codes():
+    import rayuela_jl_amd.synth as synth
+    from oracle import oracle
+    n, d, m, h = 1_000_000, 128, 8, 256
+    S = synth.sift_like(20000, d, seed=synth.SEED_BASE, ncentres=65536, row0=3_100_000_000)
+    C = synth.codebooks(S, m, h, seed=synth.SEED_CODEBOOK, iters=5, sample=20000)
+    Cc = synth.cat_codebooks(C)
+    out = np.empty((n, m), np.uint8)
+    for a in range(0, n, 250000):
+        out[a:a + 250000] = oracle.encode_pq(synth.sift_like(250000, d, seed=synth.SEED_BASE, ncentres=65536, row0=a), Cc, m, h)
+    return out
+
+
+import time
+
+import numpy as np
 rng=np.random.default_rng(0)
 def group_passes(g):
     G,_,m=g.shape; out=np.zeros((G,m))
@@ -44,7 +71,7 @@ def run(codes,bits,tables,nb_sample,label):
     p=group_passes(gg)
     base_p=group_passes(codes[o[s_lo+a:s_lo+a+b]].reshape(-1,32,m))
     print(label,"bits",bits[:6],"greedy",T,"tables: passes",p.mean(0).round(2),"sum %.2f"%p.sum(1).mean(),"| same sort without greedy %.2f"%base_p.sum(1).mean(),flush=True)
-codes=np.load('/tmp/sim/codes.npy')
+codes = np.load(sys.argv[1]) if len(sys.argv) > 1 else bench_codes()
 o15=None
 run(codes,[3,3,3,3,3,0,0,0],[5,6,7],600,"m8")
 run(codes,[3,3,3,3,0,0,0,0],[4,5,6,7],150,"m8")
