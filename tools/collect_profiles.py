@@ -23,7 +23,7 @@ for w in ("pq", "opq", "deep", "k10000", "sift1b", "sift1b_shard", "train_opq"):
     rows = list(csv.reader(open(g[0])))
     csv.writer(open("profiles/%s_bench_%s_kernel_stats.csv" % (RND, w), "w")).writerows([rows[0]] + [r for r in rows[1:] if "rq::" in r[0]])
 shutil.copy(O + "/pmc_summary.txt", "profiles/%s_pmc_counters.md" % RND)
-for extra in ("phase_clock.md", "m4_filter.md", "shape_sweep.md"):
+for extra in ("phase_clock.md", "m4_filter.md", "shape_sweep.md", "greedy_order.md"):
     if os.path.exists(O + "/" + extra):
         shutil.copy(O + "/" + extra, "profiles/%s_%s" % (RND, extra))
 if os.path.exists(O + "/index_overhead.md"):

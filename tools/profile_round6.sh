@@ -52,6 +52,7 @@ for t in "pq:" "k10000:--k 10000" "deep:--workload deep"; do
   RQ_SCAN_STATS=1 python bench.py ${t#*:} --no-cpu --no-host --no-ref1 --no-ab --steps 3 2> $O/phase_${t%%:*}.err > /dev/null
 done
 python tools/phase_clock.py $O > $O/phase_clock.md
+( echo "# the balanced row order against the plain sort (tools/greedy_order_ab.py): pass model, ordering time, scan on the prepared base and inside a 1e4-query call"; echo; echo '```'; python tools/greedy_order_ab.py 8 2>/dev/null | grep 'm='; python tools/greedy_order_ab.py 16 2>/dev/null | grep 'm=\|^ '; echo '```' ) > $O/greedy_order.md
 ( echo "# m = 4: the integer pre-filter on / off (tools/m4_filter_ab.py; random codes, Gaussian tables; resident; HIP events)"; echo; echo '```'; python tools/m4_filter_ab.py 2>/dev/null; echo '```' ) > $O/m4_filter.md
 cd /tmp
 if [ "$1" != "quick" ]; then
