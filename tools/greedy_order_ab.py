@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round 6: the greedy balance of the row order (csrc/rq_order.hip: order_fine_greedy_kernel) against the plain 15-bit sort
 (ORDER_GREEDY = 0) on the bench data: LDS passes per row and lane group (host model on the ordered codes), time of the ordering,
-scan times on the prepared base and with the ordering inside the call; answers compared.   usage: python tools/greedy_order_ab.py [8|16|4] [n]"""
+scan times on the prepared base and with the ordering inside the call; answers compared.   usage: python tools/greedy_order_ab.py [8|16] [n] [nq]"""
 import os
 import sys
 
@@ -17,7 +17,7 @@ from rayuela_jl_amd import device as rqd, _lib   # noqa: E402
 dev = torch.device("cuda", 0)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
-nq = 10_000
+nq = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000
 
 
 def bench(fn, iters=10, warm=3):
